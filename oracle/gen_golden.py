@@ -1,0 +1,229 @@
+"""TEST INFRASTRUCTURE -- generate tests/golden/*.npz by running the IMPORTED REFERENCE.
+
+Runs only in the build container (needs /root/reference).  The reference source never
+enters the repo: what is committed is this script plus the small input/output vectors it
+writes.  Weights are NOT stored -- they are regenerated from a seed by
+gsv_tts_lite_amd.synth on every box (bit-identical by construction).
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Each fixture records torch version / thread count (the reference's numbers are tied to
+this torch build's CPU kernels).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "gsv-tts-lite_amd"))
+
+from ref_harness import import_reference  # noqa: E402
+from gsv_tts_lite_amd import synth  # noqa: E402
+
+import tqdm  # noqa: E402
+import functools  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+META = dict(torch_version=torch.__version__, threads=torch.get_num_threads())
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def build_ref_gpt(T2S, cfg, weights, gpt_cache):
+    m = T2S(cfg)
+    m.load_state_dict({k: tt(v) for k, v in weights.items()})
+    m.eval()
+    m.initialize_runtime(torch.float32, torch.device("cpu"), gpt_cache)
+    # the reference allocates its KV roots with torch.empty: stale NaNs times a zero
+    # probability poison SDPA outputs.  Zero them so the fixtures are reproducible.
+    with torch.inference_mode():
+        for b, bks in m.cuda_graph_buckets.items():
+            bks[-1].k_cache.zero_()
+            bks[-1].v_cache.zero_()
+            bks[-1].kv_cache_len.zero_()
+    return m
+
+
+def with_margins(m):
+    margins = []
+    orig = m.ar_predict_layer.forward
+
+    def hook(h):
+        l = orig(h)
+        t = torch.topk(l, 2, dim=-1).values
+        margins.append((t[..., 0] - t[..., 1]).min().item())
+        return l
+
+    m.ar_predict_layer.forward = hook
+    return margins
+
+
+def gen_t2s_layers(T2S):
+    """Per-layer numerics: prefill (single + packed batch) and one decode step, 3 layers."""
+    cfg = synth.gpt_config(n_layer=3)
+    w = synth.gpt_weights(cfg, seed=11)
+    m = build_ref_gpt(T2S, cfg, w, [(1, 96), (2, 96)])
+    out = {}
+    with torch.inference_mode():
+        x, y, bert, _ = synth.synth_request(0, 9, 14, 14, seed=11, bert="random")
+        xy, mask = m.process_single_data(tt(x)[None], tt(y)[None], tt(bert)[None])
+        bk = m.cuda_graph_buckets[1][-1]
+        h = m.t2s_transformer.process_prompt(xy, bk.k_cache, bk.v_cache, bk.kv_cache_len, mask)
+        out.update(s_x=x, s_y=y, s_bert=bert, s_xy=xy.numpy(), s_mask=mask[0, 0].numpy().astype(np.uint8),
+                   s_hidden=h.numpy(), s_k=bk.k_cache[:, 0, :, :37].numpy().copy(),
+                   s_v=bk.v_cache[:, 0, :, :37].numpy().copy())
+        # one decode step on top of that prefill
+        L = xy.shape[1]
+        xin = tt(synth.hashed_uniform("dec.x", (1, 1, 512), 11))
+        bk.decode_attn_mask.fill_(False)
+        bk.decode_attn_mask[:, :, :, : L + 1] = True
+        hd = m.t2s_transformer.decode_next_token(xin, bk.k_cache, bk.v_cache, bk.kv_cache_len,
+                                                 bk.decode_attn_mask, bk.batch_indices)
+        out.update(d_x=xin.numpy(), d_hidden=hd.numpy(), d_k_new=bk.k_cache[:, 0, :, L].numpy().copy())
+        # packed batch of two rows with different lengths
+        reqs = [synth.synth_request(1, 7, 10, 12, seed=11, bert="random"),
+                synth.synth_request(2, 9, 17, 15, seed=11, bert="random")]
+        from torch.nn.utils.rnn import pad_sequence
+        bx = pad_sequence([tt(r[0]) for r in reqs], batch_first=True)
+        by = pad_sequence([tt(r[1]) for r in reqs], batch_first=True)
+        bb = pad_sequence([tt(r[2]) for r in reqs], batch_first=True)
+        xl = torch.tensor([[len(r[0])] for r in reqs]); yl = torch.tensor([[len(r[1])] for r in reqs])
+        bxy, last, bmask = m.process_batch_data(bx, by, bb, xl, yl)
+        bk2 = m.cuda_graph_buckets[2][-1]
+        bh = m.t2s_transformer.process_prompt(bxy, bk2.k_cache, bk2.v_cache, bk2.kv_cache_len, bmask)
+        for i, r in enumerate(reqs):
+            out["b%d_x" % i], out["b%d_y" % i], out["b%d_bert" % i] = r[0], r[1], r[2]
+        out.update(b_xy=bxy.numpy(), b_mask=bmask[:, 0].numpy().astype(np.uint8), b_hidden=bh.numpy(),
+                   b_last=last.numpy().astype(np.uint8))
+    np.savez_compressed(os.path.join(GOLD, "t2s_layers.npz"), seed=11, **META, **out)
+    print("t2s_layers ok")
+
+
+def gen_t2s_infer(T2S):
+    cfg = synth.gpt_config()
+    out = {}
+    cases = [  # name, weight seed, eos_gain, (prompt_ph, text_ph, prompt_tok), buckets
+        ("a", 1234, 1.0, (12, 18, 25), [(1, 96), (1, 128)]),
+        ("b", 1234, 6.0, (10, 22, 30), [(1, 200)]),
+        ("c", 21, 1.0, (40, 60, 100), [(1, 256), (1, 288)]),
+    ]
+    for name, seed, eg, (p, t, n), cache in cases:
+        w = synth.gpt_weights(cfg, seed=seed, eos_gain=eg)
+        m = build_ref_gpt(T2S, cfg, w, cache)
+        margins = with_margins(m)
+        x, y, bert, _ = synth.synth_request(100 + len(out), p, t, n, seed=seed)
+        with torch.inference_mode():
+            tok = m.infer(tt(x)[None], tt(y)[None], tt(bert)[None], top_k=1)
+        out.update({name + "_x": x, name + "_y": y, name + "_tokens": tok[0, 0].numpy(),
+                    name + "_margins": np.array(margins, np.float32),
+                    name + "_cfg": np.array([seed, p, t, n], np.int64), name + "_eos_gain": eg,
+                    name + "_cache": np.array(cache, np.int64)})
+        print("infer case", name, "tokens", tok.shape[-1], "min margin", min(margins),
+              "distinct", len(set(tok[0, 0].tolist())))
+    np.savez_compressed(os.path.join(GOLD, "t2s_infer.npz"), **META, **out)
+
+
+def gen_t2s_batched(T2S):
+    cfg = synth.gpt_config()
+    out = {}
+    cases = [  # name, seed, eos_gain, [(p,t,n)...], buckets
+        ("r", 1234, 6.0, [(8, 14, 20), (10, 20, 28), (6, 12, 16), (9, 25, 22), (7, 10, 30)], [(2, 128), (2, 160)]),
+        ("s", 33, 1.0, [(8, 14, 20), (10, 20, 28), (6, 12, 16)], [(4, 96)]),
+    ]
+    for name, seed, eg, reqs, cache in cases:
+        w = synth.gpt_weights(cfg, seed=seed, eos_gain=eg)
+        m = build_ref_gpt(T2S, cfg, w, cache + [(1, cache[-1][1])])
+        margins = with_margins(m)
+        rs = [synth.synth_request(200 + i, p, t, n, seed=seed) for i, (p, t, n) in enumerate(reqs)]
+        with torch.inference_mode():
+            pred, orig = m.infer_batched([tt(r[0]) for r in rs], [tt(r[1]) for r in rs], [tt(r[2]) for r in rs], top_k=1)
+        out[name + "_n"] = len(rs)
+        out[name + "_reqs"] = np.array(reqs, np.int64)
+        out[name + "_seed"] = seed
+        out[name + "_eos_gain"] = eg
+        out[name + "_cache"] = np.array(cache, np.int64)
+        out[name + "_orig"] = orig.numpy()
+        out[name + "_margin_min"] = min(margins)
+        for i, p_ in enumerate(pred):
+            out["%s_tok%d" % (name, i)] = p_.numpy()
+        print("batched case", name, "orig", orig.tolist(), "lens", [len(p_) for p_ in pred], "min margin", min(margins))
+    np.savez_compressed(os.path.join(GOLD, "t2s_batched.npz"), **META, **out)
+
+
+def gen_sample(sample):
+    out = {}
+    g = np.random.default_rng(5)
+    for i, (kw, prev) in enumerate([
+        (dict(top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35), True),
+        (dict(top_k=5, top_p=0.8, temperature=0.7, repetition_penalty=1.2), True),
+        (dict(top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35), False),
+        (dict(top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=1.35), True),
+    ]):
+        lg = (g.standard_normal((3, 1025)) * 3).astype(np.float32)
+        lg[:, [280, 486]] = -np.inf
+        pv = g.integers(0, 1025, size=(3, 40)) if prev else None
+        torch.manual_seed(77 + i)
+        idx, probs = sample(tt(lg.copy()), tt(pv) if prev else None, **kw)
+        torch.manual_seed(77 + i)
+        q = torch.empty_like(probs).exponential_(1)
+        out.update({"c%d_logits" % i: lg, "c%d_q" % i: q.numpy(), "c%d_idx" % i: idx.numpy(),
+                    "c%d_probs" % i: probs.numpy(), "c%d_kw" % i: np.array([kw["top_k"], kw["top_p"], kw["temperature"], kw["repetition_penalty"]], np.float64)})
+        if prev:
+            out["c%d_prev" % i] = pv
+    np.savez_compressed(os.path.join(GOLD, "sample.npz"), **META, **out)
+    print("sample ok")
+
+
+def build_ref_sovits(Syn, hps, weights):
+    s = Syn(hps["data"]["filter_length"] // 2 + 1, hps["train"]["segment_size"] // hps["data"]["hop_length"],
+            n_speakers=hps["data"]["n_speakers"], **hps["model"])
+    s.load_state_dict({k: tt(v) for k, v in weights.items()}, strict=False)
+    s.dec.remove_weight_norm()
+    s.eval()
+    return s
+
+
+def gen_vocoder(Syn):
+    out = {}
+    for ver, T, per_frame in [("v2Pro", 50, False), ("v2Pro", 55, True), ("v2ProPlus", 50, False), ("v2", 23, False)]:
+        hps = synth.sovits_hps(ver)
+        w = synth.sovits_weights(hps, seed=1234)
+        # weights were generated for the weight-norm-removed `dec`; load AFTER removing it
+        s = Syn(hps["data"]["filter_length"] // 2 + 1, hps["train"]["segment_size"] // hps["data"]["hop_length"],
+                n_speakers=hps["data"]["n_speakers"], **hps["model"])
+        s.dec.remove_weight_norm()
+        s.load_state_dict({k: tt(v) for k, v in w.items()}, strict=False)
+        s.eval()
+        gin = hps["model"]["gin_channels"]
+        name = "%s_T%d_%s" % (ver, T, "pf" if per_frame else "c")
+        z = synth.hashed_uniform(name + ".z", (1, 192, T)) * np.float32(1.7)
+        mask = np.ones((1, 1, T), np.float32)
+        if per_frame:
+            ge = np.concatenate([np.repeat(synth.synth_ge(i, gin), n, axis=2) for i, n in ((0, 20), (1, T - 20))], axis=2)
+        else:
+            ge = synth.synth_ge(0, gin)
+        with torch.inference_mode():
+            zf = s.flow(tt(z), tt(mask), tt(ge))
+            o = s.flow_dec(tt(z), tt(mask), tt(ge))
+        out.update({name + "_z": z, name + "_ge": ge, name + "_flow": zf.numpy(), name + "_o": o.numpy()[0, 0]})
+        print("vocoder", name, "o std", o.std().item(), "max", o.abs().max().item())
+    np.savez_compressed(os.path.join(GOLD, "vocoder.npz"), seed=1234, **META, **out)
+
+
+if __name__ == "__main__":
+    tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
+    torch.manual_seed(0)
+    T2S, sample, Syn = import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["layers", "infer", "batched", "sample", "vocoder"]
+    if "layers" in which: gen_t2s_layers(T2S)
+    if "infer" in which: gen_t2s_infer(T2S)
+    if "batched" in which: gen_t2s_batched(T2S)
+    if "sample" in which: gen_sample(sample)
+    if "vocoder" in which: gen_vocoder(Syn)

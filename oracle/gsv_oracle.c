@@ -1,0 +1,489 @@
+/*
+ * TEST INFRASTRUCTURE -- CPU oracle for the GPT-SoVITS inference hot path.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+ * and bench.py's `cpu_baseline` leg may load it (see DESIGN.md "Oracle").  It is a
+ * plain-C, fp32 restatement of the arithmetic the reference performs through
+ * PyTorch on CPU, written from the reference's model definitions:
+ *
+ *   GPT block (post-LN, ReLU MLP)      gsv_tts/GPT_SoVITS/GPT/t2s_model.py:31-105
+ *   decode KV append + causal attention  t2s_model.py:80-92  (mask == positions [0, kv_len])
+ *   prefill with explicit bool mask      t2s_model.py:42-52, 365-381
+ *   WaveNet flow (reverse)               SoVITS/module/modules.py:80-104, 482-511; models.py:58-65
+ *   HiFiGAN-style Generator              SoVITS/models.py:113-132; modules.py:190-203
+ *
+ * Parity status: pinned against the imported reference in the build container by
+ * oracle/gen_golden.py -> tests/golden/*.npz (the reference ships no golden vectors of
+ * its own).  Summation order differs from torch's oneDNN/MKL
+ * kernels, so agreement is to fp32 round-off (tolerances live in tests/), while greedy
+ * token ids agree exactly wherever the recorded top-1/top-2 margin exceeds that noise.
+ *
+ * Layouts: activations row-major [rows][features]; conv tensors channels-first
+ * [C][T] exactly as torch; KV cache [layer][B][H][T][Dh] as t2s_model.py:269-270.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+ORC_API int orc_version(void) { return 1; }
+
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------ basic ops */
+
+static inline float dotf(const float* a, const float* b, int n) {
+    float acc = 0.f;
+#pragma omp simd reduction(+ : acc)
+    for (int i = 0; i < n; ++i) acc += a[i] * b[i];
+    return acc;
+}
+
+/* y[m][n] = sum_k x[m][k] * w[n][k] + b[n]   (torch nn.Linear) ; act: 0 none, 1 relu */
+ORC_API void orc_linear(const float* x, int M, int K, const float* w, const float* b, int N,
+                        float* y, int act) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float v = dotf(x + (size_t)m * K, w + (size_t)n * K, K) + (b ? b[n] : 0.f);
+            if (act == 1 && v < 0.f) v = 0.f;
+            y[(size_t)m * N + n] = v;
+        }
+}
+
+/* torch nn.LayerNorm over the last dim, biased variance, eps inside sqrt */
+ORC_API void orc_layernorm(const float* x, int M, int D, const float* g, const float* b, float eps,
+                           float* y) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        const float* r = x + (size_t)m * D;
+        float mean = 0.f;
+        for (int i = 0; i < D; ++i) mean += r[i];
+        mean /= (float)D;
+        float var = 0.f;
+        for (int i = 0; i < D; ++i) {
+            float d = r[i] - mean;
+            var += d * d;
+        }
+        var /= (float)D;
+        float rs = 1.0f / sqrtf(var + eps);
+        float* o = y + (size_t)m * D;
+        for (int i = 0; i < D; ++i) o[i] = (r[i] - mean) * rs * g[i] + b[i];
+    }
+}
+
+/* ------------------------------------------------------------------ GPT block
+ * Per-layer parameter pack (floats, in this order), D = hidden, F = 4*D:
+ *   qkv_w[3D][D] qkv_b[3D] out_w[D][D] out_b[D] ln1_g[D] ln1_b[D]
+ *   w1[F][D] b1[F] w2[D][F] b2[D] ln2_g[D] ln2_b[D]
+ */
+typedef struct {
+    const float *qkv_w, *qkv_b, *out_w, *out_b, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+} layer_t;
+
+ORC_API long orc_layer_floats(int D) {
+    long F = 4L * D;
+    return 3L * D * D + 3L * D + (long)D * D + D + 2L * D + F * D + F + (long)D * F + D + 2L * D;
+}
+
+static layer_t layer_at(const float* pack, int l, int D) {
+    const float* p = pack + (size_t)l * orc_layer_floats(D);
+    long F = 4L * D;
+    layer_t L;
+    L.qkv_w = p; p += 3L * D * D;
+    L.qkv_b = p; p += 3L * D;
+    L.out_w = p; p += (long)D * D;
+    L.out_b = p; p += D;
+    L.ln1_g = p; p += D;
+    L.ln1_b = p; p += D;
+    L.w1 = p; p += F * D;
+    L.b1 = p; p += F;
+    L.w2 = p; p += (long)D * F;
+    L.b2 = p; p += D;
+    L.ln2_g = p; p += D;
+    L.ln2_b = p;
+    return L;
+}
+
+/* tail of a block shared by prefill and decode: x = LN1(x + attn@Wo^T + bo); x = LN2(x + MLP(x)) */
+static void block_tail(const layer_t* L, int M, int D, float* x, const float* attn, float* tmp_d,
+                       float* tmp_f) {
+    int F = 4 * D;
+    orc_linear(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0);
+    for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
+    orc_layernorm(tmp_d, M, D, L->ln1_g, L->ln1_b, 1e-5f, x);
+    orc_linear(x, M, D, L->w1, L->b1, F, tmp_f, 1);
+    orc_linear(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0);
+    for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
+    orc_layernorm(tmp_d, M, D, L->ln2_g, L->ln2_b, 1e-5f, x);
+}
+
+/*
+ * One decode step through all layers for B rows (t2s_model.py:67-105, 129-143).
+ *   x      [B][D]   in: token input, out: final hidden
+ *   kc, vc [n_layer][Bc][H][T][Dh] caches; row b of x uses cache row b0+b
+ *   kv_len [B]      entries already in the cache; the new K/V land at kv_len[b] and the
+ *                   query attends to positions [0, kv_len[b]]  (the caller bumps kv_len)
+ */
+ORC_API void orc_t2s_decode(const float* pack, int n_layer, int D, int H, int B, float* x, float* kc,
+                            float* vc, int Bc, int T, int b0, const int64_t* kv_len) {
+    int Dh = D / H;
+    float scale = 1.0f / sqrtf((float)Dh);
+    float* qkv = (float*)malloc(sizeof(float) * (size_t)B * 3 * D);
+    float* attn = (float*)malloc(sizeof(float) * (size_t)B * D);
+    float* tmp_d = (float*)malloc(sizeof(float) * (size_t)B * D);
+    float* tmp_f = (float*)malloc(sizeof(float) * (size_t)B * 4 * D);
+    for (int l = 0; l < n_layer; ++l) {
+        layer_t L = layer_at(pack, l, D);
+        orc_linear(x, B, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                int n = (int)kv_len[b];
+                size_t base = ((((size_t)l * Bc + (b0 + b)) * H + h) * (size_t)T) * Dh;
+                float* K = kc + base;
+                float* V = vc + base;
+                const float* q = qkv + (size_t)b * 3 * D + h * Dh;
+                memcpy(K + (size_t)n * Dh, qkv + (size_t)b * 3 * D + D + h * Dh, sizeof(float) * Dh);
+                memcpy(V + (size_t)n * Dh, qkv + (size_t)b * 3 * D + 2 * D + h * Dh, sizeof(float) * Dh);
+                int len = n + 1;
+                float* s = (float*)malloc(sizeof(float) * len);
+                float mx = -INFINITY;
+                for (int t = 0; t < len; ++t) {
+                    s[t] = dotf(q, K + (size_t)t * Dh, Dh) * scale;
+                    if (s[t] > mx) mx = s[t];
+                }
+                float den = 0.f;
+                for (int t = 0; t < len; ++t) {
+                    s[t] = expf(s[t] - mx);
+                    den += s[t];
+                }
+                float* o = attn + (size_t)b * D + h * Dh;
+                for (int d = 0; d < Dh; ++d) o[d] = 0.f;
+                for (int t = 0; t < len; ++t) {
+                    float p = s[t] / den;
+                    const float* vr = V + (size_t)t * Dh;
+                    for (int d = 0; d < Dh; ++d) o[d] += p * vr[d];
+                }
+                free(s);
+            }
+        block_tail(&L, B, D, x, attn, tmp_d, tmp_f);
+    }
+    free(qkv); free(attn); free(tmp_d); free(tmp_f);
+}
+
+/*
+ * Prefill of B packed rows of length Lq through all layers (t2s_model.py:31-65,114-127).
+ *   x    [B][Lq][D] in/out
+ *   mask [B][Lq][Lq] bytes, nonzero = may attend (the reference's bool mask, one head's worth;
+ *        it is identical across heads, t2s_model.py:347,379).  A fully-masked query row yields
+ *        zeros (torch>=2.5 SDPA behaviour).
+ * Writes K/V for positions [0, Lq) of cache rows b0..b0+B-1.
+ */
+ORC_API void orc_t2s_prefill(const float* pack, int n_layer, int D, int H, int B, int Lq, float* x,
+                             const uint8_t* mask, float* kc, float* vc, int Bc, int T, int b0) {
+    int Dh = D / H;
+    float scale = 1.0f / sqrtf((float)Dh);
+    size_t M = (size_t)B * Lq;
+    float* qkv = (float*)malloc(sizeof(float) * M * 3 * D);
+    float* attn = (float*)malloc(sizeof(float) * M * D);
+    float* tmp_d = (float*)malloc(sizeof(float) * M * D);
+    float* tmp_f = (float*)malloc(sizeof(float) * M * 4 * D);
+    for (int l = 0; l < n_layer; ++l) {
+        layer_t L = layer_at(pack, l, D);
+        orc_linear(x, (int)M, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                size_t base = ((((size_t)l * Bc + (b0 + b)) * H + h) * (size_t)T) * Dh;
+                for (int t = 0; t < Lq; ++t) {
+                    const float* r = qkv + ((size_t)b * Lq + t) * 3 * D;
+                    memcpy(kc + base + (size_t)t * Dh, r + D + h * Dh, sizeof(float) * Dh);
+                    memcpy(vc + base + (size_t)t * Dh, r + 2 * D + h * Dh, sizeof(float) * Dh);
+                }
+                float* s = (float*)malloc(sizeof(float) * Lq);
+                for (int i = 0; i < Lq; ++i) {
+                    const float* q = qkv + ((size_t)b * Lq + i) * 3 * D + h * Dh;
+                    const uint8_t* mr = mask + ((size_t)b * Lq + i) * Lq;
+                    float mx = -INFINITY;
+                    for (int t = 0; t < Lq; ++t) {
+                        if (mr[t]) {
+                            s[t] = dotf(q, kc + base + (size_t)t * Dh, Dh) * scale;
+                            if (s[t] > mx) mx = s[t];
+                        }
+                    }
+                    float* o = attn + ((size_t)b * Lq + i) * D + h * Dh;
+                    for (int d = 0; d < Dh; ++d) o[d] = 0.f;
+                    if (mx == -INFINITY) continue;
+                    float den = 0.f;
+                    for (int t = 0; t < Lq; ++t)
+                        if (mr[t]) {
+                            s[t] = expf(s[t] - mx);
+                            den += s[t];
+                        }
+                    for (int t = 0; t < Lq; ++t)
+                        if (mr[t]) {
+                            float p = s[t] / den;
+                            const float* vr = vc + base + (size_t)t * Dh;
+                            for (int d = 0; d < Dh; ++d) o[d] += p * vr[d];
+                        }
+                }
+                free(s);
+            }
+        block_tail(&L, (int)M, D, x, attn, tmp_d, tmp_f);
+    }
+    free(qkv); free(attn); free(tmp_d); free(tmp_f);
+}
+
+/* ------------------------------------------------------------------ conv primitives (channels-first) */
+
+/* torch F.conv1d, stride 1, zero padding pad on both sides, dilation dil. out length == T
+ * when pad == dil*(k-1)/2.  in_slope: leaky-relu slope applied to the input first (1.0 = none). */
+ORC_API void orc_conv1d(const float* x, int Cin, int T, const float* w, const float* b, int Cout, int k,
+                        int dil, int pad, float in_slope, float* y) {
+    float* xin = (float*)x;
+    float* act = NULL;
+    if (in_slope != 1.0f) {
+        act = (float*)malloc(sizeof(float) * (size_t)Cin * T);
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < Cin; ++c)
+            for (int t = 0; t < T; ++t) {
+                float v = x[(size_t)c * T + t];
+                act[(size_t)c * T + t] = v >= 0.f ? v : v * in_slope;
+            }
+        xin = act;
+    }
+    const int TB = 1024;
+    int nco = (Cout + 3) / 4, ntb = (T + TB - 1) / TB;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int cb = 0; cb < nco; ++cb)
+        for (int tb = 0; tb < ntb; ++tb) {
+            int t0 = tb * TB, t1 = t0 + TB < T ? t0 + TB : T;
+            int c0 = cb * 4, nc = Cout - c0 < 4 ? Cout - c0 : 4;
+            float acc[4][1024];
+            for (int j = 0; j < 4; ++j) {
+                float bv = (b && j < nc) ? b[c0 + j] : 0.f;
+                for (int t = 0; t < t1 - t0; ++t) acc[j][t] = bv;
+            }
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float* xr = xin + (size_t)ci * T;
+                for (int kk = 0; kk < k; ++kk) {
+                    int off = kk * dil - pad;
+                    int lo = t0 + off < 0 ? -off : t0;          /* first t with t+off >= 0 */
+                    int hi = t1 + off > T ? T - off : t1;        /* last t (excl) with t+off < T */
+                    if (lo >= hi) continue;
+                    float w0 = w[((size_t)(c0 + 0) * Cin + ci) * k + kk];
+                    float w1 = nc > 1 ? w[((size_t)(c0 + 1) * Cin + ci) * k + kk] : 0.f;
+                    float w2 = nc > 2 ? w[((size_t)(c0 + 2) * Cin + ci) * k + kk] : 0.f;
+                    float w3 = nc > 3 ? w[((size_t)(c0 + 3) * Cin + ci) * k + kk] : 0.f;
+                    const float* xs = xr + off;
+#pragma omp simd
+                    for (int t = lo; t < hi; ++t) {
+                        float xv = xs[t];
+                        acc[0][t - t0] += w0 * xv;
+                        acc[1][t - t0] += w1 * xv;
+                        acc[2][t - t0] += w2 * xv;
+                        acc[3][t - t0] += w3 * xv;
+                    }
+                }
+            }
+            for (int j = 0; j < nc; ++j)
+                memcpy(y + (size_t)(c0 + j) * T + t0, acc[j], sizeof(float) * (t1 - t0));
+        }
+    free(act);
+}
+
+/* torch F.conv_transpose1d, weight [Cin][Cout][k], stride u, padding pad; Tout = (T-1)*u - 2*pad + k.
+ * in_slope as above. */
+ORC_API void orc_conv_transpose1d(const float* x, int Cin, int T, const float* w, const float* b,
+                                  int Cout, int k, int u, int pad, float in_slope, float* y) {
+    int Tout = (T - 1) * u - 2 * pad + k;
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < Cout; ++co) {
+        float* yr = y + (size_t)co * Tout;
+        float bv = b ? b[co] : 0.f;
+        for (int n = 0; n < Tout; ++n) yr[n] = bv;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xr = x + (size_t)ci * T;
+            const float* wr = w + ((size_t)ci * Cout + co) * k;
+            for (int i = 0; i < T; ++i) {
+                float xv = xr[i];
+                if (in_slope != 1.0f && xv < 0.f) xv *= in_slope;
+                int n0 = i * u - pad;
+                for (int kk = 0; kk < k; ++kk) {
+                    int n = n0 + kk;
+                    if (n >= 0 && n < Tout) yr[n] += xv * wr[kk];
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ Generator (models.py:113-132)
+ * Parameter pack order (floats): conv_pre.w[C0][Cz][7] conv_pre.b[C0] cond.w[C0][gin] cond.b[C0]
+ *   for stage i: ups.w[Cin][Cout][k_i] ups.b[Cout]
+ *                for j in 0..2 (resblock kernel rk_j): for d in 0..2: convs1[d].w[C][C][rk] convs1[d].b[C]
+ *                                                      then for d in 0..2: convs2[d].w convs2[d].b
+ *   conv_post.w[1][C5][7]
+ * g: [gin][Tg] with Tg == 1 (broadcast) or Tg == T (per-frame cond, batched path TTS.py:740-744).
+ */
+ORC_API void orc_generator(const float* pack, int Cz, int C0, int gin, int n_up, const int* up_rates,
+                           const int* up_kernels, int n_rk, const int* rk, const int* rdil /*[3]*/,
+                           const float* z /*[Cz][T]*/, int T, const float* g, int Tg,
+                           float* out /*[T*prod(up)]*/) {
+    const float* p = pack;
+    const float* pre_w = p; p += (size_t)C0 * Cz * 7;
+    const float* pre_b = p; p += C0;
+    const float* cond_w = p; p += (size_t)C0 * gin;
+    const float* cond_b = p; p += C0;
+    float* x = (float*)malloc(sizeof(float) * (size_t)C0 * T);
+    orc_conv1d(z, Cz, T, pre_w, pre_b, C0, 7, 1, 3, 1.0f, x);
+    {
+        float* c = (float*)malloc(sizeof(float) * (size_t)C0 * Tg);
+        orc_conv1d(g, gin, Tg, cond_w, cond_b, C0, 1, 1, 0, 1.0f, c);
+        for (int co = 0; co < C0; ++co)
+            for (int t = 0; t < T; ++t) x[(size_t)co * T + t] += c[(size_t)co * Tg + (Tg == 1 ? 0 : t)];
+        free(c);
+    }
+    int C = C0, Tc = T;
+    for (int i = 0; i < n_up; ++i) {
+        int u = up_rates[i], k = up_kernels[i], Co = C / 2;
+        const float* uw = p; p += (size_t)C * Co * k;
+        const float* ub = p; p += Co;
+        int Tn = Tc * u;
+        float* y = (float*)malloc(sizeof(float) * (size_t)Co * Tn);
+        orc_conv_transpose1d(x, C, Tc, uw, ub, Co, k, u, (k - u) / 2, 0.1f, y);
+        free(x);
+        C = Co; Tc = Tn;
+        size_t n = (size_t)C * Tc;
+        float* xs = (float*)calloc(n, sizeof(float));
+        float* xr = (float*)malloc(sizeof(float) * n);
+        float* t1 = (float*)malloc(sizeof(float) * n);
+        float* t2 = (float*)malloc(sizeof(float) * n);
+        for (int j = 0; j < n_rk; ++j) {
+            int kk = rk[j];
+            const float* w1[3]; const float* b1[3]; const float* w2[3]; const float* b2[3];
+            for (int d = 0; d < 3; ++d) { w1[d] = p; p += (size_t)C * C * kk; b1[d] = p; p += C; }
+            for (int d = 0; d < 3; ++d) { w2[d] = p; p += (size_t)C * C * kk; b2[d] = p; p += C; }
+            memcpy(xr, y, sizeof(float) * n);
+            for (int d = 0; d < 3; ++d) {
+                orc_conv1d(xr, C, Tc, w1[d], b1[d], C, kk, rdil[d], rdil[d] * (kk - 1) / 2, 0.1f, t1);
+                orc_conv1d(t1, C, Tc, w2[d], b2[d], C, kk, 1, (kk - 1) / 2, 0.1f, t2);
+                for (size_t e = 0; e < n; ++e) xr[e] = t2[e] + xr[e];
+            }
+            for (size_t e = 0; e < n; ++e) xs[e] += xr[e];
+        }
+        for (size_t e = 0; e < n; ++e) xs[e] = xs[e] / (float)n_rk;
+        free(xr); free(t1); free(t2); free(y);
+        x = xs;
+    }
+    /* F.leaky_relu default slope 0.01 (models.py:128), conv_post without bias, tanh */
+    float* o = (float*)malloc(sizeof(float) * (size_t)Tc);
+    orc_conv1d(x, C, Tc, p, NULL, 1, 7, 1, 3, 0.01f, o);
+    for (int t = 0; t < Tc; ++t) out[t] = tanhf(o[t]);
+    free(o); free(x);
+}
+
+/* ------------------------------------------------------------------ Flow, reverse (appendix A.6)
+ * Per coupling layer pack (weights already weight-norm folded by the caller: W = g * v/||v||):
+ *   pre.w[H][half] pre.b[H] cond.w[8H][gin] cond.b[8H]
+ *   for l in 0..3: in.w[2H][H][5] in.b[2H] rs.w[R][H] rs.b[R]   (R = 2H for l<3, H for l==3)
+ *   post.w[half][H] post.b[half]
+ * x [C][T] in/out (C = 2*half), mask [T], g [gin][Tg].  Order: Flip, RCL3, Flip, RCL2, ... RCL0.
+ */
+ORC_API long orc_flow_layer_floats(int half, int H, int gin) {
+    long n = (long)H * half + H + 8L * H * gin + 8L * H;
+    for (int l = 0; l < 4; ++l) {
+        long R = l < 3 ? 2L * H : H;
+        n += 2L * H * H * 5 + 2L * H + R * H + R;
+    }
+    n += (long)half * H + half;
+    return n;
+}
+
+ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, int gin, float* x, int T,
+                              const float* mask, const float* g, int Tg) {
+    int C = 2 * half;
+    size_t HT = (size_t)H * T;
+    float* h = (float*)malloc(sizeof(float) * HT);
+    float* outp = (float*)malloc(sizeof(float) * HT);
+    float* a = (float*)malloc(sizeof(float) * 2 * HT);
+    float* acts = (float*)malloc(sizeof(float) * HT);
+    float* rs = (float*)malloc(sizeof(float) * 2 * HT);
+    float* gc = (float*)malloc(sizeof(float) * (size_t)8 * H * Tg);
+    float* m = (float*)malloc(sizeof(float) * (size_t)half * T);
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)C * T);
+    for (int f = n_flows - 1; f >= 0; --f) {
+        /* Flip: reverse channel order (modules.py:504-511) */
+        for (int c = 0; c < C; ++c) memcpy(tmp + (size_t)c * T, x + (size_t)(C - 1 - c) * T, sizeof(float) * T);
+        memcpy(x, tmp, sizeof(float) * (size_t)C * T);
+        const float* p = pack + (size_t)f * orc_flow_layer_floats(half, H, gin);
+        const float* pre_w = p; p += (size_t)H * half;
+        const float* pre_b = p; p += H;
+        const float* cond_w = p; p += (size_t)8 * H * gin;
+        const float* cond_b = p; p += 8 * H;
+        /* h = pre(x0) * mask */
+        orc_conv1d(x, half, T, pre_w, pre_b, H, 1, 1, 0, 1.0f, h);
+        for (int c = 0; c < H; ++c)
+            for (int t = 0; t < T; ++t) h[(size_t)c * T + t] *= mask[t];
+        orc_conv1d(g, gin, Tg, cond_w, cond_b, 8 * H, 1, 1, 0, 1.0f, gc);
+        memset(outp, 0, sizeof(float) * HT);
+        for (int l = 0; l < 4; ++l) {
+            int R = l < 3 ? 2 * H : H;
+            const float* in_w = p; p += (size_t)2 * H * H * 5;
+            const float* in_b = p; p += 2 * H;
+            const float* rs_w = p; p += (size_t)R * H;
+            const float* rs_b = p; p += R;
+            orc_conv1d(h, H, T, in_w, in_b, 2 * H, 5, 1, 2, 1.0f, a);
+            for (int c = 0; c < H; ++c)
+                for (int t = 0; t < T; ++t) {
+                    int tg = Tg == 1 ? 0 : t;
+                    float ta = a[(size_t)c * T + t] + gc[(size_t)(l * 2 * H + c) * Tg + tg];
+                    float sa = a[(size_t)(H + c) * T + t] + gc[(size_t)(l * 2 * H + H + c) * Tg + tg];
+                    acts[(size_t)c * T + t] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
+                }
+            orc_conv1d(acts, H, T, rs_w, rs_b, R, 1, 1, 0, 1.0f, rs);
+            if (l < 3) {
+                for (int c = 0; c < H; ++c)
+                    for (int t = 0; t < T; ++t) {
+                        h[(size_t)c * T + t] = (h[(size_t)c * T + t] + rs[(size_t)c * T + t]) * mask[t];
+                        outp[(size_t)c * T + t] += rs[(size_t)(H + c) * T + t];
+                    }
+            } else {
+                for (size_t e = 0; e < HT; ++e) outp[e] += rs[e];
+            }
+        }
+        for (int c = 0; c < H; ++c)
+            for (int t = 0; t < T; ++t) outp[(size_t)c * T + t] *= mask[t];
+        const float* post_w = p; p += (size_t)half * H;
+        const float* post_b = p; p += half;
+        orc_conv1d(outp, H, T, post_w, post_b, half, 1, 1, 0, 1.0f, m);
+        /* x1 = (x1 - m*mask) * exp(-0) * mask */
+        for (int c = 0; c < half; ++c)
+            for (int t = 0; t < T; ++t) {
+                float mm = m[(size_t)c * T + t] * mask[t];
+                float* x1 = x + (size_t)(half + c) * T + t;
+                *x1 = (*x1 - mm) * mask[t];
+            }
+    }
+    free(h); free(outp); free(a); free(acts); free(rs); free(gc); free(m); free(tmp);
+}

@@ -1,0 +1,447 @@
+"""TEST INFRASTRUCTURE -- Python face of the CPU oracle (see gsv_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The heavy arithmetic is the C restatement in gsv_oracle.c (loaded through ctypes); the
+control flow below restates the reference's AR drivers and sampling in numpy:
+
+  sampling        gsv_tts/GPT_SoVITS/GPT/utils.py:5-59
+  embeddings/PE   gsv_tts/GPT_SoVITS/GPT/embedding.py:52-75, t2s_model.py:351-361
+  masks           t2s_model.py:300-349 (batched), 365-381 (single)
+  infer           t2s_model.py:385-464
+  infer_batched   t2s_model.py:555-734
+  flow_dec        SoVITS/models.py:380-383
+
+Parity status: pinned to the imported reference by oracle/gen_golden.py (fixtures in
+tests/golden/); the reference itself ships no tests or golden vectors.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i = ctypes.POINTER(ctypes.c_int)
+c_u8 = ctypes.POINTER(ctypes.c_uint8)
+c_i64 = ctypes.POINTER(ctypes.c_int64)
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libgsv_oracle.so")
+    src = os.path.join(_HERE, "gsv_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgsv_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libgsv_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_layer_floats.restype = ctypes.c_long
+        _LIB.orc_flow_layer_floats.restype = ctypes.c_long
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_f)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int):
+    lib().orc_set_num_threads(int(n))
+
+
+# ----------------------------------------------------------------------------- sampling
+
+def logits_to_probs(logits, previous_tokens=None, temperature=1.0, top_k=None, top_p=None,
+                    repetition_penalty=1.0):
+    """GPT/utils.py:12-49.  logits float32 [B, V] (modified in place like the reference)."""
+    if previous_tokens is not None and repetition_penalty != 1.0:
+        score = np.take_along_axis(logits, previous_tokens, axis=1)
+        score = np.where(score < 0, score * np.float32(repetition_penalty),
+                         score / np.float32(repetition_penalty)).astype(np.float32)
+        np.put_along_axis(logits, previous_tokens, score, axis=1)
+    if top_p is not None and top_p < 1.0:
+        order = np.argsort(-logits, axis=1, kind="stable")
+        sl = np.take_along_axis(logits, order, axis=1)
+        e = np.exp(sl - sl.max(axis=1, keepdims=True))
+        cum = np.cumsum(e / e.sum(axis=1, keepdims=True), axis=1)
+        rem = cum > top_p
+        rem[:, 0] = False
+        remove = np.zeros_like(rem)
+        np.put_along_axis(remove, order, rem, axis=1)
+        logits = np.where(remove, -np.inf, logits).astype(np.float32)
+    logits = (logits / np.float32(max(temperature, 1e-5))).astype(np.float32)
+    if top_k is not None:
+        k = min(top_k, logits.shape[-1])
+        pivot = np.sort(logits, axis=1)[:, -k][:, None]
+        logits = np.where(logits < pivot, -np.inf, logits).astype(np.float32)
+    m = logits.max(axis=1, keepdims=True)
+    e = np.exp(logits - m)
+    return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def sample(logits, previous_tokens=None, q=None, **kw):
+    """GPT/utils.py:52-59.  q: exponential(1) noise [B, V]; None -> ones, which equals the
+    reference whenever the kept set has a unique maximum (top_k=1)."""
+    probs = logits_to_probs(logits, previous_tokens, **kw)
+    if q is None:
+        q = np.ones_like(probs)
+    return np.argmax(probs / q, axis=-1)[:, None].astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- GPT
+
+_LAYER_KEYS = ["qkv.weight", "qkv.bias", "out_proj.weight", "out_proj.bias", "norm1.weight",
+               "norm1.bias", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+               "norm2.weight", "norm2.bias"]
+
+
+def sine_pe(n_pos: int, dim: int) -> np.ndarray:
+    """embedding.py:52-69, fp32."""
+    pos = np.arange(0, n_pos, dtype=np.float32)[:, None]
+    div = np.exp(np.arange(0, dim, 2, dtype=np.float32) * np.float32(-(math.log(10000.0) / dim)))
+    pe = np.zeros((n_pos, dim), dtype=np.float32)
+    pe[:, 0::2] = np.sin(pos * div)
+    pe[:, 1::2] = np.cos(pos * div)
+    return pe
+
+
+class T2SOracle:
+    def __init__(self, config, weights, gpt_cache):
+        m = config["model"]
+        self.D, self.H, self.NL = m["hidden_dim"], m["head"], m["n_layer"]
+        self.V, self.EOS = m["vocab_size"], m["EOS"]
+        self.suppressed = [280, 486, self.EOS]
+        w = {k: _f32(v) for k, v in weights.items()}
+        self.w = w
+        self.pack = np.concatenate([w["t2s_transformer.blocks.%d.%s" % (l, k)].ravel()
+                                    for l in range(self.NL) for k in _LAYER_KEYS])
+        assert self.pack.size == lib().orc_layer_floats(self.D) * self.NL
+        pe = sine_pe(4000, self.D)
+        self.pe_text = (w["ar_text_position.alpha"][0] * pe).astype(np.float32)
+        self.pe_audio = (w["ar_audio_position.alpha"][0] * pe).astype(np.float32)
+        self.buckets = {}
+        for b, t in gpt_cache:
+            self.buckets.setdefault(b, []).append(t)
+        for b in self.buckets:
+            self.buckets[b].sort()
+        self.cache = {}
+        for b, ts in self.buckets.items():
+            shape = (self.NL, b, self.H, ts[-1], self.D // self.H)
+            self.cache[b] = (np.zeros(shape, np.float32), np.zeros(shape, np.float32))
+        self.margins = []
+        self.raw_margins = []
+
+    # -- pieces -------------------------------------------------------------------------
+    def embed_text(self, x, bert):
+        w = self.w
+        e = w["ar_text_embedding.word_embeddings.weight"][x]
+        e = e + (bert @ w["bert_proj.weight"].T + w["bert_proj.bias"])
+        return (e * np.float32(1.0) + self.pe_text[: len(x)]).astype(np.float32)
+
+    def embed_audio(self, y):
+        e = self.w["ar_audio_embedding.word_embeddings.weight"][y]
+        return (e * np.float32(1.0) + self.pe_audio[: len(y)]).astype(np.float32)
+
+    def next_input(self, tok, pos):
+        """emb[tok]*1.0 + (alpha*pe)[pos]   t2s_model.py:420,456 (negative pos wraps like torch)."""
+        e = self.w["ar_audio_embedding.word_embeddings.weight"][tok]
+        return (e * np.float32(1.0) + self.pe_audio[pos]).astype(np.float32)
+
+    @staticmethod
+    def single_mask(lx, ly):
+        L = lx + ly
+        m = np.zeros((L, L), np.uint8)
+        m[:lx, :lx] = 1
+        m[lx:, :lx] = 1
+        m[lx:, lx:] = np.tril(np.ones((ly, ly), np.uint8))
+        return m
+
+    def logits(self, h):
+        # C path (not numpy/BLAS): a second thread pool inside the AR loop fights OpenMP's
+        h = np.ascontiguousarray(h, np.float32)
+        out = np.empty((h.shape[0], self.V), np.float32)
+        lib().orc_linear(_fp(h), h.shape[0], self.D, _fp(self.w["ar_predict_layer.weight"]), None, self.V,
+                         _fp(out), 0)
+        return out
+
+    def prefill(self, xy, mask, bsz, b0, nb=None):
+        """xy [B, L, D], mask [B, L, L] -> hidden [B, L, D]; K/V into cache rows b0.."""
+        kc, vc = self.cache[bsz]
+        xy = np.ascontiguousarray(xy, np.float32).copy()
+        mask = np.ascontiguousarray(mask, np.uint8)
+        B, L, _ = xy.shape
+        if L > kc.shape[3]:
+            raise ValueError("prompt longer than the largest KV bucket")
+        lib().orc_t2s_prefill(_fp(self.pack), self.NL, self.D, self.H, B, L, _fp(xy),
+                              mask.ctypes.data_as(c_u8), _fp(kc), _fp(vc), kc.shape[1], kc.shape[3], b0)
+        return xy
+
+    def decode(self, x, bsz, kv_len):
+        kc, vc = self.cache[bsz]
+        x = np.ascontiguousarray(x, np.float32).copy()
+        kv = np.ascontiguousarray(kv_len, np.int64)
+        lib().orc_t2s_decode(_fp(self.pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),
+                             kc.shape[1], kc.shape[3], 0, kv.ctypes.data_as(c_i64))
+        return x
+
+    def _margin(self, logits_row):
+        """decision margin: top-1 minus top-2 of the logits the argmax actually saw."""
+        t = np.sort(logits_row[np.isfinite(logits_row)])
+        self.margins.append(float(t[-1] - t[-2]))
+
+    def _raw(self, lg):
+        t = np.sort(lg, axis=-1)
+        self.raw_margins.append(float((t[:, -1] - t[:, -2]).min()))
+
+    # -- drivers ------------------------------------------------------------------------
+    def infer(self, x, y, bert, top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35,
+              initial_suppression_steps=10, check_interval=5, rng=None):
+        x = np.asarray(x, np.int64); y = np.asarray(y, np.int64)
+        lx, ly = len(x), len(y)
+        L = lx + ly
+        xy = np.concatenate([self.embed_text(x, _f32(bert)), self.embed_audio(y)])[None]
+        bks = self.buckets[1]
+        bi = len(bks) - 1
+        for i, t in enumerate(bks):
+            if t > L:
+                bi = i
+                break
+        kw = dict(top_k=top_k, top_p=top_p, temperature=temperature, repetition_penalty=repetition_penalty)
+        q = (lambda shape: rng.exponential(size=shape).astype(np.float32)) if rng is not None else (lambda s: None)
+        self.margins = []
+        self.raw_margins = []
+        h = self.prefill(xy, self.single_mask(lx, ly)[None], 1, 0)
+        kv = L
+        lg = self.logits(h[:, -1])
+        self._raw(lg)
+        lg[:, self.suppressed] = -np.inf
+        pre = y[None].copy()
+        view = lg[:, :-1].copy()
+        s = sample(view, pre, q=q(view.shape), **kw)
+        self._margin(view[0])
+        pre = np.concatenate([pre, s], axis=1)
+        xin = self.next_input(s[:, 0], kv - lx)
+        n_iter = bks[-1] - kv
+        idx = 0
+        for idx in range(1, n_iter + 1):
+            if kv == bks[bi]:
+                bi += 1
+            h = self.decode(xin, 1, [kv])
+            kv += 1
+            lg = self.logits(h)
+            self._raw(lg)
+            if idx < initial_suppression_steps:
+                lg[:, self.suppressed] = -np.inf
+            s = sample(lg, pre, q=q(lg.shape), **kw)
+            self._margin(lg[0])
+            pre = np.concatenate([pre, s], axis=1)
+            if idx % check_interval == 0 and s[0, 0] == self.EOS:
+                break
+            xin = self.next_input(s[:, 0], kv - lx)
+        if idx == 0:
+            raise RuntimeError("no decode iterations: prompt fills the largest bucket")
+        out = pre[0, -idx:]
+        e = np.nonzero(out == self.EOS)[0]
+        return out[: e[0]] if e.size else out
+
+    def infer_batched(self, xs, ys, berts, top_k=15, top_p=1.0, temperature=1.0,
+                      repetition_penalty=1.35, check_interval=5, rng=None):
+        B = len(xs)
+        sizes = sorted(self.buckets)
+        bsz = sizes[-1]
+        for s_ in sizes:
+            if s_ >= B:
+                bsz = s_
+                break
+        actual = min(B, bsz)
+        kw = dict(top_k=top_k, top_p=top_p, temperature=temperature, repetition_penalty=repetition_penalty)
+        q = (lambda shape: rng.exponential(size=shape).astype(np.float32)) if rng is not None else (lambda s: None)
+        x_lens = np.array([len(a) for a in xs[:bsz]], np.int64)
+        y_lens = np.array([len(a) for a in ys[:bsz]], np.int64)
+        xy_lens = x_lens + y_lens
+        Lmax = int(xy_lens.max())
+        xy = np.zeros((actual, Lmax, self.D), np.float32)
+        mask = np.zeros((actual, Lmax, Lmax), np.uint8)
+        for b in range(actual):
+            lx, ly = int(x_lens[b]), int(y_lens[b])
+            xy[b, :lx] = self.embed_text(np.asarray(xs[b], np.int64), _f32(berts[b]))
+            xy[b, lx:lx + ly] = self.embed_audio(np.asarray(ys[b], np.int64))
+            mask[b, :lx + ly, :lx + ly] = self.single_mask(lx, ly)
+        bks = self.buckets[bsz]
+        bi = len(bks) - 1
+        for i, t in enumerate(bks):
+            if t > Lmax:
+                bi = i
+                break
+        kv = np.zeros(bsz, np.int64)
+        cur = actual
+        pre = np.zeros((bsz, bks[-1]), np.int64)
+        h = self.prefill(xy, mask, bsz, 0)
+        last = h[np.arange(actual), xy_lens[:actual] - 1]
+        lg = self.logits(last)
+        kv[:actual] = xy_lens
+        view = lg[:, :-1].copy()
+        samples = sample(view, None, q=q(view.shape), **kw)
+        xin = np.zeros((bsz, self.D), np.float32)
+        xin[:actual] = self.next_input(samples[:, 0], kv[:actual] - x_lens)
+        x_lens = np.concatenate([x_lens, np.zeros(bsz - actual, np.int64)])
+        samples = np.concatenate([samples, np.zeros((bsz - actual, 1), np.int64)])
+        pred, orig = [], []
+        slot_orig = np.arange(bsz)
+        steps = np.zeros(bsz, np.int64)
+        ignore = np.ones(bsz, bool)
+        ignore[:actual] = False
+        stop = False
+        rows = np.arange(bsz)
+        while True:
+            for idx in range(1000):
+                steps += 1
+                h = self.decode(xin, bsz, kv)
+                kv += 1
+                lg = self.logits(h)
+                samples = sample(lg, None, q=q(lg.shape), **kw)
+                pre[rows, kv] = samples[:, 0]
+                if idx % check_interval == 0:
+                    reached = kv + check_interval >= bks[min(bi, len(bks) - 1)]
+                    eos = samples[:, 0] == self.EOS
+                    fin = ~ignore & (eos | reached)
+                    if fin.any():
+                        if reached.any():
+                            bi += 1
+                            if bi < len(bks):
+                                reached[:] = False
+                        fin = ~ignore & (eos | reached)
+                        if fin.any():
+                            for i in np.nonzero(fin)[0]:
+                                seg = pre[i, kv[i] - steps[i] + 1: kv[i]]
+                                e = np.nonzero(seg == self.EOS)[0]
+                                if e.size:
+                                    seg = seg[: e[0]]
+                                pred.append(seg.copy())
+                                orig.append(int(slot_orig[i]))
+                                steps[i] = 0
+                                kv[i] = 0
+                                mx = int(kv.max())
+                                bi = len(bks) - 1
+                                for j, t in enumerate(bks):
+                                    if t >= mx + check_interval:
+                                        bi = j
+                                        break
+                                if cur == B:
+                                    ignore[i] = True
+                                    if ignore.all():
+                                        stop = True
+                                        break
+                                else:
+                                    sx = np.asarray(xs[cur], np.int64); sy = np.asarray(ys[cur], np.int64)
+                                    one = np.concatenate([self.embed_text(sx, _f32(berts[cur])),
+                                                          self.embed_audio(sy)])[None]
+                                    kc, vc = self.cache[bsz]
+                                    xyd = np.ascontiguousarray(one, np.float32)
+                                    m1 = self.single_mask(len(sx), len(sy))[None]
+                                    lib().orc_t2s_prefill(_fp(self.pack), self.NL, self.D, self.H, 1,
+                                                          xyd.shape[1], _fp(xyd), m1.ctypes.data_as(c_u8),
+                                                          _fp(kc), _fp(vc), kc.shape[1], kc.shape[3], int(i))
+                                    l1 = self.logits(xyd[:, -1])
+                                    x_lens[i] = len(sx)
+                                    kv[i] = len(sx) + len(sy)
+                                    v1 = l1[:, :-1].copy()
+                                    samples[i: i + 1] = sample(v1, None, q=q(v1.shape), **kw)
+                                    slot_orig[i] = cur
+                                    cur += 1
+                            if stop:
+                                break
+                xin = self.next_input(samples[:, 0], kv - x_lens)
+            if stop:
+                break
+        return pred, np.array(orig, np.int64)
+
+
+# ----------------------------------------------------------------------------- SoVITS flow + Generator
+
+def fold_weight_norm(g, v):
+    """torch.nn.utils.weight_norm: W = v * (g / ||v||), norm over all dims but 0."""
+    g = _f32(g); v = _f32(v)
+    n = np.sqrt((v * v).sum(axis=tuple(range(1, v.ndim)), keepdims=True, dtype=np.float32))
+    return (v * (g / n)).astype(np.float32)
+
+
+class VocoderOracle:
+    def __init__(self, hps, weights):
+        m = hps["model"]
+        self.H = m["hidden_channels"]; self.inter = m["inter_channels"]; self.gin = m["gin_channels"]
+        self.C0 = m["upsample_initial_channel"]
+        self.up_rates = np.array(m["upsample_rates"], np.int32)
+        self.up_kernels = np.array(m["upsample_kernel_sizes"], np.int32)
+        self.rk = np.array(m["resblock_kernel_sizes"], np.int32)
+        self.rdil = np.array(m["resblock_dilation_sizes"][0], np.int32)
+        self.samples_per_frame = int(np.prod(self.up_rates))
+        w = {k: _f32(v) for k, v in weights.items()}
+        parts = [w["dec.conv_pre.weight"], w["dec.conv_pre.bias"], w["dec.cond.weight"], w["dec.cond.bias"]]
+        for i in range(len(self.up_rates)):
+            parts += [w["dec.ups.%d.weight" % i], w["dec.ups.%d.bias" % i]]
+            for j in range(len(self.rk)):
+                r = "dec.resblocks.%d." % (i * len(self.rk) + j)
+                for c in ("convs1", "convs2"):
+                    for d in range(3):
+                        parts += [w["%s%s.%d.weight" % (r, c, d)], w["%s%s.%d.bias" % (r, c, d)]]
+        parts.append(w["dec.conv_post.weight"])
+        self.gen_pack = np.concatenate([p.ravel() for p in parts])
+        fparts = []
+        for fl in range(0, 8, 2):
+            p = "flow.flows.%d." % fl
+            fparts += [w[p + "pre.weight"], w[p + "pre.bias"],
+                       fold_weight_norm(w[p + "enc.cond_layer.weight_g"], w[p + "enc.cond_layer.weight_v"]),
+                       w[p + "enc.cond_layer.bias"]]
+            for l in range(4):
+                fparts += [fold_weight_norm(w["%senc.in_layers.%d.weight_g" % (p, l)], w["%senc.in_layers.%d.weight_v" % (p, l)]),
+                           w["%senc.in_layers.%d.bias" % (p, l)],
+                           fold_weight_norm(w["%senc.res_skip_layers.%d.weight_g" % (p, l)], w["%senc.res_skip_layers.%d.weight_v" % (p, l)]),
+                           w["%senc.res_skip_layers.%d.bias" % (p, l)]]
+            fparts += [w[p + "post.weight"], w[p + "post.bias"]]
+        self.flow_pack = np.concatenate([p.ravel() for p in fparts])
+        assert self.flow_pack.size == 4 * lib().orc_flow_layer_floats(self.inter // 2, self.H, self.gin)
+
+    def flow(self, z_p, y_mask, ge):
+        """z_p [C, T], y_mask [T], ge [gin, Tg] -> [C, T]  (ResidualCouplingBlock reverse)."""
+        x = _f32(z_p).copy()
+        m = _f32(y_mask).ravel()
+        g = _f32(ge).reshape(self.gin, -1)
+        lib().orc_flow_reverse(_fp(self.flow_pack), 4, self.inter // 2, self.H, self.gin, _fp(x), x.shape[1],
+                               _fp(m), _fp(g), g.shape[1])
+        return x
+
+    def dec(self, z, ge):
+        z = _f32(z)
+        g = _f32(ge).reshape(self.gin, -1)
+        T = z.shape[1]
+        out = np.zeros(T * self.samples_per_frame, np.float32)
+        lib().orc_generator(_fp(self.gen_pack), self.inter, self.C0, self.gin, len(self.up_rates),
+                            self.up_rates.ctypes.data_as(c_i), self.up_kernels.ctypes.data_as(c_i),
+                            len(self.rk), self.rk.ctypes.data_as(c_i), self.rdil.ctypes.data_as(c_i),
+                            _fp(z), T, _fp(g), g.shape[1], _fp(out))
+        return out
+
+    def flow_dec(self, z_p, y_mask, ge):
+        """models.py:380-383: o = dec(flow(z_p, mask, ge) * mask, g=ge)."""
+        z = self.flow(z_p, y_mask, ge)
+        return self.dec(z * _f32(y_mask).reshape(1, -1), ge)
