@@ -1,0 +1,975 @@
+// C ABI of the MI355X GPT-SoVITS hot path (include/gsv_tts_hip.h): handle management, weight
+// repacking into library-owned arenas, kernel sequencing, hipGraph capture of the decode step.
+// No allocation happens inside a step; nothing here falls back to a CPU or library path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gsv_tts_hip.h"
+#include "t2s_decode.h"
+#include "t2s_prefill.h"
+#include "tapgemm.h"
+#include "voc_kernels.h"
+
+using namespace gsv;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(GSV_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------
+// tapgemm host side
+// ---------------------------------------------------------------------------------------------
+struct PackedConv {
+    void* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, cin_pad = 0, k = 1, dil = 1, pad = 0, u = 0;
+    int nphase = 1, ntaps = 1, mtiles = 1;
+};
+
+template <typename CT>
+int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_t sm, int64_t sc, int64_t sk,
+              int dil, int pad, int u, const float* bias_src, float bias_scale, hipStream_t st) {
+    constexpr int KS = MfmaK<CT>::KS;
+    if (cin % KS != 0) return fail(GSV_ERR_ARG, "tapgemm: cin %d not a multiple of %d", cin, KS);
+    pc.cout = cout; pc.cin = cin; pc.cin_pad = cin; pc.k = k; pc.dil = dil; pc.pad = pad; pc.u = u;
+    pc.nphase = u > 0 ? u : 1;
+    pc.ntaps = u > 0 ? cdiv(k, u) : k;
+    pc.mtiles = cdiv(cout, 32);
+    if (pc.nphase > 10 || pc.ntaps > 12) return fail(GSV_ERR_ARG, "tapgemm: too many phases/taps");
+    const size_t elems = (size_t)pc.nphase * pc.ntaps * pc.mtiles * (cin / KS) * 64 * (KS / 2);
+    HIPCHK(hipMalloc(&pc.w, elems * sizeof(CT)));
+    const int blocks = (int)std::min<size_t>(2048, (elems + 255) / 256);
+    hipLaunchKernelGGL((tapgemm_pack_kernel<CT>), dim3(blocks), dim3(256), 0, st, src, (CT*)pc.w, cout, cin, k, sm, sc,
+                       sk, pc.nphase, pc.ntaps, u, pad, pc.mtiles);
+    if (bias_src) {
+        HIPCHK(hipMalloc(&pc.bias, sizeof(float) * cout));
+        hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, bias_src, pc.bias, (size_t)cout,
+                           bias_scale);
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+void free_conv(PackedConv& pc) {
+    if (pc.w) (void)hipFree(pc.w);
+    if (pc.bias) (void)hipFree(pc.bias);
+    pc.w = nullptr; pc.bias = nullptr;
+}
+
+struct Epi {
+    const float* add = nullptr; int ld_add = 0;
+    const void* res = nullptr; int ld_res = 0;
+    const float* mask = nullptr;
+    float scale = 1.0f; int act = ACT_NONE; int accumulate = 0; float in_slope = 1.0f;
+    bool use_bias = true;
+};
+
+template <typename IT, typename CT, typename OT>
+int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, int n_rows, const Epi& e,
+             hipStream_t st) {
+    TapGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.ldx = ldx; a.n_in = n_in; a.cin = pc.cin; a.W = pc.w; a.cout = pc.cout; a.mtiles = pc.mtiles;
+    a.ntaps = pc.ntaps; a.nphase = pc.nphase;
+    if (pc.u > 0) {
+        for (int r = 0; r < pc.u; ++r) a.pshift[r] = (r + pc.pad) / pc.u;
+        for (int t = 0; t < pc.ntaps; ++t) a.tshift[t] = -t;
+        a.omul = pc.u;
+    } else {
+        a.pshift[0] = 0;
+        for (int t = 0; t < pc.ntaps; ++t) a.tshift[t] = t * pc.dil - pc.pad;
+        a.omul = 1;
+    }
+    a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
+    a.res = e.res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
+    a.accumulate = e.accumulate; a.Y = Y; a.ldy = ldy; a.n_rows = n_rows;
+    const bool wide_m = pc.mtiles >= 2;
+    const bool wide_n = n_rows > 4096;
+    dim3 blk(256);
+    if (wide_m && wide_n) {
+        dim3 grid(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 2, 2>), grid, blk, 0, st, a);
+    } else if (wide_m) {
+        dim3 grid(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 2, 1>), grid, blk, 0, st, a);
+    } else if (wide_n) {
+        dim3 grid(cdiv(n_rows, 256), pc.mtiles, pc.nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 1, 2>), grid, blk, 0, st, a);
+    } else {
+        dim3 grid(cdiv(n_rows, 128), pc.mtiles, pc.nphase);
+        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 1, 1>), grid, blk, 0, st, a);
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// GPT
+// =============================================================================================
+struct T2SLayer {
+    void *wqkv_p = nullptr, *wo_p = nullptr, *w1 = nullptr, *w2_p = nullptr;  // decode panels (WT)
+    float *bqkv_p = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr,
+          *ln2g = nullptr, *ln2b = nullptr;
+    PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill (tapgemm fragments)
+    unsigned have = 0;
+};
+
+struct T2SBound {
+    gsv_t2s_state st;
+    hipGraphExec_t graph = nullptr;
+};
+
+struct gsv_t2s {
+    gsv_t2s_config cfg;
+    std::vector<T2SLayer> layers;
+    void* predict = nullptr;  // WT [V][512]
+    float *emb_audio = nullptr, *emb_text = nullptr, *pe_audio = nullptr, *pe_text = nullptr;
+    PackedConv g_bert;
+    unsigned have_io = 0;
+    bool finalized = false;
+    std::map<int, T2SBound> bound;
+    // scratch sized for the largest bound batch
+    int scratch_b = 0;
+    float *xcur = nullptr, *xbuf = nullptr, *x1buf = nullptr, *ypart = nullptr, *zpart = nullptr;
+    TokPart* tokpart = nullptr;
+    hipStream_t cap_stream = nullptr;
+};
+
+namespace {
+
+template <typename WT>
+int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float* data, int64_t numel, hipStream_t st) {
+    T2SLayer& L = h->layers[l];
+    auto want = [&](int64_t n) { return numel == n ? GSV_OK : fail(GSV_ERR_ARG, "layer %d %s: numel %lld, expected %lld", l, key.c_str(), (long long)numel, (long long)n); };
+    auto copy_f32 = [&](float** dst, int64_t n, unsigned bit) -> int {
+        if (int rc = want(n)) return rc;
+        if (!*dst) HIPCHK(hipMalloc(dst, sizeof(float) * n));
+        HIPCHK(hipMemcpyAsync(*dst, data, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        L.have |= bit;
+        return GSV_OK;
+    };
+    if (key == "qkv.weight") {
+        if (int rc = want(3LL * kD * kD)) return rc;
+        if (!L.wqkv_p) HIPCHK(hipMalloc(&L.wqkv_p, sizeof(WT) * 3 * kD * kD));
+        hipLaunchKernelGGL((pack_qkv_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.wqkv_p);
+        float* keep = L.g_qkv.bias; L.g_qkv.bias = nullptr;
+        free_conv(L.g_qkv);
+        if (int rc = pack_conv<WT>(L.g_qkv, data, 3 * kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        L.g_qkv.bias = keep;
+        L.have |= 1u << 0;
+    } else if (key == "qkv.bias") {
+        if (int rc = want(3 * kD)) return rc;
+        if (!L.bqkv_p) HIPCHK(hipMalloc(&L.bqkv_p, sizeof(float) * 3 * kD));
+        hipLaunchKernelGGL(pack_qkv_bias_kernel, dim3(6), dim3(256), 0, st, data, L.bqkv_p);
+        if (!L.g_qkv.bias) HIPCHK(hipMalloc(&L.g_qkv.bias, sizeof(float) * 3 * kD));
+        HIPCHK(hipMemcpyAsync(L.g_qkv.bias, data, sizeof(float) * 3 * kD, hipMemcpyDeviceToDevice, st));
+        L.have |= 1u << 1;
+    } else if (key == "out_proj.weight") {
+        if (int rc = want((int64_t)kD * kD)) return rc;
+        if (!L.wo_p) HIPCHK(hipMalloc(&L.wo_p, sizeof(WT) * kD * kD));
+        hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(512), dim3(256), 0, st, data, (WT*)L.wo_p, kH, kDh);
+        free_conv(L.g_out);
+        if (int rc = pack_conv<WT>(L.g_out, data, kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        L.have |= 1u << 2;
+    } else if (key == "out_proj.bias") {
+        if (int rc = copy_f32(&L.bo, kD, 1u << 3)) return rc;
+    } else if (key == "mlp.0.weight") {
+        if (int rc = want((int64_t)kF * kD)) return rc;
+        if (!L.w1) HIPCHK(hipMalloc(&L.w1, sizeof(WT) * kF * kD));
+        hipLaunchKernelGGL((convert_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w1, (size_t)kF * kD);
+        free_conv(L.g_w1);
+        if (int rc = pack_conv<WT>(L.g_w1, data, kF, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        L.have |= 1u << 4;
+    } else if (key == "mlp.0.bias") {
+        if (int rc = copy_f32(&L.b1, kF, 1u << 5)) return rc;
+    } else if (key == "mlp.2.weight") {
+        if (int rc = want((int64_t)kD * kF)) return rc;
+        if (!L.w2_p) HIPCHK(hipMalloc(&L.w2_p, sizeof(WT) * kD * kF));
+        hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p, kNJ, kFJ);
+        free_conv(L.g_w2);
+        if (int rc = pack_conv<WT>(L.g_w2, data, kD, kF, 1, kF, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        L.have |= 1u << 6;
+    } else if (key == "mlp.2.bias") {
+        if (int rc = copy_f32(&L.b2, kD, 1u << 7)) return rc;
+    } else if (key == "norm1.weight") {
+        if (int rc = copy_f32(&L.ln1g, kD, 1u << 8)) return rc;
+    } else if (key == "norm1.bias") {
+        if (int rc = copy_f32(&L.ln1b, kD, 1u << 9)) return rc;
+    } else if (key == "norm2.weight") {
+        if (int rc = copy_f32(&L.ln2g, kD, 1u << 10)) return rc;
+    } else if (key == "norm2.bias") {
+        if (int rc = copy_f32(&L.ln2b, kD, 1u << 11)) return rc;
+    } else {
+        return fail(GSV_ERR_ARG, "unknown layer tensor '%s'", key.c_str());
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename WT>
+int t2s_load_io_tensor(gsv_t2s* h, const std::string& name, const float* data, int64_t numel, hipStream_t st) {
+    const gsv_t2s_config& c = h->cfg;
+    auto copy_f32 = [&](float** dst, int64_t n, unsigned bit) -> int {
+        if (numel != n) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", name.c_str(), (long long)numel, (long long)n);
+        if (!*dst) HIPCHK(hipMalloc(dst, sizeof(float) * n));
+        HIPCHK(hipMemcpyAsync(*dst, data, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+        h->have_io |= bit;
+        return GSV_OK;
+    };
+    if (name == "ar_predict_layer.weight") {
+        if (numel != (int64_t)c.vocab * kD) return fail(GSV_ERR_ARG, "%s: bad numel", name.c_str());
+        if (!h->predict) HIPCHK(hipMalloc(&h->predict, sizeof(WT) * c.vocab * kD));
+        hipLaunchKernelGGL((convert_kernel<WT>), dim3(512), dim3(256), 0, st, data, (WT*)h->predict, (size_t)c.vocab * kD);
+        h->have_io |= 1u << 0;
+    } else if (name == "ar_audio_embedding.word_embeddings.weight") {
+        return copy_f32(&h->emb_audio, (int64_t)c.vocab * kD, 1u << 1);
+    } else if (name == "ar_text_embedding.word_embeddings.weight") {
+        return copy_f32(&h->emb_text, (int64_t)c.n_phoneme * kD, 1u << 2);
+    } else if (name == "ar_audio_position.pe_scaled") {
+        return copy_f32(&h->pe_audio, (int64_t)c.n_pos * kD, 1u << 3);
+    } else if (name == "ar_text_position.pe_scaled") {
+        return copy_f32(&h->pe_text, (int64_t)c.n_pos * kD, 1u << 4);
+    } else if (name == "bert_proj.weight") {
+        if (numel != (int64_t)kD * 1024) return fail(GSV_ERR_ARG, "%s: bad numel", name.c_str());
+        float* keep = h->g_bert.bias; h->g_bert.bias = nullptr;
+        free_conv(h->g_bert);
+        if (int rc = pack_conv<WT>(h->g_bert, data, kD, 1024, 1, 1024, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        h->g_bert.bias = keep;
+        h->have_io |= 1u << 5;
+    } else if (name == "bert_proj.bias") {
+        return copy_f32(&h->g_bert.bias, kD, 1u << 6);
+    } else if (name == "ar_text_position.alpha" || name == "ar_audio_position.alpha") {
+        return GSV_OK;  // folded into the pe_scaled tables by the caller
+    } else {
+        return fail(GSV_ERR_ARG, "unknown tensor '%s'", name.c_str());
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int t2s_ensure_scratch(gsv_t2s* h, int B) {
+    if (B <= h->scratch_b) return GSV_OK;
+    for (void* p : {(void*)h->xcur, (void*)h->xbuf, (void*)h->x1buf, (void*)h->ypart, (void*)h->zpart, (void*)h->tokpart})
+        if (p) (void)hipFree(p);
+    HIPCHK(hipMalloc(&h->xcur, sizeof(float) * B * kD));
+    HIPCHK(hipMalloc(&h->xbuf, sizeof(float) * B * kD));
+    HIPCHK(hipMalloc(&h->x1buf, sizeof(float) * B * kD));
+    HIPCHK(hipMalloc(&h->ypart, sizeof(float) * B * kH * kD));
+    HIPCHK(hipMalloc(&h->zpart, sizeof(float) * B * kNJ * kD));
+    HIPCHK(hipMalloc(&h->tokpart, sizeof(TokPart) * B * kNP));
+    HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
+    h->scratch_b = B;
+    // graphs captured against the old scratch pointers are stale
+    for (auto& kv : h->bound)
+        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+    return GSV_OK;
+}
+
+// the transformer stack for one token per slot; x from `xsrc` [B][512]
+template <typename WT>
+int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st) {
+    const int B = s.batch, T = s.max_kv;
+    const size_t lds = sizeof(float) * (kD + 96 + 32 + 16 + 128 + T + 8);
+    const size_t layer_elems = (size_t)B * kH * T * kDh;
+    for (int l = 0; l < h->cfg.n_layer; ++l) {
+        T2SLayer& L = h->layers[l];
+        AttnArgs<WT> a;
+        a.mode = l == 0 ? 0 : 1;
+        a.xdirect = xsrc;
+        a.zpart = h->zpart;
+        a.b2 = l ? h->layers[l - 1].b2 : nullptr;
+        a.x1 = h->x1buf;
+        a.ln2g = l ? h->layers[l - 1].ln2g : nullptr;
+        a.ln2b = l ? h->layers[l - 1].ln2b : nullptr;
+        a.xout = h->xbuf;
+        a.wqkv = (const WT*)L.wqkv_p; a.bqkv = L.bqkv_p; a.wo = (const WT*)L.wo_p;
+        a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
+        a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
+        a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart;
+        hipLaunchKernelGGL((t2s_attn_kernel<WT>), dim3(kH, B), dim3(256), lds, st, a);
+        FfnArgs<WT> f;
+        f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
+        f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart;
+        hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(256), 0, st, f);
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename WT>
+int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirect, int slot0, int nrows, int vlimit,
+               int bump, hipStream_t st) {
+    const T2SLayer& L = h->layers.back();
+    LogitsArgs<WT> a;
+    a.mode = mode; a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
+    a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0;
+    a.step = s.step; a.ctl = s.ctl; a.fctl = s.fctl; a.seen = s.seen; a.logits = s.logits; a.hidden = s.hidden;
+    a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;
+    hipLaunchKernelGGL((t2s_logits_kernel<WT>), dim3(kNP, nrows), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
+    TokenArgs a;
+    a.tokpart = h->tokpart; a.tok_override = s.tok_override; a.ctl = s.ctl; a.kv_len = s.kv_len; a.x_len = s.x_len;
+    a.pre_tokens = s.pre_tokens; a.seen = s.seen; a.step = s.step; a.eos_at = s.eos_at; a.emb = h->emb_audio;
+    a.pe = h->pe_audio; a.xcur = h->xcur; a.T = s.max_kv; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.n_pos = h->cfg.n_pos;
+    a.advance = advance;
+    hipLaunchKernelGGL(t2s_token_kernel, dim3(s.batch), dim3(256), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename WT>
+int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
+    if (int rc = t2s_token(h, s, 1, st)) return rc;
+    if (int rc = t2s_layers<WT>(h, s, h->xcur, st)) return rc;
+    return t2s_logits<WT>(h, s, 1, nullptr, 0, s.batch, h->cfg.vocab, 1, st);
+}
+
+template <typename WT>
+int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                     const int64_t* y_lens, void* ws, size_t ws_bytes, hipStream_t st) {
+    const gsv_t2s_state& s = bd.st;
+    const int M = nrows * l_max, T = s.max_kv;
+    const size_t need = gsv_t2s_prefill_workspace(h, nrows, l_max);
+    if (ws_bytes < need) return fail(GSV_ERR_ARG, "prefill workspace %zu < %zu", ws_bytes, need);
+    float* qkv = (float*)ws;
+    float* attn = qkv + (size_t)M * 3 * kD;
+    float* ybuf = attn + (size_t)M * kD;
+    float* fbuf = ybuf + (size_t)M * kD;
+    float* hlast = fbuf + (size_t)M * kF;
+    const size_t layer_elems = (size_t)s.batch * kH * T * kDh;
+    const int qsplit = nrows >= 16 ? 1 : (nrows >= 4 ? 2 : 4);
+    const size_t lds = sizeof(float) * ((size_t)l_max * 33 + (size_t)l_max * 32 + 4 * (size_t)l_max + 128 + 8);
+    if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int l = 0; l < h->cfg.n_layer; ++l) {
+        T2SLayer& L = h->layers[l];
+        Epi e0;
+        if (int rc = run_conv<float, WT, float>(L.g_qkv, xy, kD, M, qkv, 3 * kD, M, e0, st)) return rc;
+        PrefillAttnArgs<WT> pa;
+        pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
+        pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
+        pa.T = T; pa.slot0 = slot0; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
+        hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
+        Epi e1; e1.res = xy; e1.ld_res = kD;
+        // out_proj bias lives in the decode copy (L.bo); tapgemm bias pointer set per call
+        PackedConv go = L.g_out; go.bias = L.bo;
+        if (int rc = run_conv<float, WT, float>(go, attn, kD, M, ybuf, kD, M, e1, st)) return rc;
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln1g, L.ln1b, xy, M);
+        Epi e2; e2.act = ACT_RELU;
+        PackedConv g1 = L.g_w1; g1.bias = L.b1;
+        if (int rc = run_conv<float, WT, float>(g1, xy, kD, M, fbuf, kF, M, e2, st)) return rc;
+        Epi e3; e3.res = xy; e3.ld_res = kD;
+        PackedConv g2 = L.g_w2; g2.bias = L.b2;
+        if (int rc = run_conv<float, WT, float>(g2, fbuf, kF, M, ybuf, kD, M, e3, st)) return rc;
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln2g, L.ln2b, xy, M);
+    }
+    PrefillFinishArgs fa;
+    fa.hidden = xy; fa.x_lens = x_lens; fa.y_lens = y_lens; fa.hlast = hlast; fa.kv_len = s.kv_len; fa.x_len = s.x_len;
+    fa.step = s.step; fa.eos_at = s.eos_at; fa.slot0 = slot0; fa.l_max = l_max;
+    hipLaunchKernelGGL(t2s_prefill_finish_kernel, dim3(nrows), dim3(128), 0, st, fa);
+    HIPCHK(hipGetLastError());
+    // first sample: logits[:, :-1] (t2s_model.py:417,613) -> EOS column dropped
+    return t2s_logits<WT>(h, s, 0, hlast, slot0, nrows, h->cfg.vocab - 1, 0, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsv_version(void) { return 1; }
+const char* gsv_last_error(void) { return g_err.c_str(); }
+
+int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
+    if (!cfg || !out) return fail(GSV_ERR_ARG, "null argument");
+    if (cfg->hidden != kD || cfg->n_head != kH)
+        return fail(GSV_ERR_ARG, "unsupported GPT shape: hidden %d heads %d (kernels are specialised for 512/16)", cfg->hidden, cfg->n_head);
+    if (cfg->vocab < 2 || cfg->vocab > kNP * 128 || cfg->n_layer < 1 || cfg->n_pos < 1)
+        return fail(GSV_ERR_ARG, "unsupported vocab/n_layer/n_pos");
+    if (cfg->dtype != GSV_F32 && cfg->dtype != GSV_BF16) return fail(GSV_ERR_ARG, "bad dtype");
+    gsv_t2s* h = new gsv_t2s();
+    h->cfg = *cfg;
+    h->layers.resize(cfg->n_layer);
+    if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(GSV_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = h;
+    return GSV_OK;
+}
+
+int gsv_t2s_destroy(gsv_t2s* h) {
+    if (!h) return GSV_OK;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : h->bound)
+        if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
+    for (T2SLayer& L : h->layers) {
+        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
+                        (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b})
+            if (p) (void)hipFree(p);
+        free_conv(L.g_qkv); L.g_out.bias = nullptr; free_conv(L.g_out); L.g_w1.bias = nullptr; free_conv(L.g_w1);
+        L.g_w2.bias = nullptr; free_conv(L.g_w2);
+    }
+    for (void* p : {h->predict, (void*)h->emb_audio, (void*)h->emb_text, (void*)h->pe_audio, (void*)h->pe_text,
+                    (void*)h->xcur, (void*)h->xbuf, (void*)h->x1buf, (void*)h->ypart, (void*)h->zpart, (void*)h->tokpart})
+        if (p) (void)hipFree(p);
+    free_conv(h->g_bert);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    delete h;
+    return GSV_OK;
+}
+
+int gsv_t2s_load_tensor(gsv_t2s* h, const char* name, const float* data, int64_t numel, void* stream) {
+    if (!h || !name || !data) return fail(GSV_ERR_ARG, "null argument");
+    std::string n(name);
+    const std::string pre = "t2s_transformer.blocks.";
+    h->finalized = false;
+    if (n.compare(0, pre.size(), pre) == 0) {
+        size_t dot = n.find('.', pre.size());
+        if (dot == std::string::npos) return fail(GSV_ERR_ARG, "bad tensor name '%s'", name);
+        int l = atoi(n.substr(pre.size(), dot - pre.size()).c_str());
+        if (l < 0 || l >= h->cfg.n_layer) return fail(GSV_ERR_ARG, "layer index out of range in '%s'", name);
+        std::string key = n.substr(dot + 1);
+        return h->cfg.dtype == GSV_BF16 ? t2s_load_layer_tensor<bf16_t>(h, l, key, data, numel, S(stream))
+                                        : t2s_load_layer_tensor<float>(h, l, key, data, numel, S(stream));
+    }
+    return h->cfg.dtype == GSV_BF16 ? t2s_load_io_tensor<bf16_t>(h, n, data, numel, S(stream))
+                                    : t2s_load_io_tensor<float>(h, n, data, numel, S(stream));
+}
+
+int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
+    if (!h) return fail(GSV_ERR_ARG, "null handle");
+    for (int l = 0; l < h->cfg.n_layer; ++l)
+        if (h->layers[l].have != 0xfffu) return fail(GSV_ERR_STATE, "layer %d incomplete (mask 0x%x)", l, h->layers[l].have);
+    if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    h->finalized = true;
+    return GSV_OK;
+}
+
+int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
+    if (!h || !st) return fail(GSV_ERR_ARG, "null argument");
+    if (st->batch < 1 || st->max_kv < 2) return fail(GSV_ERR_ARG, "bad batch/max_kv");
+    if (!st->k_cache || !st->v_cache || !st->kv_len || !st->x_len || !st->pre_tokens || !st->seen || !st->step ||
+        !st->eos_at || !st->logits || !st->hidden || !st->tok_override || !st->ctl || !st->fctl)
+        return fail(GSV_ERR_ARG, "state has null pointers");
+    if (int rc = t2s_ensure_scratch(h, st->batch)) return rc;
+    T2SBound& b = h->bound[st->batch];
+    if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    b.st = *st;
+    return GSV_OK;
+}
+
+static T2SBound* t2s_find(gsv_t2s* h, int batch) {
+    auto it = h->bound.find(batch);
+    return it == h->bound.end() ? nullptr : &it->second;
+}
+
+int gsv_t2s_embed_prompt(gsv_t2s* h, int nrows, int lx_max, int ly_max, int l_max, const int64_t* x_ids,
+                         const int64_t* y_ids, const float* bert, const int64_t* x_lens, const int64_t* y_lens,
+                         float* xy, float* scratch, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    if (nrows < 1 || lx_max < 1 || ly_max < 1 || l_max < 1 || l_max > h->cfg.n_pos) return fail(GSV_ERR_ARG, "bad sizes");
+    const int M = nrows * lx_max;
+    Epi e;
+    int rc = h->cfg.dtype == GSV_BF16 ? run_conv<float, bf16_t, float>(h->g_bert, bert, 1024, M, scratch, kD, M, e, S(stream))
+                                      : run_conv<float, float, float>(h->g_bert, bert, 1024, M, scratch, kD, M, e, S(stream));
+    if (rc) return rc;
+    EmbedArgs a;
+    a.x_ids = x_ids; a.y_ids = y_ids; a.proj = scratch; a.x_lens = x_lens; a.y_lens = y_lens; a.emb_text = h->emb_text;
+    a.emb_audio = h->emb_audio; a.pe_text = h->pe_text; a.pe_audio = h->pe_audio; a.xy = xy; a.lx_max = lx_max;
+    a.ly_max = ly_max; a.l_max = l_max; a.n_phoneme = h->cfg.n_phoneme; a.V = h->cfg.vocab;
+    hipLaunchKernelGGL(t2s_embed_kernel, dim3(l_max, nrows), dim3(128), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+size_t gsv_t2s_prefill_workspace(gsv_t2s* h, int nrows, int l_max) {
+    (void)h;
+    const size_t M = (size_t)nrows * l_max;
+    return sizeof(float) * (M * (3 * kD + kD + kD + kF) + (size_t)nrows * kD) + 256;
+}
+
+int gsv_t2s_prefill(gsv_t2s* h, int batch, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                    const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    if (slot0 < 0 || nrows < 1 || slot0 + nrows > batch) return fail(GSV_ERR_ARG, "slot range out of bounds");
+    if (l_max < 1 || l_max > b->st.max_kv) return fail(GSV_ERR_ARG, "prompt of %d positions does not fit the KV cache (%d)", l_max, b->st.max_kv);
+    return h->cfg.dtype == GSV_BF16
+               ? t2s_prefill_impl<bf16_t>(h, *b, slot0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream))
+               : t2s_prefill_impl<float>(h, *b, slot0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream));
+}
+
+int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    int rc = h->cfg.dtype == GSV_BF16 ? t2s_layers<bf16_t>(h, b->st, x, S(stream)) : t2s_layers<float>(h, b->st, x, S(stream));
+    if (rc) return rc;
+    return h->cfg.dtype == GSV_BF16 ? t2s_logits<bf16_t>(h, b->st, 1, nullptr, 0, batch, h->cfg.vocab, 1, S(stream))
+                                    : t2s_logits<float>(h, b->st, 1, nullptr, 0, batch, h->cfg.vocab, 1, S(stream));
+}
+
+int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    const bool bf = h->cfg.dtype == GSV_BF16;
+    if (!use_graph) {
+        for (int i = 0; i < n_steps; ++i)
+            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream)) : t2s_step<float>(h, b->st, S(stream))) return rc;
+        return GSV_OK;
+    }
+    if (!b->graph) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream) : t2s_step<float>(h, b->st, h->cap_stream);
+        hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(b->graph, S(stream)));
+    return GSV_OK;
+}
+
+int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    return t2s_token(h, b->st, 0, S(stream));
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// SoVITS flow + Generator
+// =============================================================================================
+struct VocFlow {
+    PackedConv pre, cond, post;      // post packed NEGATED: x1 + (-(W out + b)) in the epilogue
+    PackedConv in_l[4], rs_res[3], rs_skip[4];
+};
+struct VocResBlock {
+    PackedConv c1[3], c2[3];
+    int k = 3;
+};
+struct VocStage {
+    PackedConv up;
+    std::vector<VocResBlock> rb;
+    int cin = 0, cout = 0, u = 1;
+};
+
+struct gsv_voc {
+    gsv_voc_config cfg;
+    std::map<std::string, std::pair<float*, int64_t>> staged;
+    bool finalized = false;
+    std::vector<VocFlow> flows;
+    PackedConv conv_pre, cond, conv_post;
+    std::vector<VocStage> stages;
+    int total_up = 1;
+    int max_stage_elems_per_frame = 0;  // max over stages of ld(C) * time multiplier
+};
+
+namespace {
+
+inline int ld_of(int c) { return (c + 15) / 16 * 16; }
+
+struct VocWs {
+    // channels-last buffers (element type AT unless noted)
+    void *zin, *zflip, *h, *outp, *a, *acts, *ge_cl;
+    float *gc, *condbuf;
+    void* st[5];  // stage ping-pong: xu, xa, xb, t1, xs
+    size_t bytes;
+};
+
+template <typename AT>
+VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
+    const gsv_voc_config& c = v->cfg;
+    const int H = c.hidden_channels, C = c.inter_channels;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    VocWs w;
+    w.zin = take(sizeof(AT) * (size_t)T * C);
+    w.zflip = take(sizeof(AT) * (size_t)T * C);
+    w.h = take(sizeof(AT) * (size_t)T * H);
+    w.outp = take(sizeof(AT) * (size_t)T * H);
+    w.a = take(sizeof(AT) * (size_t)T * 2 * H);
+    w.acts = take(sizeof(AT) * (size_t)T * H);
+    w.ge_cl = take(sizeof(AT) * (size_t)Tg * c.gin_channels);
+    w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H);
+    w.condbuf = (float*)take(sizeof(float) * (size_t)Tg * c.upsample_initial_channel);
+    const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
+    for (int i = 0; i < 5; ++i) w.st[i] = take(sizeof(AT) * se);
+    w.bytes = off;
+    return w;
+}
+
+template <typename AT>
+int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStream_t st) {
+    const gsv_voc_config& c = v->cfg;
+    const int H = c.hidden_channels, C = c.inter_channels, half = C / 2;
+    AT* x = (AT*)w.zin;
+    AT* xf = (AT*)w.zflip;
+    const int ew = std::min(2048, cdiv(T * H, 256));
+    for (int f = c.n_flows - 1; f >= 0; --f) {
+        VocFlow& F = v->flows[f];
+        hipLaunchKernelGGL((flip_kernel<AT>), dim3(std::min(2048, cdiv(T * C, 256))), dim3(256), 0, st, x, xf, C, T, C);
+        std::swap(x, xf);  // x is now the flipped tensor
+        Epi ep; ep.mask = mask;
+        if (int rc = run_conv<AT, AT, AT>(F.pre, x, C, T, w.h, H, T, ep, st)) return rc;
+        Epi ec;
+        if (int rc = run_conv<AT, AT, float>(F.cond, w.ge_cl, c.gin_channels, Tg, w.gc, 8 * H, Tg, ec, st)) return rc;
+        for (int l = 0; l < 4; ++l) {
+            Epi ei; ei.add = w.gc + (size_t)l * 2 * H; ei.ld_add = Tg == 1 ? 0 : 8 * H;
+            if (int rc = run_conv<AT, AT, AT>(F.in_l[l], w.h, H, T, w.a, 2 * H, T, ei, st)) return rc;
+            hipLaunchKernelGGL((gate_kernel<AT>), dim3(ew), dim3(256), 0, st, (const AT*)w.a, (AT*)w.acts, H, T);
+            Epi es; es.accumulate = l > 0;
+            if (int rc = run_conv<AT, AT, AT>(F.rs_skip[l], w.acts, H, T, w.outp, H, T, es, st)) return rc;
+            if (l < 3) {
+                Epi er; er.res = w.h; er.ld_res = H; er.mask = mask;
+                if (int rc = run_conv<AT, AT, AT>(F.rs_res[l], w.acts, H, T, w.h, H, T, er, st)) return rc;
+            }
+        }
+        // x1 = (x1 - (post(out*mask)+b)*mask) * mask, binary mask; post is packed negated
+        Epi eo; eo.res = x + half; eo.ld_res = C; eo.mask = mask;
+        if (int rc = run_conv<AT, AT, AT>(F.post, w.outp, H, T, x + half, C, T, eo, st)) return rc;
+    }
+    if (x != (AT*)w.zin) HIPCHK(hipMemcpyAsync(w.zin, x, sizeof(AT) * (size_t)T * C, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename AT>
+int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st) {
+    const gsv_voc_config& c = v->cfg;
+    const int C0 = c.upsample_initial_channel;
+    Epi ec;
+    if (int rc = run_conv<AT, AT, float>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, Tg, ec, st)) return rc;
+    AT* x = (AT*)w.st[4];
+    Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0;
+    if (int rc = run_conv<AT, AT, AT>(v->conv_pre, w.zin, c.inter_channels, T, x, ld_of(C0), T, ep, st)) return rc;
+    int Tc = T;
+    AT *xu = (AT*)w.st[0], *xa = (AT*)w.st[1], *xb = (AT*)w.st[2], *t1 = (AT*)w.st[3];
+    for (size_t i = 0; i < v->stages.size(); ++i) {
+        VocStage& sg = v->stages[i];
+        const int ldi = ld_of(sg.cin), ldo = ld_of(sg.cout);
+        const int Tn = Tc * sg.u;
+        if (ldo != sg.cout) {  // pad channels feed zero-weight k-steps but must not hold NaN/Inf bit patterns
+            for (AT* p : {xu, xa, xb, t1}) HIPCHK(hipMemsetAsync(p, 0, sizeof(AT) * (size_t)Tn * ldo, st));
+        }
+        Epi eu; eu.in_slope = 0.1f;
+        if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
+        AT* xs = x;  // the stage input buffer is dead once the upsample has read it: accumulate the mean there
+        if (ldo != sg.cout) HIPCHK(hipMemsetAsync(xs, 0, sizeof(AT) * (size_t)Tn * ldo, st));
+        const float inv = 1.0f / (float)sg.rb.size();
+        for (size_t j = 0; j < sg.rb.size(); ++j) {
+            VocResBlock& rb = sg.rb[j];
+            const AT* cur = xu;
+            for (int d = 0; d < 3; ++d) {
+                Epi e1; e1.in_slope = 0.1f;
+                if (int rc = run_conv<AT, AT, AT>(rb.c1[d], cur, ldo, Tn, t1, ldo, Tn, e1, st)) return rc;
+                Epi e2; e2.in_slope = 0.1f; e2.res = cur; e2.ld_res = ldo;
+                AT* dst = (d == 0) ? xa : (d == 1 ? xb : xs);
+                if (d == 2) { e2.scale = inv; e2.accumulate = j > 0; }
+                if (int rc = run_conv<AT, AT, AT>(rb.c2[d], t1, ldo, Tn, dst, ldo, Tn, e2, st)) return rc;
+                cur = dst;
+            }
+        }
+        x = xs;
+        Tc = Tn;
+        // stage output lives where the stage input was; next stage's xu etc. stay distinct
+    }
+    Epi eo; eo.in_slope = 0.01f; eo.act = ACT_TANH; eo.use_bias = false;
+    if (int rc = run_conv<AT, AT, float>(v->conv_post, x, ld_of(v->stages.back().cout), Tc, out, 1, Tc, eo, st)) return rc;
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename AT>
+int voc_prepare(gsv_voc* v, VocWs& w, const float* z, const float* ge, int T, int Tg, hipStream_t st) {
+    const gsv_voc_config& c = v->cfg;
+    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(T, 32), cdiv(c.inter_channels, 32)), dim3(256), 0, st, z,
+                       (AT*)w.zin, c.inter_channels, T, c.inter_channels);
+    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(c.gin_channels, 32)), dim3(256), 0, st, ge,
+                       (AT*)w.ge_cl, c.gin_channels, Tg, c.gin_channels);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename AT>
+int voc_run(gsv_voc* v, int what, const float* z, const float* mask, const float* ge, int T, int Tg, float* out,
+            void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
+    if (T < 1 || (Tg != 1 && Tg != T)) return fail(GSV_ERR_ARG, "bad T/Tg");
+    VocWs w = voc_layout<AT>(v, T, Tg, (char*)ws);
+    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "vocoder workspace %zu < %zu", ws_bytes, w.bytes);
+    if (int rc = voc_prepare<AT>(v, w, z, ge, T, Tg, st)) return rc;
+    if (what & 1)
+        if (int rc = voc_flow_impl<AT>(v, w, mask, T, Tg, st)) return rc;
+    if (what == 1) {  // flow only: back to channels-first fp32
+        hipLaunchKernelGGL((cl_to_cf_kernel<AT>), dim3(cdiv(T, 32), cdiv(v->cfg.inter_channels, 32)), dim3(256), 0, st,
+                           (const AT*)w.zin, out, v->cfg.inter_channels, T, v->cfg.inter_channels);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    }
+    return voc_dec_impl<AT>(v, w, T, Tg, out, st);
+}
+
+template <typename CT>
+int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
+    const gsv_voc_config& c = v->cfg;
+    const int H = c.hidden_channels, C = c.inter_channels, half = C / 2, gin = c.gin_channels;
+    auto get = [&](const std::string& n, int64_t numel, const float** out) -> int {
+        auto it = v->staged.find(n);
+        if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing tensor '%s'", n.c_str());
+        if (it->second.second != numel) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", n.c_str(), (long long)it->second.second, (long long)numel);
+        *out = it->second.first;
+        return GSV_OK;
+    };
+    std::vector<float*> temps;
+    auto folded = [&](const std::string& base, int rows, int row_elems, float sign, const float** out) -> int {
+        const float *g, *vv;
+        if (int rc = get(base + ".weight_g", rows, &g)) return rc;
+        if (int rc = get(base + ".weight_v", (int64_t)rows * row_elems, &vv)) return rc;
+        float* wbuf;
+        HIPCHK(hipMalloc(&wbuf, sizeof(float) * (size_t)rows * row_elems));
+        temps.push_back(wbuf);
+        hipLaunchKernelGGL(weight_norm_fold_kernel, dim3(rows), dim3(256), 0, st, g, vv, wbuf, row_elems, sign);
+        *out = wbuf;
+        return GSV_OK;
+    };
+    int rc = GSV_OK;
+    v->flows.resize(c.n_flows);
+    for (int f = 0; f < c.n_flows && !rc; ++f) {
+        VocFlow& F = v->flows[f];
+        const std::string p = "flow.flows." + std::to_string(2 * f) + ".";
+        const float *w, *b;
+        if ((rc = get(p + "pre.weight", (int64_t)H * half, &w)) || (rc = get(p + "pre.bias", H, &b))) break;
+        if ((rc = pack_conv<CT>(F.pre, w, H, half, 1, half, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+        if ((rc = folded(p + "enc.cond_layer", 8 * H, gin, 1.f, &w)) || (rc = get(p + "enc.cond_layer.bias", 8 * H, &b))) break;
+        if ((rc = pack_conv<CT>(F.cond, w, 8 * H, gin, 1, gin, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+        for (int l = 0; l < 4 && !rc; ++l) {
+            const std::string il = p + "enc.in_layers." + std::to_string(l), rl = p + "enc.res_skip_layers." + std::to_string(l);
+            if ((rc = folded(il, 2 * H, H * 5, 1.f, &w)) || (rc = get(il + ".bias", 2 * H, &b))) break;
+            if ((rc = pack_conv<CT>(F.in_l[l], w, 2 * H, H, 5, (int64_t)H * 5, 5, 1, 1, 2, 0, b, 1.f, st))) break;
+            const int R = l < 3 ? 2 * H : H;
+            if ((rc = folded(rl, R, H, 1.f, &w)) || (rc = get(rl + ".bias", R, &b))) break;
+            if (l < 3) {
+                if ((rc = pack_conv<CT>(F.rs_res[l], w, H, H, 1, H, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+                if ((rc = pack_conv<CT>(F.rs_skip[l], w + (size_t)H * H, H, H, 1, H, 1, 0, 1, 0, 0, b + H, 1.f, st))) break;
+            } else {
+                if ((rc = pack_conv<CT>(F.rs_skip[l], w, H, H, 1, H, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+            }
+        }
+        if (rc) break;
+        if ((rc = get(p + "post.weight", (int64_t)half * H, &w)) || (rc = get(p + "post.bias", half, &b))) break;
+        float* neg;
+        HIPCHK(hipMalloc(&neg, sizeof(float) * half * H));
+        temps.push_back(neg);
+        hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(half * H, 256)), dim3(256), 0, st, w, neg, (size_t)half * H, -1.0f);
+        if ((rc = pack_conv<CT>(F.post, neg, half, H, 1, H, 1, 0, 1, 0, 0, b, -1.f, st))) break;
+    }
+    const int C0 = c.upsample_initial_channel;
+    const float *w = nullptr, *b = nullptr;
+    if (!rc) rc = get("dec.conv_pre.weight", (int64_t)C0 * C * 7, &w);
+    if (!rc) rc = get("dec.conv_pre.bias", C0, &b);
+    if (!rc) rc = pack_conv<CT>(v->conv_pre, w, C0, C, 7, (int64_t)C * 7, 7, 1, 1, 3, 0, b, 1.f, st);
+    if (!rc) rc = get("dec.cond.weight", (int64_t)C0 * gin, &w);
+    if (!rc) rc = get("dec.cond.bias", C0, &b);
+    if (!rc) rc = pack_conv<CT>(v->cond, w, C0, gin, 1, gin, 1, 0, 1, 0, 0, b, 1.f, st);
+    v->stages.resize(c.n_upsample);
+    int ch = C0, tm = 1;
+    v->max_stage_elems_per_frame = ld_of(C0);
+    constexpr int KS = MfmaK<CT>::KS;
+    for (int i = 0; i < c.n_upsample && !rc; ++i) {
+        VocStage& sg = v->stages[i];
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], co = ch / 2;
+        sg.cin = ch; sg.cout = co; sg.u = u;
+        tm *= u;
+        v->max_stage_elems_per_frame = std::max(v->max_stage_elems_per_frame, ld_of(co) * tm);
+        const std::string un = "dec.ups." + std::to_string(i);
+        if ((rc = get(un + ".weight", (int64_t)ch * co * k, &w)) || (rc = get(un + ".bias", co, &b))) break;
+        // ConvTranspose1d weight [Cin][Cout][k]: element (m=co, c=ci, kk) at ci*(Cout*k) + co*k + kk
+        const int cin_pad = (ch + KS - 1) / KS * KS;
+        if (cin_pad != ch) { rc = fail(GSV_ERR_ARG, "stage %d: %d input channels not a multiple of %d", i, ch, KS); break; }
+        if ((rc = pack_conv<CT>(sg.up, w, co, ch, k, k, (int64_t)co * k, 1, 1, (k - u) / 2, u, b, 1.f, st))) break;
+        sg.rb.resize(c.n_resblock_kernels);
+        const int cpad = (co + KS - 1) / KS * KS;  // contraction over zero-padded channels when co % KS != 0
+        for (int j = 0; j < c.n_resblock_kernels && !rc; ++j) {
+            VocResBlock& rb = sg.rb[j];
+            rb.k = c.resblock_kernel_sizes[j];
+            const std::string rn = "dec.resblocks." + std::to_string(i * c.n_resblock_kernels + j);
+            for (int d = 0; d < 3 && !rc; ++d) {
+                for (int which = 0; which < 2 && !rc; ++which) {
+                    const std::string cn = rn + (which ? ".convs2." : ".convs1.") + std::to_string(d);
+                    if ((rc = get(cn + ".weight", (int64_t)co * co * rb.k, &w)) || (rc = get(cn + ".bias", co, &b))) break;
+                    const float* wsrc = w;
+                    if (cpad != co) {  // re-lay as [co][cpad][k] with zero channels
+                        float* padded;
+                        HIPCHK(hipMalloc(&padded, sizeof(float) * (size_t)co * cpad * rb.k));
+                        temps.push_back(padded);
+                        HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * (size_t)co * cpad * rb.k, st));
+                        HIPCHK(hipMemcpy2DAsync(padded, sizeof(float) * cpad * rb.k, w, sizeof(float) * co * rb.k,
+                                                sizeof(float) * co * rb.k, co, hipMemcpyDeviceToDevice, st));
+                        wsrc = padded;
+                    }
+                    const int dil = which ? 1 : c.resblock_dilations[d];
+                    PackedConv& pc = which ? rb.c2[d] : rb.c1[d];
+                    rc = pack_conv<CT>(pc, wsrc, co, cpad, rb.k, (int64_t)cpad * rb.k, rb.k, 1, dil, dil * (rb.k - 1) / 2, 0, b, 1.f, st);
+                }
+            }
+        }
+        ch = co;
+    }
+    v->total_up = tm;
+    if (!rc) rc = get("dec.conv_post.weight", (int64_t)ch * 7, &w);
+    if (!rc) {
+        const int cpad = (ch + KS - 1) / KS * KS;
+        const float* wsrc = w;
+        if (cpad != ch) {
+            float* padded;
+            HIPCHK(hipMalloc(&padded, sizeof(float) * (size_t)cpad * 7));
+            temps.push_back(padded);
+            HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * (size_t)cpad * 7, st));
+            HIPCHK(hipMemcpyAsync(padded, w, sizeof(float) * (size_t)ch * 7, hipMemcpyDeviceToDevice, st));
+            wsrc = padded;
+        }
+        rc = pack_conv<CT>(v->conv_post, wsrc, 1, cpad, 7, (int64_t)cpad * 7, 7, 1, 1, 3, 0, nullptr, 1.f, st);
+    }
+    (void)hipStreamSynchronize(st);
+    for (float* t : temps) (void)hipFree(t);
+    if (rc) return rc;
+    for (auto& kv : v->staged) (void)hipFree(kv.second.first);
+    v->staged.clear();
+    v->finalized = true;
+    return GSV_OK;
+}
+
+void voc_free(gsv_voc* v) {
+    for (auto& kv : v->staged) (void)hipFree(kv.second.first);
+    v->staged.clear();
+    for (VocFlow& F : v->flows) {
+        free_conv(F.pre); free_conv(F.cond); free_conv(F.post);
+        for (auto& p : F.in_l) free_conv(p);
+        for (auto& p : F.rs_res) free_conv(p);
+        for (auto& p : F.rs_skip) free_conv(p);
+    }
+    free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post);
+    for (VocStage& s : v->stages) {
+        free_conv(s.up);
+        for (VocResBlock& r : s.rb)
+            for (int d = 0; d < 3; ++d) { free_conv(r.c1[d]); free_conv(r.c2[d]); }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out) {
+    if (!cfg || !out) return fail(GSV_ERR_ARG, "null argument");
+    if (cfg->n_upsample < 1 || cfg->n_upsample > 8 || cfg->n_resblock_kernels < 1 || cfg->n_resblock_kernels > 4 ||
+        cfg->n_flows < 1 || cfg->inter_channels % 32 != 0 || cfg->hidden_channels % 16 != 0 || cfg->gin_channels % 16 != 0 ||
+        cfg->upsample_initial_channel % 32 != 0)
+        return fail(GSV_ERR_ARG, "unsupported vocoder configuration");
+    for (int i = 0; i < cfg->n_upsample; ++i)
+        if (cfg->upsample_rates[i] < 1 || cfg->upsample_rates[i] > 10 || (cfg->upsample_kernel_sizes[i] - cfg->upsample_rates[i]) % 2 != 0)
+            return fail(GSV_ERR_ARG, "unsupported upsample stage %d", i);
+    if (cfg->dtype != GSV_F32 && cfg->dtype != GSV_BF16) return fail(GSV_ERR_ARG, "bad dtype");
+    gsv_voc* v = new gsv_voc();
+    v->cfg = *cfg;
+    *out = v;
+    return GSV_OK;
+}
+
+int gsv_voc_destroy(gsv_voc* v) {
+    if (!v) return GSV_OK;
+    (void)hipDeviceSynchronize();
+    voc_free(v);
+    delete v;
+    return GSV_OK;
+}
+
+int gsv_voc_load_tensor(gsv_voc* v, const char* name, const float* data, int64_t numel, void* stream) {
+    if (!v || !name || !data || numel < 1) return fail(GSV_ERR_ARG, "null argument");
+    if (v->finalized) return fail(GSV_ERR_STATE, "vocoder already finalized");
+    std::string n(name);
+    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0) return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow/dec", name);
+    auto it = v->staged.find(n);
+    if (it != v->staged.end()) { (void)hipFree(it->second.first); v->staged.erase(it); }
+    float* p;
+    HIPCHK(hipMalloc(&p, sizeof(float) * numel));
+    HIPCHK(hipMemcpyAsync(p, data, sizeof(float) * numel, hipMemcpyDeviceToDevice, S(stream)));
+    v->staged[n] = {p, numel};
+    return GSV_OK;
+}
+
+int gsv_voc_finalize(gsv_voc* v, void* stream) {
+    if (!v) return fail(GSV_ERR_ARG, "null handle");
+    if (v->finalized) return GSV_OK;
+    return v->cfg.dtype == GSV_BF16 ? voc_finalize_impl<bf16_t>(v, S(stream)) : voc_finalize_impl<float>(v, S(stream));
+}
+
+size_t gsv_voc_workspace(gsv_voc* v, int T) {
+    if (!v || !v->finalized || T < 1) return 0;
+    return v->cfg.dtype == GSV_BF16 ? voc_layout<bf16_t>(v, T, T, nullptr).bytes : voc_layout<float>(v, T, T, nullptr).bytes;
+}
+
+int gsv_voc_flow_dec(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !z_p || !y_mask || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream))
+                                    : voc_run<float>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream));
+}
+
+int gsv_voc_flow(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* z_out,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !z_p || !y_mask || !ge || !z_out || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 1, z_p, y_mask, ge, T, Tg, z_out, workspace, workspace_bytes, S(stream))
+                                    : voc_run<float>(v, 1, z_p, y_mask, ge, T, Tg, z_out, workspace, workspace_bytes, S(stream));
+}
+
+int gsv_voc_dec(gsv_voc* v, const float* z, const float* ge, int T, int Tg, float* out, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    if (!v || !z || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 2, z, nullptr, ge, T, Tg, out, workspace, workspace_bytes, S(stream))
+                                    : voc_run<float>(v, 2, z, nullptr, ge, T, Tg, out, workspace, workspace_bytes, S(stream));
+}
+
+}  // extern "C"

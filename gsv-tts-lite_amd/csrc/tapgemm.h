@@ -1,0 +1,307 @@
+// tapgemm: the one MFMA contraction kernel behind every dense op outside the decode step --
+// Linear layers of the GPT prefill, Conv1d / 1x1 conv / ConvTranspose1d of the SoVITS flow and
+// Generator -- written for gfx950 matrix cores.
+//
+//   Y[n*omul + r][m] = epilogue( sum_t sum_c  W_{r,t}[m][c] * pre(X[n + shift(r,t)][c]) )
+//
+// * activations are CHANNELS-LAST ([time][channel]), so both MFMA operands are 16-byte
+//   contiguous per lane: B fragment = 8 bf16 (4 f32) consecutive channels of one time row,
+//   A fragment = the same slice of one weight row.  Weights are pre-packed at load time in
+//   fragment order ([phase][tap][mtile][kstep][lane][16 B]) so a wave's A load is one 1 KiB line.
+// * a Conv1d tap is a row shift of X (zero rows outside [0, n_in)); a ConvTranspose1d of stride u
+//   is u phases r, each a small conv with ceil(k/u) taps, writing rows n*u + r.
+// * bf16 mode: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  fp32 parity mode:
+//   v_mfma_f32_32x32x2_f32, which is an exact f32 fma chain (MI355X_MICROARCH.md), 4 per 16 B.
+// * epilogue fuses bias, conditioning add (broadcast or per-row), residual, mask, scale,
+//   activation and accumulate; prologue fuses leaky-ReLU on the input.
+// * one wave = (WM*32 channels) x (WN*32 rows) accumulators; 4 waves side by side along rows.
+//
+// D fragment (32x32): column j = lane&31 is the time row, register q holds output channel
+// (q&3) + 8*(q>>2) + 4*(lane>>5)  => each lane owns 4 runs of 4 consecutive channels of one
+// row: 16-byte stores into the channels-last output.
+#pragma once
+#include "gsv_common.h"
+
+namespace gsv {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+struct TapGemmArgs {
+    const void* X;       // [n_in][ldx]
+    int ldx;             // elements per input row
+    int n_in;            // valid input rows
+    int cin;             // channels contracted (multiple of the k-step)
+    const void* W;       // packed fragments
+    int cout;            // logical output channels
+    int mtiles;          // ceil(cout / 32)
+    int ntaps;           // taps per phase
+    int nphase;          // 1 (conv/linear) or u (transposed conv)
+    int pshift[10];      // shift(r,t) = pshift[r] + tshift[t]
+    int tshift[12];
+    float in_slope;      // leaky-relu slope applied to X on load (1 = none)
+    // epilogue
+    const float* bias;   // [cout] or null
+    const void* add;     // conditioning term, element type = OT? no: float. [rows or 1][ld_add]
+    int ld_add;          // row stride of add (0 = broadcast one row)
+    const void* res;     // residual, same type/layout as output (row index n*omul + r), or null
+    int ld_res;
+    const float* mask;   // [n_out rows] multiplies the result, or null
+    float scale;         // result *= scale (after everything else)
+    int act;
+    int accumulate;      // Y += result instead of Y = result
+    void* Y;             // [n_rows*omul][ldy]
+    int ldy;
+    int n_rows;          // rows n computed per phase: n in [0, n_rows)
+    int omul;            // output row = n*omul + phase
+};
+
+template <typename CT> struct MfmaK;
+template <> struct MfmaK<float> { static constexpr int KS = 8; };     // channels per k-step
+template <> struct MfmaK<bf16_t> { static constexpr int KS = 16; };
+
+// B-fragment loaders: one lane's 16 bytes of compute-type operands from input type IT
+template <typename IT, typename CT> struct BFrag;
+template <> struct BFrag<float, float> {
+    using type = f32x4;
+    static __device__ __forceinline__ type load(const float* p, bool ok, float slope) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p);
+        if (slope != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * slope;
+        }
+        return v;
+    }
+};
+template <> struct BFrag<float, bf16_t> {
+    using type = u32x4;
+    static __device__ __forceinline__ type load(const float* p, bool ok, float slope) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            a = *reinterpret_cast<const f32x4*>(p);
+            b = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+        if (slope != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = a[i] >= 0.f ? a[i] : a[i] * slope;
+                b[i] = b[i] >= 0.f ? b[i] : b[i] * slope;
+            }
+        }
+        u32x4 r;
+        r[0] = (uint32_t)f32_to_bf16(a[0]) | ((uint32_t)f32_to_bf16(a[1]) << 16);
+        r[1] = (uint32_t)f32_to_bf16(a[2]) | ((uint32_t)f32_to_bf16(a[3]) << 16);
+        r[2] = (uint32_t)f32_to_bf16(b[0]) | ((uint32_t)f32_to_bf16(b[1]) << 16);
+        r[3] = (uint32_t)f32_to_bf16(b[2]) | ((uint32_t)f32_to_bf16(b[3]) << 16);
+        return r;
+    }
+};
+template <> struct BFrag<bf16_t, bf16_t> {
+    using type = u32x4;
+    static __device__ __forceinline__ type load(const bf16_t* p, bool ok, float slope) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(p);
+        if (slope != 1.0f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float lo = __uint_as_float(v[i] << 16), hi = __uint_as_float(v[i] & 0xffff0000u);
+                lo = lo >= 0.f ? lo : lo * slope;
+                hi = hi >= 0.f ? hi : hi * slope;
+                v[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+            }
+        }
+        return v;
+    }
+};
+
+template <typename CT> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(f32x16& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                      acc, 0, 0, 0);
+    }
+};
+
+template <typename OT> struct Out4;
+template <> struct Out4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = t;
+    }
+};
+template <> struct Out4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        uint2 t;
+        t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = t;
+    }
+};
+
+// IT: input element type, CT: MFMA operand / packed-weight type, OT: output (and residual) type
+template <typename IT, typename CT, typename OT, int WM, int WN>
+__global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
+    constexpr int KS = MfmaK<CT>::KS;
+    constexpr int E = KS / 2;  // elements per lane per fragment
+    using AF = typename BFrag<IT, CT>::type;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int phase = blockIdx.z;
+    const int n0 = (blockIdx.x * 4 + wid) * (WN * 32);
+    const int mt0 = blockIdx.y * WM;
+    if (n0 >= a.n_rows) return;
+    const int j = lane & 31, hf = lane >> 5;
+    const int ksteps = a.cin / KS;
+    const IT* X = reinterpret_cast<const IT*>(a.X);
+    // packed weights: 16 bytes per lane per (phase, tap, mtile, kstep)
+    const uint4* Wp = reinterpret_cast<const uint4*>(a.W);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int k = 0; k < WN; ++k)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][k][q] = 0.f;
+
+    for (int t = 0; t < a.ntaps; ++t) {
+        const int sh = a.pshift[phase] + a.tshift[t];
+        const IT* xrow[WN];
+        bool ok[WN];
+#pragma unroll
+        for (int k = 0; k < WN; ++k) {
+            const int row = n0 + k * 32 + j + sh;
+            ok[k] = (row >= 0) && (row < a.n_in);
+            xrow[k] = X + (size_t)(ok[k] ? row : 0) * a.ldx + hf * E;
+        }
+        const uint4* wt = Wp + ((size_t)(phase * a.ntaps + t) * a.mtiles) * ksteps * 64 + lane;
+#pragma unroll 2
+        for (int ks = 0; ks < ksteps; ++ks) {
+            AF bf[WN];
+#pragma unroll
+            for (int k = 0; k < WN; ++k) bf[k] = BFrag<IT, CT>::load(xrow[k] + ks * KS, ok[k], a.in_slope);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int mt = mt0 + i;
+                if (mt < a.mtiles) {
+                    uint4 wa = wt[((size_t)mt * ksteps + ks) * 64];
+                    AF af = __builtin_bit_cast(AF, wa);
+#pragma unroll
+                    for (int k = 0; k < WN; ++k) Mma<CT>::run(acc[i][k], af, bf[k]);
+                }
+            }
+        }
+    }
+
+    // epilogue
+    OT* Y = reinterpret_cast<OT*>(a.Y);
+    const OT* R = reinterpret_cast<const OT*>(a.res);
+    const float* A = reinterpret_cast<const float*>(a.add);
+#pragma unroll
+    for (int k = 0; k < WN; ++k) {
+        const int n = n0 + k * 32 + j;
+        if (n >= a.n_rows) continue;
+        const size_t orow = (size_t)n * a.omul + phase;
+        const float mk = a.mask ? a.mask[orow] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int mt = mt0 + i;
+            if (mt >= a.mtiles) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = mt * 32 + 8 * g + 4 * hf;
+                if (m >= a.cout) continue;
+                const bool full = (m + 4 <= a.cout);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][k][4 * g + e];
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (full || m + e < a.cout) ? a.bias[m + e] : 0.f;
+                }
+                if (A) {
+                    const float* ap = A + (a.ld_add ? orow * (size_t)a.ld_add : (size_t)0) + m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (full || m + e < a.cout) ? ap[e] : 0.f;
+                }
+                if (a.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (a.act == ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+                }
+                OT* yp = Y + orow * a.ldy + m;
+                if (full) {
+                    if (R) {
+                        float rv[4];
+                        Out4<OT>::load(R + orow * a.ld_res + m, rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * mk * a.scale;
+                    if (a.accumulate) {
+                        float ov[4];
+                        Out4<OT>::load(yp, ov);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += ov[e];
+                    }
+                    Out4<OT>::store(yp, v);
+                } else {
+                    for (int e = 0; e < 4 && m + e < a.cout; ++e) {
+                        float x = v[e];
+                        if (R) x += to_f32<OT>(R[orow * a.ld_res + m + e]);
+                        x = x * mk * a.scale;
+                        if (a.accumulate) x += to_f32<OT>(yp[e]);
+                        yp[e] = from_f32<OT>(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Pack torch-layout fp32 weights into fragment order.
+//   src element (m, c, kk) at src[m*sm + c*sc + kk*sk];  tap index kk(phase r, tap t):
+//   conv: kk = t ; transposed conv (u > 0): kk = (r + pad) % u + t*u, zero panel when kk >= k.
+template <typename CT>
+__global__ void tapgemm_pack_kernel(const float* __restrict__ src, CT* __restrict__ dst, int cout, int cin,
+                                    int k, int64_t sm, int64_t sc, int64_t sk, int nphase, int ntaps, int u,
+                                    int pad, int mtiles) {
+    constexpr int KS = MfmaK<CT>::KS;
+    constexpr int E = KS / 2;
+    const int ksteps = cin / KS;
+    const size_t total = (size_t)nphase * ntaps * mtiles * ksteps * 64 * E;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int e = r % E; r /= E;
+        const int lane = r % 64; r /= 64;
+        const int ks = r % ksteps; r /= ksteps;
+        const int mt = r % mtiles; r /= mtiles;
+        const int t = r % ntaps; r /= ntaps;
+        const int ph = (int)r;
+        const int m = mt * 32 + (lane & 31);
+        const int c = ks * KS + (lane >> 5) * E + e;
+        const int kk = (u > 0) ? ((ph + pad) % u + t * u) : t;
+        float v = 0.f;
+        if (m < cout && kk < k) v = src[m * sm + c * sc + kk * sk];
+        dst[idx] = from_f32<CT>(v);
+    }
+}
+
+}  // namespace gsv

@@ -1,0 +1,123 @@
+// Small layout / elementwise kernels of the SoVITS flow + Generator path (gfx950).
+// Everything dense goes through tapgemm.h; these only move or gate data.
+#pragma once
+#include "gsv_common.h"
+
+namespace gsv {
+
+// torch channels-first fp32 [C][T]  ->  channels-last AT [T][ld] (pad channels zeroed)
+template <typename AT>
+__global__ void cf_to_cl_kernel(const float* __restrict__ src, AT* __restrict__ dst, int C, int T, int ld) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? src[(size_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < ld) dst[(size_t)t * ld + c] = from_f32<AT>(tile[tx][i]);
+    }
+}
+
+// channels-last AT [T][ld] -> torch channels-first fp32 [C][T]
+template <typename AT>
+__global__ void cl_to_cf_kernel(const AT* __restrict__ src, float* __restrict__ dst, int C, int T, int ld) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        tile[i][tx] = (t < T && c < C) ? to_f32<AT>(src[(size_t)t * ld + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < C && t < T) dst[(size_t)c * T + t] = tile[tx][i];
+    }
+}
+
+// Flip (modules.py:504-511): dst[t][c] = src[t][C-1-c]
+template <typename AT>
+__global__ void flip_kernel(const AT* __restrict__ src, AT* __restrict__ dst, int C, int T, int ld) {
+    const size_t n = (size_t)T * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / C;
+        const int c = (int)(i % C);
+        dst[t * ld + c] = src[t * ld + (C - 1 - c)];
+    }
+}
+
+// fused_add_tanh_sigmoid_multiply (commons.py:14-21), conditioning already added by the conv
+// epilogue: acts[t][c] = tanh(a[t][c]) * sigmoid(a[t][H + c])
+template <typename AT>
+__global__ void gate_kernel(const AT* __restrict__ a, AT* __restrict__ acts, int H, int T) {
+    const size_t n = (size_t)T * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / H;
+        const int c = (int)(i % H);
+        const float ta = to_f32<AT>(a[t * 2 * H + c]);
+        const float sa = to_f32<AT>(a[t * 2 * H + H + c]);
+        acts[t * H + c] = from_f32<AT>(tanhf(ta) * (1.0f / (1.0f + expf(-sa))));
+    }
+}
+
+// W = v * (g / ||v||) per output row (torch.nn.utils.weight_norm, dim=0); one block per row
+__global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                        float* __restrict__ w, int row_elems, float sign) {
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    const float* vr = v + (size_t)r * row_elems;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < row_elems; i += blockDim.x) s += vr[i] * vr[i];
+    s = block_sum<4>(s, red);
+    const float f = sign * g[r] / sqrtf(s);
+    for (int i = threadIdx.x; i < row_elems; i += blockDim.x) w[(size_t)r * row_elems + i] = vr[i] * f;
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float s) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i] * s;
+}
+
+template <typename WT>
+__global__ void convert_kernel(const float* __restrict__ src, WT* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<WT>(src[i]);
+}
+
+// generic gather-pack: dst[i] = src[map(i)] for the decode weight panels (see t2s pack lambdas)
+// qkv head panels: dst[h][r][c], r in [0,96): q/k/v row (r/32)*512 + h*32 + r%32
+template <typename WT>
+__global__ void pack_qkv_panel_kernel(const float* __restrict__ w, WT* __restrict__ dst) {
+    const size_t n = (size_t)16 * 96 * 512;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % 512;
+        const int r = (i / 512) % 96;
+        const int h = i / (512 * 96);
+        const int row = (r / 32) * 512 + h * 32 + (r % 32);
+        dst[i] = from_f32<WT>(w[(size_t)row * 512 + c]);
+    }
+}
+__global__ void pack_qkv_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16 * 96) {
+        const int r = i % 96, h = i / 96;
+        dst[i] = b[(r / 32) * 512 + h * 32 + (r % 32)];
+    }
+}
+// column-slice panels: dst[j][n][i] = w[n][j*K + i], w is [512][J*K]
+template <typename WT>
+__global__ void pack_col_panel_kernel(const float* __restrict__ w, WT* __restrict__ dst, int J, int K) {
+    const size_t n = (size_t)J * 512 * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = idx % K;
+        const int row = (idx / K) % 512;
+        const int j = idx / ((size_t)K * 512);
+        dst[idx] = from_f32<WT>(w[(size_t)row * (J * K) + (size_t)j * K + i]);
+    }
+}
+
+}  // namespace gsv

@@ -1,0 +1,197 @@
+"""SynthesizerTrn: host-side mirror of the reference's SoVITS runtime for the decode path.
+
+Mirrors gsv_tts/GPT_SoVITS/SoVITS/models.py (class SynthesizerTrn): `initialize_runtime`,
+`decode(codes, text, ge, noise_scale, speed, cuda_graph, stream_mode, valid_start_idx,
+overlap_len, slice_indices) -> (o, attn)`, `flow_dec(z_p, y_mask, ge) -> o`, and the attributes
+TTS reads (`samples_per_frame`, `enc_p.y_overlap`, `enc_p.mrte.cross_attention.attn`).
+
+flow + Generator (models.py:58-65, 113-132 -- the >90% of vocoder time)
+run as hand-written HIP behind `gsv_voc_flow_dec`.  The text/ssl encoder `enc_p` (a "next"
+row) is plain torch in sovits_encoder.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+V2PRO_SET = {"v2Pro", "v2ProPlus"}
+
+
+class _VocoderNative:
+    """flow + dec behind the C ABI; owns the native handle and a caller-side workspace."""
+
+    def __init__(self, hps_model, weights, dtype, device):
+        m = hps_model
+        L = N.lib()
+        cfg = N.VocConfig()
+        cfg.inter_channels = m["inter_channels"]
+        cfg.hidden_channels = m["hidden_channels"]
+        cfg.gin_channels = m["gin_channels"]
+        cfg.upsample_initial_channel = m["upsample_initial_channel"]
+        cfg.n_upsample = len(m["upsample_rates"])
+        for i, (u, k) in enumerate(zip(m["upsample_rates"], m["upsample_kernel_sizes"])):
+            cfg.upsample_rates[i] = u
+            cfg.upsample_kernel_sizes[i] = k
+        cfg.n_resblock_kernels = len(m["resblock_kernel_sizes"])
+        for i, k in enumerate(m["resblock_kernel_sizes"]):
+            cfg.resblock_kernel_sizes[i] = k
+        dil = m["resblock_dilation_sizes"][0]
+        for d in m["resblock_dilation_sizes"]:
+            if list(d) != list(dil):
+                raise ValueError("per-resblock dilation sets are not supported")
+        for i, d in enumerate(dil):
+            cfg.resblock_dilations[i] = d
+        cfg.n_flows = 4
+        cfg.dtype = N.dtype_code(dtype)
+        self.device = torch.device(device)
+        self.gin = m["gin_channels"]
+        self.inter = m["inter_channels"]
+        self.samples_per_frame = int(np.prod(m["upsample_rates"]))
+        h = ctypes.c_void_p()
+        N.check(L.gsv_voc_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        stream = N.current_stream_ptr(self.device)
+        for name, t in weights.items():
+            if not (name.startswith("dec.") or name.startswith("flow.")):
+                continue
+            d = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            N.check(L.gsv_voc_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
+        N.check(L.gsv_voc_finalize(h, stream))
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                N.lib().gsv_voc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _workspace(self, T):
+        need = N.lib().gsv_voc_workspace(self._h, T)
+        if need == 0:
+            raise RuntimeError("gsv_voc_workspace failed")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _prep(self, z, ge):
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        ge = ge.to(device=self.device, dtype=torch.float32).contiguous()
+        assert z.dim() == 3 and z.shape[0] == 1, "flow/dec run one (possibly time-concatenated) sequence"
+        T = z.shape[2]
+        Tg = ge.shape[2]
+        return z, ge, T, Tg
+
+    def flow_dec(self, z_p, y_mask, ge):
+        z, ge, T, Tg = self._prep(z_p, ge)
+        mask = y_mask.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+        out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        ws = self._workspace(T)
+        N.check(N.lib().gsv_voc_flow_dec(self._h, z.data_ptr(), mask.data_ptr(), ge.data_ptr(), T, Tg, out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
+        return out
+
+    def flow(self, z_p, y_mask, ge):
+        z, ge, T, Tg = self._prep(z_p, ge)
+        mask = y_mask.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+        out = torch.empty_like(z)
+        ws = self._workspace(T)
+        N.check(N.lib().gsv_voc_flow(self._h, z.data_ptr(), mask.data_ptr(), ge.data_ptr(), T, Tg, out.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
+        return out
+
+    def dec(self, z, ge):
+        z, ge, T, Tg = self._prep(z, ge)
+        out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        ws = self._workspace(T)
+        N.check(N.lib().gsv_voc_dec(self._h, z.data_ptr(), ge.data_ptr(), T, Tg, out.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), N.current_stream_ptr(self.device)))
+        return out
+
+
+class SynthesizerTrn:
+    def __init__(self, spec_channels, segment_size, inter_channels, hidden_channels, filter_channels, n_heads,
+                 n_layers, kernel_size, p_dropout, resblock, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_initial_channel, upsample_kernel_sizes, n_speakers=0, gin_channels=0,
+                 semantic_frame_rate="25hz", freeze_quantizer=None, version="v2", **kwargs):
+        self.hps_model = dict(inter_channels=inter_channels, hidden_channels=hidden_channels,
+                              filter_channels=filter_channels, n_heads=n_heads, n_layers=n_layers,
+                              kernel_size=kernel_size, p_dropout=p_dropout, resblock=resblock,
+                              resblock_kernel_sizes=list(resblock_kernel_sizes),
+                              resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes],
+                              upsample_rates=list(upsample_rates), upsample_initial_channel=upsample_initial_channel,
+                              upsample_kernel_sizes=list(upsample_kernel_sizes), gin_channels=gin_channels,
+                              version=version)
+        self.inter_channels = inter_channels
+        self.gin_channels = gin_channels
+        self.upsample_rates = list(upsample_rates)
+        self.samples_per_frame = math.prod(self.upsample_rates)
+        self.semantic_frame_rate = semantic_frame_rate
+        self.version = version
+        self.is_v2pro = version in V2PRO_SET
+        self.cuda_graph_buckets = []
+        self._weights = None
+        self._voc = None
+        self.enc_p = None
+
+    def load_state_dict(self, sd, strict=False):
+        self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
+                         for k, v in sd.items()}
+
+    def eval(self):
+        return self
+
+    @torch.inference_mode()
+    def initialize_runtime(self, dtype, device, sovits_caches):
+        """models.py:322-369.  The reference captures one CUDA graph per cache length; here the
+        native path has no per-length state (it allocates nothing per call), so `sovits_caches`
+        only records the bucket list for API compatibility."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the MI355X hot path needs a GPU device; there is no CPU fallback")
+        self.device, self.dtype = device, dtype
+        self._voc = _VocoderNative(self.hps_model, self._weights, dtype, device)
+        self.cuda_graph_buckets = sorted(sovits_caches)
+        try:
+            from .sovits_encoder import TextEncoder, codebook_decode  # torch, "next" row
+            self.enc_p = TextEncoder(self.hps_model, self._weights, device)
+            self._codebook_decode = codebook_decode
+        except KeyError:
+            self.enc_p = None  # hot-path-only weight sets (no enc_p tensors): flow_dec still works
+
+    def flow_dec(self, z_p, y_mask, ge):
+        """models.py:380-383"""
+        return self._voc.flow_dec(z_p, y_mask, ge)
+
+    @torch.inference_mode()
+    def decode(self, codes, text, ge, noise_scale=0.5, speed=1, cuda_graph=True, stream_mode=False,
+               valid_start_idx=None, overlap_len=None, slice_indices=None, generator=None):
+        """models.py:385-429"""
+        if self.enc_p is None:
+            raise RuntimeError("decode() needs the enc_p / quantizer tensors in the state dict")
+        w = self._weights
+        quantized = self._codebook_decode(w, codes.to(self.device))
+        quantized = F.interpolate(quantized, size=quantized.shape[-1] * 2, mode="nearest")
+        ge = ge.to(device=self.device, dtype=torch.float32)
+        if ge.shape[-1] != 1:
+            ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
+        ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
+        m_p, logs_p, y_mask = self.enc_p.infer(quantized, text.to(self.device), ge_in, speed, stream_mode,
+                                               valid_start_idx, overlap_len, slice_indices)
+        if speed != 1 and ge.shape[-1] != 1:
+            ge = F.interpolate(ge, size=m_p.shape[-1], mode="nearest")
+        if noise_scale != 0:
+            noise = torch.randn(m_p.shape, dtype=m_p.dtype, device=m_p.device, generator=generator)
+            z_p = m_p + noise * torch.exp(logs_p) * noise_scale
+        else:
+            z_p = m_p
+        o = self.flow_dec(z_p, y_mask, ge)
+        attn = self.enc_p.mrte.cross_attention.attn
+        return o, attn[0, ...]

@@ -1,0 +1,410 @@
+"""Text2SemanticDecoder: host-side mirror of the reference's GPT runtime, driving the HIP path.
+
+Mirrors gsv_tts/GPT_SoVITS/GPT/t2s_model.py (class Text2SemanticDecoder): the same
+constructor config, `initialize_runtime(dtype, device, gpt_cache)`, `infer`, `infer_batched`,
+bucket bookkeeping and return conventions -- but every tensor op of the reference's hot loop
+(embedding, 24 post-LN blocks, nested KV cache, logits, greedy sampling, next-token
+embedding) is one C-ABI call into libgsv_hip.so.  torch is used for device memory, the
+current stream, and (only when top_k != 1) the stochastic sampler.
+
+Quirks of the reference that are reproduced on purpose:
+  * the token sampled from the prefill logits is fed back but never returned;
+  * `infer` output = every sample up to (excluding) the first EOS; the reference only *tests*
+    EOS every `check_interval` steps, which changes when it stops, never what it returns;
+  * `infer_batched`: no repetition penalty, no early suppression, capacity stop at
+    kv_len + check_interval >= bucket.max_kv, completion-order output + semantic_orig_idx,
+    finished slots refilled by a B=1 prefill, idle slots keep stepping.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class Bucket:
+    """t2s_model.py:146-156 -- all buckets of a batch size alias one KV storage (nested cache)."""
+
+    def __init__(self, batch_size, max_kv_cache, owner):
+        self.batch_size = batch_size
+        self.max_kv_cache = max_kv_cache
+        self._o = owner
+
+    @property
+    def k_cache(self):
+        return self._o["k"][:, :, :, : self.max_kv_cache]
+
+    @property
+    def v_cache(self):
+        return self._o["v"][:, :, :, : self.max_kv_cache]
+
+    @property
+    def kv_cache_len(self):
+        return self._o["kv_len"]
+
+
+def _sine_pe(n_pos, dim):
+    """embedding.py:52-69 (fp32 on host, like the reference)."""
+    position = torch.arange(0, n_pos, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe = torch.zeros(n_pos, dim)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def sample_from_logits(logits, top_k=15, top_p=1.0, temperature=1.0, generator=None):
+    """Stochastic tail of GPT/utils.py:29-59 on logits that already carry suppression and the
+    repetition penalty (both applied on device by the logits kernel)."""
+    if top_p is not None and top_p < 1.0:
+        sl, si = torch.sort(logits, descending=True)
+        cum = torch.cumsum(torch.softmax(sl, dim=-1), dim=-1)
+        rem = cum > top_p
+        rem[:, 0] = False
+        logits = logits.masked_fill(rem.scatter(1, si, rem), -float("inf"))
+    logits = logits / max(temperature, 1e-5)
+    if top_k is not None:
+        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
+        logits = torch.where(logits < v[:, -1:], -float("inf"), logits)
+    probs = torch.softmax(logits, dim=-1)
+    q = torch.empty_like(probs).exponential_(1, generator=generator)
+    return torch.argmax(probs / q, dim=-1)
+
+
+class Text2SemanticDecoder:
+    def __init__(self, config):
+        m = config["model"]
+        self.config = config
+        self.model_dim = m["hidden_dim"]
+        self.embedding_dim = m["embedding_dim"]
+        self.num_head = m["head"]
+        self.num_layers = m["n_layer"]
+        self.vocab_size = m["vocab_size"]
+        self.phoneme_vocab_size = m["phoneme_vocab_size"]
+        self.EOS = m["EOS"]
+        self.suppressed_tokens = [280, 486, self.EOS]
+        self.cuda_graph_buckets = {}
+        self.use_graph = True
+        self._weights = None
+        self._h = None
+        self._rt = {}
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd):
+        self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
+                         for k, v in sd.items()}
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ runtime
+    @torch.inference_mode()
+    def initialize_runtime(self, dtype, device, gpt_cache):
+        """t2s_model.py:210-298.  Builds the native handle, uploads/repacks weights, allocates the
+        nested KV cache (one root K and V; per batch size a [L,B,H,T,Dh] view; smaller buckets
+        are prefix slices on T) and binds one state per batch size."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the MI355X hot path needs a GPU device (got %s); there is no CPU fallback" % device)
+        if self._weights is None:
+            raise RuntimeError("load_state_dict() first")
+        L = N.lib()
+        self.device, self.dtype = device, dtype
+        cfg = N.T2SConfig(self.num_layers, self.model_dim, self.num_head, self.vocab_size, self.EOS, 4000,
+                          self.phoneme_vocab_size, N.dtype_code(dtype))
+        h = ctypes.c_void_p()
+        N.check(L.gsv_t2s_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        stream = N.current_stream_ptr(device)
+        pe = _sine_pe(4000, self.embedding_dim)
+        for name, t in self._weights.items():
+            if name.endswith("position.alpha"):
+                scaled = (t.float().reshape(1) * pe).contiguous()
+                nm = name.replace("alpha", "pe_scaled")
+                d = scaled.to(device)
+                N.check(L.gsv_t2s_load_tensor(h, nm.encode(), d.data_ptr(), d.numel(), stream))
+                continue
+            d = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            N.check(L.gsv_t2s_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
+        N.check(L.gsv_t2s_finalize(h, stream))
+
+        for batch_size, max_kv in gpt_cache:
+            self.cuda_graph_buckets.setdefault(batch_size, [])
+            if max_kv not in self.cuda_graph_buckets[batch_size]:
+                self.cuda_graph_buckets[batch_size].append(max_kv)
+        max_elem = max(b * max(ts) for b, ts in self.cuda_graph_buckets.items())
+        numel = self.num_layers * max_elem * self.model_dim
+        self.k_cache_root = torch.zeros(numel, dtype=dtype, device=device)
+        self.v_cache_root = torch.zeros(numel, dtype=dtype, device=device)
+        dh = self.model_dim // self.num_head
+        for b in sorted(self.cuda_graph_buckets):
+            ts = sorted(self.cuda_graph_buckets[b])
+            T = ts[-1]
+            n = self.num_layers * b * T * self.model_dim
+            rt = {
+                "batch": b, "T": T,
+                "k": self.k_cache_root[:n].view(self.num_layers, b, self.num_head, T, dh),
+                "v": self.v_cache_root[:n].view(self.num_layers, b, self.num_head, T, dh),
+                "kv_len": torch.zeros(b, dtype=torch.int64, device=device),
+                "x_len": torch.zeros(b, dtype=torch.int64, device=device),
+                "pre_tokens": torch.zeros(b, T + 1, dtype=torch.int64, device=device),
+                "seen": torch.zeros(b, self.vocab_size, dtype=torch.uint8, device=device),
+                "step": torch.zeros(b, dtype=torch.int32, device=device),
+                "eos_at": torch.full((b,), -1, dtype=torch.int32, device=device),
+                "logits": torch.zeros(b, self.vocab_size, dtype=torch.float32, device=device),
+                "hidden": torch.zeros(b, self.model_dim, dtype=torch.float32, device=device),
+                "tok_override": torch.zeros(b, dtype=torch.int64, device=device),
+                "ctl": torch.zeros(4, dtype=torch.int32, device=device),
+                "fctl": torch.ones(4, dtype=torch.float32, device=device),
+            }
+            st = N.T2SState(b, T, *[rt[k].data_ptr() for k in (
+                "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden",
+                "tok_override", "ctl", "fctl")])
+            N.check(L.gsv_t2s_bind_state(h, ctypes.byref(st)))
+            self._rt[b] = rt
+            self.cuda_graph_buckets[b] = [Bucket(b, t, rt) for t in ts]
+        self._ws = None
+        torch.cuda.synchronize(device)
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                N.lib().gsv_t2s_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ pieces (C-ABI seams)
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def embed_prompt(self, xs: List[torch.Tensor], ys: List[torch.Tensor], berts: List[torch.Tensor]):
+        """process_single_data / process_batch_data (t2s_model.py:300-383): packed rows
+        [x_b | y_b | 0-pad] -> (xy float32 [n, Lmax, D], x_lens, y_lens)."""
+        n = len(xs)
+        dev = self.device
+        x_lens = torch.tensor([int(t.shape[0]) for t in xs], dtype=torch.int64)
+        y_lens = torch.tensor([int(t.shape[0]) for t in ys], dtype=torch.int64)
+        lx, ly = int(x_lens.max()), int(y_lens.max())
+        lmax = int((x_lens + y_lens).max())
+        xi = torch.zeros(n, lx, dtype=torch.int64, device=dev)
+        yi = torch.zeros(n, ly, dtype=torch.int64, device=dev)
+        bt = torch.zeros(n, lx, 1024, dtype=torch.float32, device=dev)
+        for i in range(n):
+            xi[i, : x_lens[i]] = xs[i].to(dev)
+            yi[i, : y_lens[i]] = ys[i].to(dev)
+            bt[i, : x_lens[i]] = berts[i].to(device=dev, dtype=torch.float32)
+        xl, yl = x_lens.to(dev), y_lens.to(dev)
+        xy = torch.empty(n, lmax, self.model_dim, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n * lx, self.model_dim, dtype=torch.float32, device=dev)
+        N.check(N.lib().gsv_t2s_embed_prompt(self._h, n, lx, ly, lmax, xi.data_ptr(), yi.data_ptr(), bt.data_ptr(),
+                                              xl.data_ptr(), yl.data_ptr(), xy.data_ptr(), scratch.data_ptr(),
+                                              N.current_stream_ptr(dev)))
+        return xy, xl, yl, x_lens, y_lens
+
+    def prefill(self, batch, slot0, xy, xl, yl):
+        """T2STransformer.process_prompt + first logits (t2s_model.py:114-127, 414-417, 608-613)."""
+        n, lmax, _ = xy.shape
+        L = N.lib()
+        need = L.gsv_t2s_prefill_workspace(self._h, n, lmax)
+        ws = self._workspace(need)
+        N.check(L.gsv_t2s_prefill(self._h, batch, slot0, n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
+
+    def decode_hidden(self, batch, x):
+        """T2STransformer.decode_next_token for an explicit x [B, D] (t2s_model.py:129-143)."""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        N.check(N.lib().gsv_t2s_decode_hidden(self._h, batch, x.data_ptr(), N.current_stream_ptr(self.device)))
+        return self._rt[batch]["hidden"]
+
+    def _decode(self, batch, n):
+        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, 1 if self.use_graph else 0,
+                                       N.current_stream_ptr(self.device)))
+
+    def _flush(self, batch):
+        N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))
+
+    def _set_ctl(self, rt, use_override, suppress_steps, rep_enabled, rep):
+        rt["ctl"].copy_(torch.tensor([int(use_override), int(suppress_steps), int(rep_enabled), 0], dtype=torch.int32))
+        rt["fctl"].copy_(torch.tensor([float(rep), 0.0, 0.0, 0.0], dtype=torch.float32))
+
+    # ------------------------------------------------------------------ drivers
+    @torch.inference_mode()
+    def infer(self, x, y, bert_feature, top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
+              repetition_penalty: float = 1.35, initial_suppression_steps: int = 10, check_interval: int = 5,
+              generator=None):
+        """t2s_model.py:385-464.  x int64[1,Lx], y int64[1,Ly], bert [1,Lx,1024] -> int64[1,1,N]."""
+        rt = self._rt[1]
+        buckets = self.cuda_graph_buckets[1]
+        lx, ly = int(x.shape[1]), int(y.shape[1])
+        Lp = lx + ly
+        if Lp > buckets[-1].max_kv_cache:
+            raise ValueError("prompt of %d positions exceeds the largest KV bucket (%d)" % (Lp, buckets[-1].max_kv_cache))
+        n_iter = buckets[-1].max_kv_cache - Lp
+        if n_iter < 1:
+            raise RuntimeError("no decode iterations: prompt fills the largest bucket")
+        greedy = top_k == 1
+        rep_on = repetition_penalty != 1.0
+        self._set_ctl(rt, not greedy, initial_suppression_steps, rep_on, repetition_penalty)
+        rt["seen"].zero_()
+        if rep_on:
+            rt["seen"][0, y[0].to(self.device)] = 1
+        xy, xl, yl, _, _ = self.embed_prompt([x[0]], [y[0]], [bert_feature[0]])
+        self.prefill(1, 0, xy, xl, yl)
+        done = 0
+        eos_at = -1
+        if greedy:
+            while done < n_iter:
+                n = min(check_interval, n_iter - done)
+                self._decode(1, n)
+                done += n
+                self._flush(1)
+                eos_at = int(rt["eos_at"][0].item())  # host sync every check_interval steps, like the reference
+                if eos_at >= 0:
+                    break
+        else:
+            while done < n_iter:
+                tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
+                rt["tok_override"].copy_(tok)
+                self._decode(1, 1)
+                done += 1
+                if done % check_interval == 0:
+                    eos_at = int(rt["eos_at"][0].item())
+                    if eos_at >= 0:
+                        break
+            if eos_at < 0:
+                tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
+                rt["tok_override"].copy_(tok)
+                self._flush(1)
+                eos_at = int(rt["eos_at"][0].item())
+        # sample s_i sits at kv position Lp + i; s_0 (the prefill sample) is never returned
+        n_valid = done if eos_at < 0 else min(done, eos_at - 1)
+        out = rt["pre_tokens"][0, Lp + 1: Lp + 1 + n_valid].clone()
+        return out.unsqueeze(0).unsqueeze(0)
+
+    @torch.inference_mode()
+    def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
+                      top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
+                      repetition_penalty: float = 1.35, check_interval: int = 5, generator=None):
+        """t2s_model.py:555-734: continuous batching over the slots of one batch-size family."""
+        B = len(x)
+        sizes = sorted(self.cuda_graph_buckets)
+        batch_size = sizes[-1]
+        for s in sizes:
+            if s >= B:
+                batch_size = s
+                break
+        rt = self._rt[batch_size]
+        buckets = self.cuda_graph_buckets[batch_size]
+        caps = [b.max_kv_cache for b in buckets]
+        actual = min(B, batch_size)
+        greedy = top_k == 1
+        self._set_ctl(rt, not greedy, 0, False, 1.0)
+        dev = self.device
+        rt["kv_len"].zero_()
+        rt["x_len"].zero_()
+        xy, xl, yl, x_lens_h, y_lens_h = self.embed_prompt(x[:actual], y[:actual], bert_feature[:actual])
+        lmax = xy.shape[1]
+        bucket_i = len(caps) - 1
+        for i, c in enumerate(caps):
+            if c > lmax:
+                bucket_i = i
+                break
+        if lmax > caps[-1]:
+            raise ValueError("prompt longer than the largest KV bucket")
+        self.prefill(batch_size, 0, xy, xl, yl)
+        rows = torch.arange(batch_size, device=dev)
+
+        have_tok = False
+
+        def draw():
+            tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
+            rt["tok_override"].copy_(tok)
+
+        pred, orig = [], []
+        slot_orig = list(range(batch_size))
+        steps = [0] * batch_size
+        ignore = [i >= actual for i in range(batch_size)]
+        cur = actual
+        stop = False
+        idx = 0
+        while not stop:
+            # the reference tests after steps 1, 6, 11, ... of each 1000-iteration inner loop
+            if greedy:
+                n = 1 if idx == 0 else check_interval
+                n = min(n, 1000 - idx) if idx else 1
+                self._decode(batch_size, n)
+            else:
+                n = 1
+                if not have_tok:
+                    draw()
+                have_tok = False
+                self._decode(batch_size, 1)
+            for b in range(batch_size):
+                steps[b] += n
+            idx += n
+            last = idx - 1
+            if idx >= 1000:
+                idx = 0
+            if last % check_interval != 0:
+                continue
+            if not greedy:
+                draw()
+                have_tok = True
+            self._flush(batch_size)
+            kv = rt["kv_len"].clone()
+            samples = rt["pre_tokens"][rows, kv.clamp(max=rt["T"])]
+            kv_h = kv.tolist()
+            smp = samples.tolist()
+            cap = caps[min(bucket_i, len(caps) - 1)]
+            reached = [k + check_interval >= cap for k in kv_h]
+            eos = [t == self.EOS for t in smp]
+            fin = [(not ignore[b]) and (eos[b] or reached[b]) for b in range(batch_size)]
+            if not any(fin):
+                continue
+            if any(reached):
+                bucket_i += 1
+                if bucket_i < len(caps):
+                    reached = [False] * batch_size
+            fin = [(not ignore[b]) and (eos[b] or reached[b]) for b in range(batch_size)]
+            if not any(fin):
+                continue
+            for i in [b for b in range(batch_size) if fin[b]]:
+                seg = rt["pre_tokens"][i, kv_h[i] - steps[i] + 1: kv_h[i]]
+                e = (seg == self.EOS).nonzero(as_tuple=True)[0]
+                if e.numel() > 0:
+                    seg = seg[: int(e[0].item())]
+                pred.append(seg.clone())
+                orig.append(slot_orig[i])
+                steps[i] = 0
+                kv_h[i] = 0
+                rt["kv_len"][i] = 0
+                mx = max(kv_h)
+                bucket_i = len(caps) - 1
+                for j, c in enumerate(caps):
+                    if c >= mx + check_interval:
+                        bucket_i = j
+                        break
+                if cur == B:
+                    ignore[i] = True
+                    if all(ignore):
+                        stop = True
+                        break
+                else:
+                    xy1, xl1, yl1, xh, yh = self.embed_prompt([x[cur]], [y[cur]], [bert_feature[cur]])
+                    if xy1.shape[1] > caps[-1]:
+                        raise ValueError("prompt longer than the largest KV bucket")
+                    self.prefill(batch_size, i, xy1, xl1, yl1)
+                    if not greedy:  # the refilled slot needs its own first sample (t2s_model.py:713-714)
+                        rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]
+                    kv_h[i] = int(xh[0] + yh[0])
+                    slot_orig[i] = cur
+                    cur += 1
+        return pred, torch.tensor(orig, device=dev)

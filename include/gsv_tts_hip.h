@@ -1,0 +1,167 @@
+/*
+ * gsv_tts_hip.h -- C ABI of the MI355X (gfx950) GPT-SoVITS inference hot path.
+ *
+ * The reference (chinokikiss/GSV-TTS-Lite) has no FFI: its hot path is PyTorch modules
+ * driven from Python.  This header is the boundary a maintainer would bind underneath those
+ * modules (ctypes stub in INTEGRATION.md).  Every entry point names the reference interface
+ * it replaces (file:line in the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types; returns GSV_OK (0) or an
+ *     error code, message via gsv_last_error() (thread-local).  No exceptions cross the ABI.
+ *   - All tensor pointers are DEVICE pointers unless a parameter says "host".
+ *   - `stream` is a hipStream_t passed as void* (torch: torch.cuda.current_stream().cuda_stream).
+ *   - Ownership mirrors the reference: the caller owns KV caches, kv_len and
+ *     every I/O buffer (torch allocations made once in initialize_runtime); the library owns
+ *     only its repacked weight arena and fixed scratch, created at load time.  Nothing is
+ *     allocated or freed inside a step, so steps are hipGraph-capturable.
+ *   - One caller per handle at a time (the reference serialises with TTS._infer_lock,
+ *     gsv_tts/TTS.py:145); distinct handles (one per GPU/process) are independent.
+ */
+#ifndef GSV_TTS_HIP_H
+#define GSV_TTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSV_OK 0
+#define GSV_ERR_ARG 1     /* bad argument / unknown tensor name / shape mismatch */
+#define GSV_ERR_HIP 2     /* a HIP runtime call failed */
+#define GSV_ERR_STATE 3   /* call order violated (e.g. step before finalize/bind) */
+
+#define GSV_F32 0         /* fp32 weights/KV/activations: the bit-exact-token parity mode */
+#define GSV_BF16 1        /* bf16 weights + KV (+ bf16 vocoder activations), fp32 accumulate */
+
+int gsv_version(void);
+const char* gsv_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GPT semantic-token decoder  (reference: gsv_tts/GPT_SoVITS/GPT/t2s_model.py)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gsv_t2s gsv_t2s;
+
+typedef struct {
+    int n_layer, hidden, n_head, vocab, eos; /* config["model"], t2s_model.py:159-168 */
+    int n_pos;                               /* rows of the sinusoidal tables (4000, t2s_model.py:212) */
+    int n_phoneme;                           /* phoneme_vocab_size */
+    int dtype;                               /* GSV_F32 | GSV_BF16 */
+} gsv_t2s_config;
+
+/* replaces Text2SemanticDecoder.__init__ + Loader.get_gpt_weights (gsv_tts/Loader.py:111-170) */
+int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out);
+int gsv_t2s_destroy(gsv_t2s* h);
+
+/* Hand one fp32 device tensor to the library under its reference state-dict name (after the
+ * Loader.py:130-154 remap), e.g. "t2s_transformer.blocks.3.qkv.weight", "ar_predict_layer.weight",
+ * "ar_audio_embedding.word_embeddings.weight", "bert_proj.weight".  Two synthetic names carry
+ * the host-precomputed tables alpha*pe of embedding.py:58-69: "ar_text_position.pe_scaled",
+ * "ar_audio_position.pe_scaled" ([n_pos][hidden]).  The data is converted/repacked into the
+ * library's arena during the call (stream-ordered); the source may be freed afterwards. */
+int gsv_t2s_load_tensor(gsv_t2s* h, const char* name, const float* data, int64_t numel, void* stream);
+/* all tensors present?  builds decode panels; required before any step */
+int gsv_t2s_finalize(gsv_t2s* h, void* stream);
+
+/* Caller-owned runtime state for ONE batch size: the reference's Bucket family for that batch
+ * size (t2s_model.py:146-156, 240-276).  All bucket lengths of a batch size alias one storage
+ * with the largest T as stride, so `max_kv` is that largest T ("nested" KV cache). */
+typedef struct {
+    int batch;              /* B */
+    int max_kv;             /* T: positions per sequence (cache stride) */
+    void* k_cache;          /* [n_layer][B][n_head][T][head_dim], cfg.dtype */
+    void* v_cache;          /* same */
+    int64_t* kv_len;        /* [B]   Bucket.kv_cache_len */
+    int64_t* x_len;         /* [B]   text length per slot (PE offset, t2s_model.py:456,728) */
+    int64_t* pre_tokens;    /* [B][T+1] sampled token at kv position (t2s_model.py:605,653); column T
+                               holds the sample taken when the cache is exactly full */
+    uint8_t* seen;          /* [B][vocab] repetition-penalty membership (prompt + generated) */
+    int32_t* step;          /* [B]   logits launches since the slot was (re)filled */
+    int32_t* eos_at;        /* [B]   first step whose sample was EOS, else -1 */
+    float* logits;          /* [B][vocab] last logits after suppression/penalty (host sampling) */
+    float* hidden;          /* [B][hidden] last final hidden state (Bucket.graph_xy_dec) */
+    int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] != 0 */
+    int32_t* ctl;           /* [4]   {use_override, suppress_steps, rep_enabled, drop_eos_col_steps} */
+    float* fctl;            /* [4]   {repetition_penalty, -, -, -} */
+} gsv_t2s_state;
+int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st);
+
+/* replaces process_single_data / process_batch_data (t2s_model.py:300-383): builds packed rows
+ * [x_b | y_b | 0-pad] = text-emb + bert_proj + alpha_t*pe, audio-emb + alpha_a*pe.
+ *   x_ids [nrows][lx_max], y_ids [nrows][ly_max], bert [nrows][lx_max][1024] (row-padded),
+ *   x_lens/y_lens [nrows] -> xy [nrows][l_max][hidden] fp32.  scratch: [nrows*lx_max][hidden] f32 */
+int gsv_t2s_embed_prompt(gsv_t2s* h, int nrows, int lx_max, int ly_max, int l_max, const int64_t* x_ids,
+                         const int64_t* y_ids, const float* bert, const int64_t* x_lens,
+                         const int64_t* y_lens, float* xy, float* scratch, void* stream);
+
+/* replaces T2STransformer.process_prompt (t2s_model.py:31-65,114-127) + ar_predict_layer +
+ * the first sample (t2s_model.py:414-420, 608-616).  xy [nrows][l_max][hidden] is consumed
+ * (overwritten with the hidden states).  Attention mask is the reference's prompt mask,
+ * implied by (x_len, y_len) per row: text rows see all text, audio rows see all text + causal
+ * audio; rows/cols >= x_len+y_len are padding.  K/V for positions [0, x_len+y_len) go to cache
+ * rows slot0..slot0+nrows-1 of the state bound for `batch`; afterwards for those slots:
+ * kv_len = x_len + y_len, x_len set, step = 0, eos_at = -1, and the first token is pending
+ * (sampled from logits[:, :-1], i.e. EOS impossible; suppression per ctl).
+ * workspace: gsv_t2s_prefill_workspace(h, nrows, l_max) bytes. */
+size_t gsv_t2s_prefill_workspace(gsv_t2s* h, int nrows, int l_max);
+int gsv_t2s_prefill(gsv_t2s* h, int batch, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                    const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
+ * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
+ * final hidden state to state.hidden and bumps kv_len.  No sampling. */
+int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
+
+/* The AR hot loop body (t2s_model.py:430-456 / 637-653, 727-728) `n_steps` times, all on device:
+ * take the pending token (greedy argmax of the penalised logits, or tok_override), record it in
+ * pre_tokens[b][kv_len[b]], build emb + alpha*pe[kv_len - x_len], run the layers, bump kv_len,
+ * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
+ * When use_graph != 0 the step is replayed from a hipGraph captured on first use. */
+int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream);
+/* materialise the pending token of every slot into pre_tokens/seen/eos_at (idempotent) */
+int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SoVITS flow + Generator  (reference: gsv_tts/GPT_SoVITS/SoVITS/models.py, module/modules.py)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gsv_voc gsv_voc;
+
+typedef struct {
+    int inter_channels, hidden_channels, gin_channels, upsample_initial_channel;
+    int n_upsample;
+    int upsample_rates[8], upsample_kernel_sizes[8];
+    int n_resblock_kernels;
+    int resblock_kernel_sizes[4];
+    int resblock_dilations[4];   /* (1,3,5): same for every resblock, modules.py:116 */
+    int n_flows;                 /* 4 coupling layers, models.py:31 */
+    int dtype;                   /* GSV_F32 | GSV_BF16 */
+} gsv_voc_config;
+
+/* replaces SynthesizerTrn.{flow,dec} construction + Loader.get_sovits_weights (Loader.py:59-103) */
+int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out);
+int gsv_voc_destroy(gsv_voc* h);
+/* fp32 device tensor under its state-dict name: "dec.*" (weight-norm removed, Loader.py:95) and
+ * "flow.flows.{0,2,4,6}.*" (weight_g/weight_v still separate; folded by finalize) */
+int gsv_voc_load_tensor(gsv_voc* h, const char* name, const float* data, int64_t numel, void* stream);
+int gsv_voc_finalize(gsv_voc* h, void* stream);
+
+/* replaces SynthesizerTrn.flow_dec (models.py:380-383): o = dec(flow(z_p, mask, ge) * mask, g=ge).
+ *   z_p [inter][T] fp32 channels-first (torch layout), y_mask [T], ge [gin][Tg] with Tg in {1, T}
+ *   (Tg == T: per-frame speaker embedding of the time-concatenated batch, TTS.py:740-744)
+ *   out [T * prod(upsample_rates)] fp32.  workspace from gsv_voc_workspace(h, T). */
+size_t gsv_voc_workspace(gsv_voc* h, int T);
+int gsv_voc_flow_dec(gsv_voc* h, const float* z_p, const float* y_mask, const float* ge, int T, int Tg,
+                     float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* parity seams: the flow alone (ResidualCouplingBlock.forward reverse, models.py:58-65) and the
+ * Generator alone (models.py:113-132); same layouts. */
+int gsv_voc_flow(gsv_voc* h, const float* z_p, const float* y_mask, const float* ge, int T, int Tg,
+                 float* z_out, void* workspace, size_t workspace_bytes, void* stream);
+int gsv_voc_dec(gsv_voc* h, const float* z, const float* ge, int T, int Tg, float* out, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSV_TTS_HIP_H */
