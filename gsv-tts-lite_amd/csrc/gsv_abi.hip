@@ -294,32 +294,43 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     return GSV_OK;
 }
 
+template <typename WT>
+void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsrc, hipStream_t st) {
+    const int B = s.batch, T = s.max_kv;
+    const size_t lds = sizeof(float) * (kAttnLdsFloats + T + 8);
+    const size_t layer_elems = (size_t)B * kH * T * kDh;
+    T2SLayer& L = h->layers[l];
+    AttnArgs<WT> a;
+    a.xdirect = xsrc;
+    a.zpart = h->zpart;
+    a.b2 = l ? h->layers[l - 1].b2 : nullptr;
+    a.x1 = h->x1buf;
+    a.ln2g = l ? h->layers[l - 1].ln2g : nullptr;
+    a.ln2b = l ? h->layers[l - 1].ln2b : nullptr;
+    a.xout = h->xbuf;
+    a.wqkv = (const WT*)L.wqkv_p; a.bqkv = L.bqkv_p; a.wo = (const WT*)L.wo_p;
+    a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
+    a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
+    a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart;
+    if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
+    else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
+}
+
+template <typename WT>
+void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
+    T2SLayer& L = h->layers[l];
+    FfnArgs<WT> f;
+    f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
+    f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart;
+    hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, s.batch), dim3(kNT), 0, st, f);
+}
+
 // the transformer stack for one token per slot; x from `xsrc` [B][512]
 template <typename WT>
 int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st) {
-    const int B = s.batch, T = s.max_kv;
-    const size_t lds = sizeof(float) * (kD + 96 + 32 + 16 + 128 + T + 8);
-    const size_t layer_elems = (size_t)B * kH * T * kDh;
     for (int l = 0; l < h->cfg.n_layer; ++l) {
-        T2SLayer& L = h->layers[l];
-        AttnArgs<WT> a;
-        a.mode = l == 0 ? 0 : 1;
-        a.xdirect = xsrc;
-        a.zpart = h->zpart;
-        a.b2 = l ? h->layers[l - 1].b2 : nullptr;
-        a.x1 = h->x1buf;
-        a.ln2g = l ? h->layers[l - 1].ln2g : nullptr;
-        a.ln2b = l ? h->layers[l - 1].ln2b : nullptr;
-        a.xout = h->xbuf;
-        a.wqkv = (const WT*)L.wqkv_p; a.bqkv = L.bqkv_p; a.wo = (const WT*)L.wo_p;
-        a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
-        a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-        a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart;
-        hipLaunchKernelGGL((t2s_attn_kernel<WT>), dim3(kH, B), dim3(256), lds, st, a);
-        FfnArgs<WT> f;
-        f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
-        f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart;
-        hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(256), 0, st, f);
+        t2s_launch_attn<WT>(h, s, l, xsrc, st);
+        t2s_launch_ffn<WT>(h, s, l, st);
     }
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -330,11 +341,12 @@ int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirec
                int bump, hipStream_t st) {
     const T2SLayer& L = h->layers.back();
     LogitsArgs<WT> a;
-    a.mode = mode; a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
+    a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
     a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0;
     a.step = s.step; a.ctl = s.ctl; a.fctl = s.fctl; a.seen = s.seen; a.logits = s.logits; a.hidden = s.hidden;
     a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;
-    hipLaunchKernelGGL((t2s_logits_kernel<WT>), dim3(kNP, nrows), dim3(256), 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL((t2s_logits_kernel<WT, 0>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
+    else hipLaunchKernelGGL((t2s_logits_kernel<WT, 1>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
@@ -406,6 +418,35 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
 }
 
 }  // namespace
+
+template <typename WT>
+static int t2s_time_impl(gsv_t2s* h, T2SBound* b, int iters, float* out_ms, hipStream_t st) {
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int NL = h->cfg.n_layer;
+    // save the sequence position: the sweeps below re-run real kernels on the live state
+    for (int cls = 0; cls < 4; ++cls) {
+        for (int rep = 0; rep < 2; ++rep) {  // rep 0 = warm-up
+            HIPCHK(hipEventRecord(e0, st));
+            int launches = 0;
+            for (int it = 0; it < (rep ? iters : 1); ++it) {
+                if (cls == 0) for (int l = 0; l < NL; ++l, ++launches) t2s_launch_attn<WT>(h, b->st, l, h->xcur, st);
+                if (cls == 1) for (int l = 0; l < NL; ++l, ++launches) t2s_launch_ffn<WT>(h, b->st, l, st);
+                if (cls == 2) { for (int l = 0; l < NL; ++l, ++launches) if (int rc = t2s_logits<WT>(h, b->st, 1, nullptr, 0, b->st.batch, h->cfg.vocab, 0, st)) return rc; }
+                if (cls == 3) { for (int l = 0; l < NL; ++l, ++launches) if (int rc = t2s_token(h, b->st, 0, st)) return rc; }
+            }
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) out_ms[cls] = ms / (float)launches;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return GSV_OK;
+}
 
 extern "C" {
 
@@ -567,6 +608,14 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
     }
     for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(b->graph, S(stream)));
     return GSV_OK;
+}
+
+int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream) {
+    if (!h || !h->finalized || !out_ms || iters < 1) return fail(GSV_ERR_STATE, "bad call");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    return h->cfg.dtype == GSV_BF16 ? t2s_time_impl<bf16_t>(h, b, iters, out_ms, S(stream))
+                                    : t2s_time_impl<float>(h, b, iters, out_ms, S(stream));
 }
 
 int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream) {

@@ -120,6 +120,11 @@ int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
  * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
  * When use_graph != 0 the step is replayed from a hipGraph captured on first use. */
 int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream);
+/* Measurement aid (bench.py `roofline`): average duration in ms of ONE launch of each decode-step
+ * kernel class {attn, ffn, logits, token}, timed with hipEvents on `stream` around `iters`
+ * back-to-back sweeps over all layers' launches of that class on the live state (every layer
+ * streams its own weights, as in a real step).  out_ms: host float[4].  Leaves kv_len untouched. */
+int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream);
 /* materialise the pending token of every slot into pre_tokens/seen/eos_at (idempotent) */
 int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream);
 
