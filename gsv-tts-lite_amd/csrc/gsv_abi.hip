@@ -162,6 +162,7 @@ struct gsv_t2s {
     float *xcur = nullptr, *xbuf = nullptr, *x1buf = nullptr, *ypart = nullptr, *zpart = nullptr;
     TokPart* tokpart = nullptr;
     hipStream_t cap_stream = nullptr;
+    unsigned long long* dbg = nullptr;
 };
 
 namespace {
@@ -297,7 +298,7 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
 template <typename WT>
 void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsrc, hipStream_t st) {
     const int B = s.batch, T = s.max_kv;
-    const size_t lds = sizeof(float) * (kAttnLdsFloats + T + 8);
+    const size_t lds = 0;  // static LDS only: scores never leave registers
     const size_t layer_elems = (size_t)B * kH * T * kDh;
     T2SLayer& L = h->layers[l];
     AttnArgs<WT> a;
@@ -311,7 +312,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     a.wqkv = (const WT*)L.wqkv_p; a.bqkv = L.bqkv_p; a.wo = (const WT*)L.wo_p;
     a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
     a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-    a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart;
+    a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart; a.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
@@ -321,7 +322,7 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     T2SLayer& L = h->layers[l];
     FfnArgs<WT> f;
     f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
-    f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart;
+    f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, s.batch), dim3(kNT), 0, st, f);
 }
 
@@ -616,6 +617,14 @@ int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* 
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     return h->cfg.dtype == GSV_BF16 ? t2s_time_impl<bf16_t>(h, b, iters, out_ms, S(stream))
                                     : t2s_time_impl<float>(h, b, iters, out_ms, S(stream));
+}
+
+int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
+    if (!h) return fail(GSV_ERR_ARG, "null handle");
+    h->dbg = (unsigned long long*)buf;
+    for (auto& kv : h->bound)
+        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+    return GSV_OK;
 }
 
 int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream) {

@@ -59,15 +59,55 @@ template <int N> struct Ld<bf16_t, N> {
     }
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// ---- wave64 reductions on the DPP cross-lane network (VALU, a few cycles per step) instead of
+// ds_bpermute (an LDS-crossbar round trip of >100 cycles per dependent level).
+//   quad_perm(1,0,3,2), quad_perm(2,3,0,1): butterfly inside each quad
+//   row_half_mirror, row_mirror: fold 8 and 16 lanes (valid because lower levels are already uniform)
+//   row_bcast15 / row_bcast31: carry row totals into the next rows; lane 63 ends with the wave total
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// every lane of an aligned 16-lane row gets the row's sum / max
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
     return v;
+}
+// sums over aligned groups of 4 / 8 lanes, result in every lane of the group
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    return v;
+}
+__device__ __forceinline__ float oct_sum(float v) {
+    v = quad_sum(v);
+    return v + dpp_f32<0x141>(v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    // rows 1 and 3 add rows 0 and 2 (row_bcast15, row_mask 0b1010); rows 2,3 add lane 31 (row_bcast31, 0b1100)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 // Block-wide reductions for 256-thread (4-wave) blocks; `red` is >= 8 floats of LDS.

@@ -50,6 +50,11 @@ struct TokPart {
 //    overlap (one wave issues ~1 VALU op per 4-5 cycles), so a block is 16 waves (1024 threads):
 //    4 waves per SIMD share the rows/keys, each wave's stream is a quarter of a 256-thread block's.
 
+// optional phase timestamps (bring-up aid): block (0,0) thread 0 writes clock64() into dbg[slot]
+__device__ __forceinline__ void stamp(unsigned long long* dbg, int slot) {
+    if (dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[slot] = clock64();
+}
+
 constexpr int kNT = 1024;       // threads per decode block
 constexpr int kNW = kNT / 64;   // 16 waves
 
@@ -180,38 +185,77 @@ template <> __device__ __forceinline__ int sumN_index<4>() {
     return ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
 }
 
-// LayerNorm of a 512-vector, thread t < 512 owning element t (two-pass, like torch)
+// LayerNorm of a 512-vector, thread t < 512 owning element t.  One block reduction of (sum, sum of
+// squares) = ONE barrier; var = E[x^2] - mean^2 in fp32 is within ~1e-6 of torch's two-pass form
+// for these O(1) activations (tests hold it to 2e-5 against the reference's outputs).
+// `red` must hold 2*kNW floats and not be in use by another reduction.
 __device__ __forceinline__ float ln512(float v, bool owner, float g, float bta, float* red) {
-    const float mean = block_sum<kNW>(owner ? v : 0.f, red) * (1.0f / kD);
-    const float d = owner ? v - mean : 0.f;
-    const float var = block_sum<kNW>(d * d, red) * (1.0f / kD);
+    float s = owner ? v : 0.f, q = s * s;
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = s; red[2 * w + 1] = q; }
+    __syncthreads();
+    float ts = 0.f, tq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNW; ++i) { ts += red[2 * i]; tq += red[2 * i + 1]; }
+    const float mean = ts * (1.0f / kD);
+    const float var = fmaxf(tq * (1.0f / kD) - mean * mean, 0.f);
     const float rs = 1.0f / sqrtf(var + kEps);
-    return d * rs * g + bta;
+    return (v - mean) * rs * g + bta;
 }
 
-// sum of NPART partial 512-vectors (+ bias + residual), thread t < 512 owning element t; the loads
-// are issued by `issue` at kernel entry, the sum (fixed index order) happens in `finish`.
+// Sum of NPART partial 512-vectors (+ bias + residual) in two stages so that the global side is a
+// handful of 1-KiB wave loads instead of NPART narrow ones per owner thread (the per-CU address
+// path, not bandwidth, is what a 36-loads-per-thread prologue pays for):
+//   stage A  wave w loads rows w*NPW .. +NPW-1 (16 B per lane), adds them lane-wise, parks the
+//            result in LDS stage[w][512];        -- issue() at kernel entry, park() after the pin
+//   stage B  thread t < 512 adds the 16 parked rows in index order, + bias + residual.
+// Fixed order everywhere => bit-reproducible.
 template <int NPART> struct PartialSum {
-    float p[NPART];
+    static constexpr int NPW = NPART / kNW;     // rows per wave (2 for the 32 FFN slices, 1 for the 16 heads)
+    static_assert(NPART % kNW == 0, "NPART");
+    f32x4 p[NPW][2];
     float bias, resid, lng, lnb;
     __device__ __forceinline__ void issue(const float* __restrict__ part, const float* __restrict__ b,
                                           const float* __restrict__ r, const float* __restrict__ g,
                                           const float* __restrict__ beta) {
-        const int t = threadIdx.x & (kD - 1);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
-        for (int j = 0; j < NPART; ++j) p[j] = part[(size_t)j * kD + t];
-        bias = b[t];
-        resid = r[t];
-        lng = g[t];
-        lnb = beta[t];
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                p[j][c] = *reinterpret_cast<const f32x4*>(part + (size_t)(wid * NPW + j) * kD + c * 256 + lane * 4);
+        if (threadIdx.x < kD) {
+            const int t = threadIdx.x;
+            bias = b[t]; resid = r[t]; lng = g[t]; lnb = beta[t];
+        }
     }
-    __device__ __forceinline__ float finish() {
+    __device__ __forceinline__ void park(float* __restrict__ stage) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 s = p[0][c];
+#pragma unroll
+            for (int j = 1; j < NPW; ++j) s += p[j][c];
+            *reinterpret_cast<f32x4*>(stage + wid * kD + c * 256 + lane * 4) = s;
+        }
+    }
+    __device__ __forceinline__ float finish(const float* __restrict__ stage) {  // owners only, after a barrier
+        const int t = threadIdx.x;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NPART; ++j) s += p[j];
+        for (int w = 0; w < kNW; ++w) s += stage[w * kD + t];
         return s + bias + resid;
     }
 };
+
+template <int G> __device__ __forceinline__ float group_sum(float v) {  // aligned groups of G lanes, all lanes
+    static_assert(G == 4 || G == 8 || G == 16, "group");
+    if constexpr (G == 4) return quad_sum(v);
+    else if constexpr (G == 8) return oct_sum(v);
+    else return row16_sum(v);
+}
 
 // panel GEMV out[row] = dot(P[row][0:K], v) for 512 rows, K in {32, 64}: K/EPL lanes per row.
 template <typename WT, int K> struct Panel {
@@ -239,8 +283,7 @@ template <typename WT, int K> struct Panel {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < EPL; ++i) s = fmaf(wv[i], vr[i], s);
-#pragma unroll
-            for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+            s = group_sum<LPR>(s);
             if (part == 0) out[rsub + it * RPI] = s;
         }
     }
@@ -266,19 +309,22 @@ struct AttnArgs {
     const int64_t* kv_len;
     int T;
     float* ypart;        // [B][16][512]
+    unsigned long long* dbg;
 };
 
-constexpr int kAttnLdsFloats = kD + 96 + 32 + 16 + kNW * 32;  // + T scores
+constexpr int kAttnLdsFloats = kD + 96 + 32 + 2 * kNW + kNW * 32 + 2 * kNW + kNW * kD;
 
 template <typename WT, int MODE>
 __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;            // 512
-    float* qkv = xs + kD;        // 96
-    float* att = qkv + 96;       // 32
-    float* red = att + 32;       // 16
-    float* pacc = red + 16;      // 16*32
-    float* sc = pacc + kNW * 32; // T
+    __shared__ __attribute__((aligned(16))) float smem[kAttnLdsFloats];
+    float* xs = smem;             // 512
+    float* qkv = xs + kD;         // 96
+    float* att = qkv + 96;        // 32
+    float* red = att + 32;        // 2*16
+    float* pacc = red + 2 * kNW;  // 16*32  per-wave un-normalised P.V
+    float* pm = pacc + kNW * 32;  // 16     per-wave running max
+    float* pl = pm + kNW;         // 16     per-wave sum of exp
+    float* stage = pl + kNW;      // 16*512 parked partial sums
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int EPL = Geo<WT>::EPL;
     constexpr int CPR = Geo<WT>::CPR;
@@ -287,22 +333,27 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     constexpr int KCH = 2;                 // iterations held in registers per chunk (512 positions bf16, 256 f32)
     constexpr int RW = 96 / kNW;           // 6 QKV rows per wave
     const bool owner = tid < kD;
+    stamp(a.dbg, 0);
 
     int n = (int)a.kv_len[b];
     if (n > a.T - 1) n = a.T - 1;  // memory safety only; the host never steps a full cache
     if (n < 0) n = 0;
-    const WT* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
-    const WT* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
+    WT* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
+    WT* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
     const int part = tid % LPR, rsub = tid / LPR;
 
     // ---- issue everything whose address is known now, in consumption order
-    PartialSum<MODE ? kNJ : 1> ps;
+    PartialSum<kNJ> ps;
     float xd = 0.f;
-    if (owner) {
-        if constexpr (MODE == 0) xd = a.xdirect[(size_t)b * kD + tid];
-        else ps.issue(a.zpart + (size_t)b * kNJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
+    if constexpr (MODE == 0) {
+        if (owner) xd = a.xdirect[(size_t)b * kD + tid];
+    } else {
+        ps.issue(a.zpart + (size_t)b * kNJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
     }
-    asm volatile("" : : : "memory");  // partials first: consumed first, and loads retire in order
+    // partials first: a CU serves its waves' loads in issue order and waves start staggered, so
+    // without this rendezvous the last wave's partial rows queue behind the first waves' weights
+    if constexpr (MODE != 0) __builtin_amdgcn_s_barrier();
+    asm volatile("" : : : "memory");
     const WT* wp = a.wqkv + ((size_t)h * 96 + wid * RW) * kD;
     raw16 wq[RW][CPR];
 #pragma unroll
@@ -322,19 +373,27 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // chain, so no add can be scheduled above it, while the memory clobber keeps every load above
     // it.  It only needs the FIRST-issued load to have landed.
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
-    else asm volatile("" : "+v"(ps.p[0]) : : "memory");
+    else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
+    stamp(a.dbg, 1);
 
     // ---- layer input
     float v;
-    if constexpr (MODE == 0) v = xd;
-    else v = ln512(owner ? ps.finish() : 0.f, owner, ps.lng, ps.lnb, red);
+    if constexpr (MODE == 0) {
+        v = xd;
+    } else {
+        ps.park(stage);
+        __syncthreads();
+        v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+    }
     if (owner) {
         xs[tid] = v;
         if (h == 0) a.xout[(size_t)b * kD + tid] = v;
     }
     __syncthreads();
+    stamp(a.dbg, 2);
 
-    // ---- q, k, v of this head: 96 rows, 6 per wave
+    // ---- q, k, v of this head: 96 rows, 6 per wave.  k and v are rounded through the cache type
+    //      (this step must see exactly what later steps read back) and appended at position n.
     {
         float xr[8];
         lane_x<WT>(xs, xr);
@@ -342,31 +401,40 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = u < RW ? row_dot<WT>(wq[u < RW ? u : 0], xr) : 0.f;
         const float tot = wave_sumN<8>(acc);
-        if ((lane & 7) == 0 && oi < RW) qkv[wid * RW + oi] = tot + bq;
+        if ((lane & 7) == 0 && oi < RW) {
+            const int row = wid * RW + oi;
+            float val = tot + bq;
+            if (row >= 32) {
+                const WT s = from_f32<WT>(val);
+                val = to_f32<WT>(s);
+                if (row < 64) Kp[(size_t)n * kDh + row - 32] = s; else Vp[(size_t)n * kDh + row - 64] = s;
+            }
+            qkv[row] = val;
+        }
     }
     __syncthreads();
+    stamp(a.dbg, 3);
 
-    WT* Kw = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
-    WT* Vw = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
-    if (tid < 64) {
-        // round through the cache type so this step sees exactly what later steps will read back
-        WT s = from_f32<WT>(qkv[32 + tid]);
-        qkv[32 + tid] = to_f32<WT>(s);
-        if (tid < 32) Kw[(size_t)n * kDh + tid] = s; else Vw[(size_t)n * kDh + tid - 32] = s;
-    }
-    __syncthreads();
-
-    // ---- scores over [0, n]; position n (this token) comes from LDS, the rest from registers/chunks
+    // ---- single-pass attention over [0, n]: every thread owns the same rows of K and of V, so the
+    //      scores never leave registers; each wave keeps a running (max, sum, P.V) and the 16 waves
+    //      are merged once at the end (flash-decoding style, deterministic order).
     const float scale = 0.17677669529663687f;  // 1/sqrt(32)
     float qr[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) qr[i] = qkv[part * EPL + i];
-    for (int c0 = 0; c0 < n; c0 += KCH * RPI) {
+    float m_run = -INFINITY, l_run = 0.f, acc[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+    for (int c0 = 0; c0 == 0 || c0 < n; c0 += KCH * RPI) {
         if (c0 > 0) {
 #pragma unroll
-            for (int it = 0; it < KCH; ++it)
+            for (int it = 0; it < KCH; ++it) {
                 kreg[it] = ldg16(Kp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
+                vreg[it] = ldg16(Vp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
+            }
         }
+        float sv[KCH + 1];
+        float cmax = -INFINITY;
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
             const int r = c0 + rsub + it * RPI;
@@ -375,75 +443,77 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], kk[i], s);
-#pragma unroll
-            for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-            if (part == 0 && r < n) sc[r] = s * scale;
+            s = group_sum<LPR>(s);
+            sv[it] = r < n ? s * scale : -INFINITY;
+            cmax = fmaxf(cmax, sv[it]);
         }
-    }
-    if (tid < LPR) {  // the new token's own key
-        float s = 0.f;
+        {   // the new token's own key/value (position n) rides with wave 0's first chunk
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], qkv[32 + part * EPL + i], s);
-#pragma unroll
-        for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        if (part == 0) sc[n] = s * scale;
-    }
-    __syncthreads();
-    float mx = -INFINITY;
-    for (int r = tid; r <= n; r += kNT) mx = fmaxf(mx, sc[r]);
-    mx = block_max<kNW>(mx, red);
-    float sum = 0.f;
-    for (int r = tid; r <= n; r += kNT) {
-        float e = expf(sc[r] - mx);
-        sc[r] = e;
-        sum += e;
-    }
-    sum = block_sum<kNW>(sum, red);  // (its barriers also publish sc[])
-    {
-        float acc[EPL];
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
-        for (int c0 = 0; c0 < n; c0 += KCH * RPI) {
-            if (c0 > 0) {
-#pragma unroll
-                for (int it = 0; it < KCH; ++it)
-                    vreg[it] = ldg16(Vp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
-            }
-#pragma unroll
-            for (int it = 0; it < KCH; ++it) {
-                const int r = c0 + rsub + it * RPI;
-                float vv[EPL];
-                Unpack<WT, EPL>::run(vreg[it], vv);
-                const bool live = r < n;   // clamped rows hold other data: mask both factors
-                const float p = live ? sc[r] / sum : 0.f;
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, live ? vv[i] : 0.f, acc[i]);
-            }
+            for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], qkv[32 + part * EPL + i], s);
+            s = group_sum<LPR>(s);
+            sv[KCH] = (c0 == 0 && tid < LPR) ? s * scale : -INFINITY;
+            cmax = fmaxf(cmax, sv[KCH]);
         }
-        if (tid < LPR) {
-            const float p = sc[n] / sum;
+        cmax = wave_max(cmax);
+        const float m_new = fmaxf(m_run, cmax);
+        const float mref = (m_new == -INFINITY) ? 0.f : m_new;
+        const float f = expf(m_run - mref);      // exp(-inf) = 0 on the first live chunk
+        l_run *= f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) acc[i] *= f;
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            const float p = expf(sv[it] - mref);  // 0 for masked rows
+            const bool live = sv[it] != -INFINITY;
+            float vv[EPL];
+            Unpack<WT, EPL>::run(vreg[it], vv);
+            if (part == 0) l_run += p;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, live ? vv[i] : 0.f, acc[i]);
+        }
+        {
+            const float p = expf(sv[KCH] - mref);
+            if (part == 0) l_run += p;
 #pragma unroll
             for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, qkv[64 + part * EPL + i], acc[i]);
         }
+        m_run = m_new;
+    }
 #pragma unroll
-        for (int m = 32; m >= LPR; m >>= 1) {
+    for (int m = 32; m >= LPR; m >>= 1) {
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) acc[i] += __shfl_xor(acc[i], m, 64);
-        }
-        if (lane < LPR) {
+        for (int i = 0; i < EPL; ++i) acc[i] += __shfl_xor(acc[i], m, 64);
+    }
+    l_run = wave_sum(l_run);
+    if (lane < LPR) {
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) pacc[wid * 32 + part * EPL + i] = acc[i];
-        }
+        for (int i = 0; i < EPL; ++i) pacc[wid * 32 + part * EPL + i] = acc[i];
+    }
+    if (lane == 0) { pm[wid] = m_run; pl[wid] = l_run; }
+    stamp(a.dbg, 4);
+    __syncthreads();
+    if (wid == 0) {
+        // merge the 16 waves: lane l (mod 16) owns wave l's (max, sum); 2x32 lanes own the 32 dims
+        const float mw = pm[lane & 15], lw = pl[lane & 15];
+        float M = mw;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) M = fmaxf(M, __shfl_xor(M, m, 64));
+        const float f = expf(mw - M);            // waves with no live rows: exp(-inf) = 0
+        float den = lw * f;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) den += __shfl_xor(den, m, 64);
+        const int hf = lane >> 5, d = lane & 31;
+        float num = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], __shfl(f, hf * 8 + w, 64), num);
+        num += __shfl_xor(num, 32, 64);
+        if (lane < 32) att[d] = num / den;
     }
     __syncthreads();
-    if (tid < 32) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < kNW; ++w) s += pacc[w * 32 + tid];
-        att[tid] = s;
-    }
-    __syncthreads();
+    stamp(a.dbg, 5);
     po.finish(att, a.ypart + ((size_t)b * kH + h) * kD);
+    stamp(a.dbg, 6);
 }
 
 // ---- ffn kernel ----------------------------------------------------------------------------
@@ -460,21 +530,25 @@ struct FfnArgs {
     const float* b1;
     const WT* w2p;       // [32][512][64]  w2p[j][n][i] = W2[n][j*64+i]
     float* zpart;        // [B][32][512]
+    unsigned long long* dbg;
 };
 
 template <typename WT>
 __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
-    __shared__ __attribute__((aligned(16))) float smem[kD + kFJ + 16];
+    __shared__ __attribute__((aligned(16))) float smem[kD + kFJ + 2 * kNW + kNW * kD];
     float* xs = smem;
     float* hb = xs + kD;
     float* red = hb + kFJ;
+    float* stage = red + 2 * kNW;
     const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int CPR = Geo<WT>::CPR;
     constexpr int RW = kFJ / kNW;  // 4 W1 rows per wave
     const bool owner = tid < kD;
+    stamp(a.dbg, 8);
 
     PartialSum<kH> ps;
-    if (owner) ps.issue(a.ypart + (size_t)b * kH * kD, a.bo, a.x + (size_t)b * kD, a.ln1g, a.ln1b);
+    ps.issue(a.ypart + (size_t)b * kH * kD, a.bo, a.x + (size_t)b * kD, a.ln1g, a.ln1b);
+    __builtin_amdgcn_s_barrier();  // all partial loads queued before any weight load (see attn kernel)
     asm volatile("" : : : "memory");
     const int row0 = j * kFJ + wid * RW;
     raw16 w1r[RW][CPR];
@@ -484,14 +558,21 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     p2.issue(a.w2p + (size_t)j * kD * kFJ);
     const int oi = sumN_index<RW>();
     const float b1r = a.b1[row0 + oi];
-    asm volatile("" : "+v"(ps.p[0]) : : "memory");
+    asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
+    stamp(a.dbg, 9);
 
-    const float v = ln512(owner ? ps.finish() : 0.f, owner, ps.lng, ps.lnb, red);
+    ps.park(stage);
+    stamp(a.dbg, 13);
+    __syncthreads();
+    stamp(a.dbg, 14);
+    const float v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+    stamp(a.dbg, 15);
     if (owner) {
         xs[tid] = v;
         if (j == 0) a.x1out[(size_t)b * kD + tid] = v;
     }
     __syncthreads();
+    stamp(a.dbg, 10);
     {
         float xr[8];
         lane_x<WT>(xs, xr);
@@ -502,7 +583,9 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
         if ((lane & 15) == 0) hb[wid * RW + oi] = fmaxf(tot + b1r, 0.f);
     }
     __syncthreads();
+    stamp(a.dbg, 11);
     p2.finish(hb, a.zpart + ((size_t)b * kNJ + j) * kD);
+    stamp(a.dbg, 12);
 }
 
 // ---- logits kernel -------------------------------------------------------------------------
@@ -533,10 +616,11 @@ struct LogitsArgs {
 
 template <typename WT, int MODE>
 __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
-    __shared__ __attribute__((aligned(16))) float smem[kD + 16 + 128];
+    __shared__ __attribute__((aligned(16))) float smem[kD + 2 * kNW + 128 + kNW * kD];
     float* xs = smem;
     float* red = xs + kD;
-    float* lg = red + 16;  // up to 128 rows per slice
+    float* lg = red + 2 * kNW;  // up to 128 rows per slice
+    float* stage = lg + 128;
     const int p = blockIdx.x, r_ = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int b = a.slot0 + r_;  // state slot; row r_ of zpart/x1/hdirect
     constexpr int CPR = Geo<WT>::CPR;
@@ -546,11 +630,13 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     const int nrow = min(rpb, a.V - vbase);
     const bool owner = tid < kD;
 
-    PartialSum<MODE ? kNJ : 1> ps;
+    PartialSum<kNJ> ps;
     float xd = 0.f;
-    if (owner) {
-        if constexpr (MODE == 0) xd = a.hdirect[(size_t)r_ * kD + tid];
-        else ps.issue(a.zpart + (size_t)r_ * kNJ * kD, a.b2, a.x1 + (size_t)r_ * kD, a.ln2g, a.ln2b);
+    if constexpr (MODE == 0) {
+        if (owner) xd = a.hdirect[(size_t)r_ * kD + tid];
+    } else {
+        ps.issue(a.zpart + (size_t)r_ * kNJ * kD, a.b2, a.x1 + (size_t)r_ * kD, a.ln2g, a.ln2b);
+        __builtin_amdgcn_s_barrier();
     }
     asm volatile("" : : : "memory");
     raw16 wr[8][CPR];
@@ -566,11 +652,16 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     const int myr = wid * rww + oi;             // slice row this lane will emit (if oi < rww)
     const uint8_t sn = a.seen[(size_t)b * a.V + min(vbase + myr, a.V - 1)];
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
-    else asm volatile("" : "+v"(ps.p[0]) : : "memory");
+    else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
 
     float v;
-    if constexpr (MODE == 0) v = xd;
-    else v = ln512(owner ? ps.finish() : 0.f, owner, ps.lng, ps.lnb, red);
+    if constexpr (MODE == 0) {
+        v = xd;
+    } else {
+        ps.park(stage);
+        __syncthreads();
+        v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+    }
     if (owner) {
         xs[tid] = v;
         if (p == 0) a.hidden[(size_t)b * kD + tid] = v;

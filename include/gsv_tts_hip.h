@@ -125,6 +125,9 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
  * back-to-back sweeps over all layers' launches of that class on the live state (every layer
  * streams its own weights, as in a real step).  out_ms: host float[4].  Leaves kv_len untouched. */
 int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream);
+/* Bring-up aid: when `buf` (device, >= 16 x uint64) is non-null the LAST layer's attn/ffn kernels
+ * write shader-clock timestamps of their phases into it (slots 0-6 attn, 8-12 ffn). */
+int gsv_t2s_set_debug(gsv_t2s* h, void* buf);
 /* materialise the pending token of every slot into pre_tokens/seen/eos_at (idempotent) */
 int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream);
 
