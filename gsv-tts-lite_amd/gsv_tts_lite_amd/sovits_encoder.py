@@ -1,0 +1,189 @@
+"""SoVITS text/ssl encoder `enc_p` (TextEncoder) and codebook lookup, in plain torch.
+
+This is the stage in front of the HIP flow+Generator inside `SynthesizerTrn.decode`.  It is a
+"next" row of the scope table (~10 % of vocoder time, runs once per
+utterance), so it is functional torch on the GPU rather than hand-written HIP.  Semantics follow
+the reference:
+
+  TextEncoder.infer            gsv_tts/GPT_SoVITS/SoVITS/models.py:196-224
+  attentions.Encoder / FFN     SoVITS/module/attentions.py:10-77, 221-277
+  windowed relative attention  SoVITS/module/attentions.py:80-219  (window 4, shared heads)
+  MRTE cross attention         SoVITS/module/mrte_model.py:6-38
+  channel LayerNorm            SoVITS/module/modules.py:15-27
+  codebook decode              SoVITS/module/core_vq.py:147-149,222-226,295-301
+
+The relative-position terms are computed directly on the 2w+1 band (gather / scatter on the
+offset j - i) instead of the reference's pad-and-reshape skewing; the result is the same
+attention (embeddings outside the window are zero in both formulations).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _dev(weights, name, device):
+    return weights[name].detach().to(device=device, dtype=torch.float32)
+
+
+def codebook_decode(weights, codes):
+    """codes int64 [n_q=1, B, N] -> [B, 768, N]"""
+    out = None
+    for q in range(codes.shape[0]):
+        emb = weights["quantizer.vq.layers.%d._codebook.embed" % q]
+        emb = emb.detach().to(device=codes.device, dtype=torch.float32)
+        v = F.embedding(codes[q], emb).transpose(1, 2)
+        out = v if out is None else out + v
+    return out
+
+
+def channel_layer_norm(x, gamma, beta, eps=1e-5):
+    return F.layer_norm(x.transpose(1, -1), (x.shape[1],), gamma, beta, eps).transpose(1, -1)
+
+
+class _Attention:
+    """multi-head attention over channels-first tensors; optional windowed relative positions"""
+
+    def __init__(self, w, prefix, device, n_heads, window=None):
+        g = lambda n: _dev(w, prefix + n, device)
+        self.wq, self.bq = g("conv_q.weight"), g("conv_q.bias")
+        self.wk, self.bk = g("conv_k.weight"), g("conv_k.bias")
+        self.wv, self.bv = g("conv_v.weight"), g("conv_v.bias")
+        self.wo, self.bo = g("conv_o.weight"), g("conv_o.bias")
+        self.n_heads = n_heads
+        self.window = window
+        if window is not None:
+            self.rel_k, self.rel_v = g("emb_rel_k"), g("emb_rel_v")  # [1, 2w+1, dk]
+        self.attn = None
+
+    def __call__(self, x, c, mask):
+        q = F.conv1d(x, self.wq, self.bq)
+        k = F.conv1d(c, self.wk, self.bk)
+        v = F.conv1d(c, self.wv, self.bv)
+        b, d, tt = q.shape
+        ts = k.shape[2]
+        h, dk = self.n_heads, d // self.n_heads
+        q = q.view(b, h, dk, tt).transpose(2, 3) / math.sqrt(dk)
+        k = k.view(b, h, dk, ts).transpose(2, 3)
+        v = v.view(b, h, dk, ts).transpose(2, 3)
+        scores = q @ k.transpose(-2, -1)
+        if self.window is not None:
+            w = self.window
+            idx = torch.arange(ts, device=x.device)
+            off = idx[None, :] - idx[:, None]                       # j - i
+            band = off.abs() <= w
+            bin_ = (off.clamp(-w, w) + w)[None, None].expand(b, h, tt, ts)
+            rel_logits = q @ self.rel_k.transpose(-2, -1)           # [b,h,t,2w+1]
+            scores = scores + torch.gather(rel_logits, -1, bin_) * band
+        if mask is not None:
+            scores = scores.masked_fill(mask == 0, -1e4)
+        p = torch.softmax(scores, dim=-1)
+        out = p @ v
+        if self.window is not None:
+            rel_w = torch.zeros(b, h, tt, 2 * w + 1, device=x.device, dtype=p.dtype)
+            rel_w.scatter_add_(-1, bin_, p * band)
+            out = out + rel_w @ self.rel_v
+        self.attn = p
+        out = out.transpose(2, 3).contiguous().view(b, d, tt)
+        return F.conv1d(out, self.wo, self.bo)
+
+
+class _Encoder:
+    def __init__(self, w, prefix, device, n_heads, n_layers, kernel_size, window=4):
+        self.layers = []
+        for i in range(n_layers):
+            g = lambda n: _dev(w, prefix + n, device)
+            self.layers.append(dict(
+                attn=_Attention(w, "%sattn_layers.%d." % (prefix, i), device, n_heads, window),
+                n1=(g("norm_layers_1.%d.gamma" % i), g("norm_layers_1.%d.beta" % i)),
+                n2=(g("norm_layers_2.%d.gamma" % i), g("norm_layers_2.%d.beta" % i)),
+                c1=(g("ffn_layers.%d.conv_1.weight" % i), g("ffn_layers.%d.conv_1.bias" % i)),
+                c2=(g("ffn_layers.%d.conv_2.weight" % i), g("ffn_layers.%d.conv_2.bias" % i)),
+            ))
+        self.k = kernel_size
+
+    def __call__(self, x, x_mask):
+        attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+        x = x * x_mask
+        pl, pr = (self.k - 1) // 2, self.k // 2
+        for L in self.layers:
+            y = L["attn"](x, x, attn_mask)
+            x = channel_layer_norm(x + y, *L["n1"])
+            y = F.conv1d(F.pad(x * x_mask, (pl, pr)), *L["c1"])
+            y = torch.relu(y)
+            y = F.conv1d(F.pad(y * x_mask, (pl, pr)), *L["c2"]) * x_mask
+            x = channel_layer_norm(x + y, *L["n2"])
+        return x * x_mask
+
+
+class _MRTE:
+    def __init__(self, w, device):
+        g = lambda n: _dev(w, "enc_p.mrte." + n, device)
+        self.cross_attention = _Attention(w, "enc_p.mrte.cross_attention.", device, 4, None)
+        self.c_pre = (g("c_pre.weight"), g("c_pre.bias"))
+        self.text_pre = (g("text_pre.weight"), g("text_pre.bias"))
+        self.c_post = (g("c_post.weight"), g("c_post.bias"))
+
+    def __call__(self, ssl_enc, ssl_mask, text, text_mask, ge, slice_indices=None):
+        if ge is None:
+            ge = 0
+        if slice_indices is None:
+            attn_mask = text_mask.unsqueeze(2) * ssl_mask.unsqueeze(-1)
+        else:  # restrict each frame's cross-attention to its own utterance's phonemes (+ the last column)
+            rng = torch.arange(text.shape[-1], device=text.device).unsqueeze(0)
+            attn_mask = (rng >= slice_indices[:, 0:1]) & (rng < slice_indices[:, 1:2])
+            attn_mask[:, -1] = True
+            attn_mask = attn_mask.unsqueeze(0).unsqueeze(0)
+        ssl_enc = F.conv1d(ssl_enc * ssl_mask, *self.c_pre)
+        text_enc = F.conv1d(text * text_mask, *self.text_pre)
+        x = self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, attn_mask) + ssl_enc + ge
+        return F.conv1d(x * ssl_mask, *self.c_post)
+
+
+class TextEncoder:
+    def __init__(self, hps_model, weights, device):
+        m = hps_model
+        self.device = device
+        g = lambda n: _dev(weights, "enc_p." + n, device)
+        self.out_channels = m["inter_channels"]
+        self.ssl_proj = (g("ssl_proj.weight"), g("ssl_proj.bias"))
+        nh, nl, k = m["n_heads"], m["n_layers"], m["kernel_size"]
+        self.encoder_ssl = _Encoder(weights, "enc_p.encoder_ssl.", device, nh, nl // 2, k)
+        self.encoder_text = _Encoder(weights, "enc_p.encoder_text.", device, nh, nl, k)
+        self.text_embedding = g("text_embedding.weight")
+        self.mrte = _MRTE(weights, device)
+        self.encoder2 = _Encoder(weights, "enc_p.encoder2.", device, nh, nl // 2, k)
+        self.proj = (g("proj.weight"), g("proj.bias"))
+        self.y_overlap = None
+        if m["version"] in ("v2Pro", "v2ProPlus"):
+            self._ge512 = (_dev(weights, "ge_to512.weight", device), _dev(weights, "ge_to512.bias", device))
+
+    def ge_to512(self, ge):
+        """models.py:394: Linear over the channel axis of ge [1, gin, Tg]"""
+        return F.linear(ge.transpose(2, 1), *self._ge512).transpose(2, 1)
+
+    def infer(self, y, text, ge, speed, stream_mode=False, valid_start_idx=None, overlap_len=None, slice_indices=None):
+        y = y.to(torch.float32)
+        y_mask = torch.ones((1, 1, y.size(2)), dtype=y.dtype, device=y.device)
+        y = F.conv1d(y * y_mask, *self.ssl_proj) * y_mask
+        y = self.encoder_ssl(y * y_mask, y_mask)
+        text_mask = torch.ones((1, 1, text.size(1)), dtype=y.dtype, device=y.device)
+        t = F.embedding(text, self.text_embedding).transpose(1, 2)
+        t = self.encoder_text(t * text_mask, text_mask)
+        y = self.mrte(y, y_mask, t, text_mask, ge, slice_indices)
+        y = self.encoder2(y * y_mask, y_mask)
+        if stream_mode:
+            y = y[:, :, valid_start_idx:]
+            y_mask = y_mask[:, :, valid_start_idx:]
+            alpha = torch.linspace(0, 1, overlap_len, dtype=y.dtype, device=y.device).view(1, 1, -1)
+            if self.y_overlap is not None:
+                y[:, :, :overlap_len] = self.y_overlap * (1 - alpha) + y[:, :, :overlap_len] * alpha
+            self.y_overlap = y[:, :, -overlap_len:]
+        if speed != 1:
+            y = F.interpolate(y, size=int(y.shape[-1] / speed) + 1, mode="linear")
+            y_mask = F.interpolate(y_mask, size=y.shape[-1], mode="nearest")
+        stats = F.conv1d(y, *self.proj) * y_mask
+        m, logs = torch.split(stats, self.out_channels, dim=1)
+        return m, logs, y_mask

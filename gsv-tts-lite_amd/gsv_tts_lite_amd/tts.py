@@ -1,0 +1,402 @@
+"""`TTS`: the reference's engine facade (gsv_tts/TTS.py) over the MI355X hot path.
+
+Drop-in surface kept from the reference:
+    TTS(gpt_cache, sovits_cache, models_dir, device, dtype, use_flash_attn, use_bert, auto_bert,
+        use_jieba_fast, always_load_cnhubert, always_load_sv)                 TTS.py:39-52
+    infer(...) -> AudioClip                                                    TTS.py:150-286
+    infer_batched(...) -> tuple[AudioClip]                                     TTS.py:507-868
+    load_gpt_model / load_sovits_model / unload_* / get_*_list                 TTS.py:1264-1345
+    AudioClip(audio_data, samplerate, audio_len_s, subtitles, orig_text)       Player.py:68-99
+
+What sits in front of the hot path in the reference -- G2P text frontends, CN-HuBERT prompt
+tokens, ERes2Net/ref_enc speaker embedding -- is OUT OF SCOPE of this build (SURVEY.md section 2
+rows 7-9: CPU string processing and once-per-speaker models whose third-party packages are not
+installable here).  Their *outputs* enter through the same caches the reference keeps:
+    cache_spk_audio(path, ge=...)                      (reference fills it via get_ge, TTS.py:1346)
+    cache_prompt_audio(path, text, prompt=..., phones1=..., bert1=...)       (TTS.py:1391)
+    set_text_frontend(fn)   fn(text) -> (phones2, word2ph, bert2[P,1024], norm_text)
+With those in place infer()/infer_batched() behave as in the reference.  Subtitle alignment
+(`return_subtitles=True`, TTS.py:1744) is a later row.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+import threading
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .loader import Gpt, Sovits, get_gpt_weights, get_sovits_weights
+
+log = logging.getLogger("gsv_tts_lite_amd")
+
+PAUSE_MARKS = tuple("…。？！.?!,，:：;；~、・—")
+
+
+class Config:
+    def __init__(self):
+        if torch.cuda.is_available():
+            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            self.dtype = torch.bfloat16
+        else:
+            self.device = torch.device("cpu")
+            self.dtype = torch.float32
+        self.use_flash_attn = False
+        self.gpt_cache = []
+        self.sovits_cache = []
+
+
+class AudioClip:
+    """Player.py:68-99 fields; playback needs `sounddevice`, saving uses `soundfile` when present
+    and falls back to a 16-bit PCM WAV writer."""
+
+    def __init__(self, audio_queue, audio_data, samplerate, audio_len_s, subtitles, orig_text):
+        self.audio_queue = audio_queue
+        self.audio_data = audio_data
+        self.samplerate = samplerate
+        self.audio_len_s = audio_len_s
+        self.subtitles = subtitles
+        self.orig_text = orig_text
+
+    def play(self, volume: float = 1.0):
+        if self.audio_queue is None:
+            raise RuntimeError("audio playback needs the optional `sounddevice` package")
+        data = self.audio_data if volume == 1.0 else np.clip(self.audio_data * volume, -1.0, 1.0)
+        self.audio_queue.put(data)
+
+    def save(self, save_path: str, is_save_subtitles: bool = False):
+        try:
+            import soundfile as sf
+            sf.write(save_path, self.audio_data, self.samplerate)
+        except ImportError:
+            import wave
+            pcm = (np.clip(self.audio_data, -1.0, 1.0) * 32767.0).astype("<i2")
+            with wave.open(save_path, "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(self.samplerate)
+                w.writeframes(pcm.tobytes())
+        if is_save_subtitles:
+            import json
+            with open(os.path.splitext(save_path)[0] + ".json", "w", encoding="utf-8") as f:
+                json.dump(self.subtitles, f, ensure_ascii=False, indent=2)
+
+
+def cut_text(text: str, minlen: int = 10) -> list:
+    """Split text into sentence-like segments at pause punctuation, merging segments shorter than
+    `minlen` into their neighbour (role of TextProcessor.cut_text, TextProcessor.py:18-59; the
+    reference delegates sentence boundaries to pysbd, unavailable here)."""
+    parts = [p for p in re.split(r"(?<=[。！？!?\.…;；\n])", text) if p and p.strip()]
+    out, cur = [], ""
+    for p in parts:
+        cur += p
+        if len(cur) >= minlen:
+            out.append(cur)
+            cur = ""
+    if cur:
+        if out:
+            out[-1] += cur
+        else:
+            out.append(cur)
+    return [s.strip() for s in out if s.strip()]
+
+
+class TTS:
+    def __init__(self, gpt_cache=[(1, 512), (1, 768), (1, 1024), (4, 512), (4, 1024)], sovits_cache=[50, 55],
+                 models_dir: str = None, device: str = None, dtype: str = None, use_flash_attn: bool = False,
+                 use_bert: bool = False, auto_bert: bool = True, use_jieba_fast: bool = False,
+                 always_load_cnhubert: bool = False, always_load_sv: bool = False):
+        self.tts_config = Config()
+        if device is not None:
+            self.tts_config.device = torch.device(device)
+        if dtype is not None:
+            self.tts_config.dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16}.get(dtype.lower())
+            if self.tts_config.dtype is None:
+                raise ValueError("dtype must be float32 or bfloat16 on the MI355X path (float16 is not implemented)")
+        if use_flash_attn:
+            log.warning("use_flash_attn is ignored: the HIP decode kernel already reads only kv_len entries")
+        self.tts_config.gpt_cache = list(gpt_cache)
+        self.tts_config.sovits_cache = list(sovits_cache)
+        self.models_dir = models_dir if models_dir is not None else Path.home() / ".cache" / "gsv"
+        self.default_gpt_path = Path(self.models_dir) / "s1v3.ckpt"
+        self.default_sovits_path = Path(self.models_dir) / "s2Gv2ProPlus.pth"
+        self.gpt_models: dict = {}
+        self.sovits_models: dict = {}
+        self.spk_audio_cache: dict = {}
+        self.prompt_audio_cache: dict = {}
+        self.samplerate, self.gpt_hz, self.sovits_hz = 32000, 25, 50
+        self.audio_queue = None
+        self._infer_lock = threading.Lock()
+        self._text_frontend = None
+
+    # ------------------------------------------------------------------ model management
+    def load_gpt_model(self, *model_paths):
+        for p in (model_paths or (self.default_gpt_path,)):
+            self.gpt_models[p] = get_gpt_weights(p, self.tts_config)
+            log.info("Loaded GPT model: %s", p)
+
+    def load_sovits_model(self, *model_paths):
+        for p in (model_paths or (self.default_sovits_path,)):
+            self.sovits_models[p] = get_sovits_weights(p, self.tts_config)
+            log.info("Loaded SoVITS model: %s", p)
+
+    def unload_gpt_model(self, *model_paths):
+        try:
+            for p in model_paths:
+                if self.gpt_models.pop(p, None) is None:
+                    log.warning("GPT model %s not found.", p)
+        finally:
+            self._empty_cache()
+
+    def unload_sovits_model(self, *model_paths):
+        try:
+            for p in model_paths:
+                if self.sovits_models.pop(p, None) is None:
+                    log.warning("SoVITS model %s not found.", p)
+                for a in self.spk_audio_cache.values():
+                    a["ge"].pop(p, None)
+        finally:
+            self._empty_cache()
+
+    def get_gpt_list(self):
+        return list(self.gpt_models.keys())
+
+    def get_sovits_list(self):
+        return list(self.sovits_models.keys())
+
+    def _empty_cache(self):
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ front-of-hot-path inputs
+    def set_text_frontend(self, fn):
+        """fn(text) -> (phones2 list[int], word2ph dict, bert2 [P,1024] tensor, norm_text)"""
+        self._text_frontend = fn
+
+    def cache_spk_audio(self, spk_audio_paths, sovits_model=None, ge=None):
+        if ge is None:
+            raise NotImplementedError("computing ge from audio (ref_enc + ERes2Net) is outside this build's scope; "
+                                      "pass ge=[1, gin, 1] (SURVEY.md section 2 rows 8-9)")
+        sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+        entry = self.spk_audio_cache.setdefault(spk_audio_paths, {"ge": {}})
+        entry["ge"][sovits_model] = ge.to(self.tts_config.device)
+
+    def cache_prompt_audio(self, prompt_audio_paths, prompt_audio_texts, prompt=None, phones1=None, bert1=None):
+        if not prompt_audio_texts:
+            raise ValueError("prompt_audio_text must not be empty")
+        if prompt is None or phones1 is None:
+            raise NotImplementedError("CN-HuBERT prompt tokenisation / G2P are outside this build's scope; pass "
+                                      "prompt=int64[1,Ly], phones1=list[int] (and bert1=[Lx1,1024])")
+        if bert1 is None:
+            bert1 = torch.zeros(len(phones1), 1024)
+        self.prompt_audio_cache[prompt_audio_paths] = {
+            "prompt": prompt.to(self.tts_config.device), "phones1": list(phones1),
+            "bert1": bert1.to(self.tts_config.device), "text": prompt_audio_texts}
+
+    def _pick(self, table, name, default):
+        if name is None:
+            name = next(iter(table)) if table else default
+        return name
+
+    def _phones_and_bert(self, text):
+        if self._text_frontend is None:
+            raise NotImplementedError("no text frontend installed: call set_text_frontend(fn); the reference's G2P stack "
+                                      "(pypinyin/jieba/pyopenjtalk/...) is outside this build's scope")
+        phones2, word2ph, bert2, norm_text = self._text_frontend(text)
+        if not phones2:
+            raise ValueError("text produced no phonemes")
+        if bert2 is None:
+            bert2 = torch.zeros(len(phones2), 1024)
+        return list(phones2), word2ph, bert2.to(self.tts_config.device), norm_text
+
+    def _ge_for(self, spk_audio_path, sovits_model):
+        def one(p):
+            if p not in self.spk_audio_cache or sovits_model not in self.spk_audio_cache[p]["ge"]:
+                self.cache_spk_audio(p, sovits_model=sovits_model)
+            return self.spk_audio_cache[p]["ge"][sovits_model]
+        if isinstance(spk_audio_path, dict):  # multi-speaker fusion, TTS.py:668-679
+            total = sum(spk_audio_path.values())
+            ge = None
+            for p, wgt in spk_audio_path.items():
+                g = one(p) * (wgt / total)
+                ge = g if ge is None else ge + g
+            return ge
+        return one(spk_audio_path)
+
+    def _prompt_for(self, path, text):
+        if path not in self.prompt_audio_cache:
+            self.cache_prompt_audio(path, text)
+        c = self.prompt_audio_cache[path]
+        return c["prompt"], c["phones1"], c["bert1"]
+
+    # ------------------------------------------------------------------ trimming (TTS.py:1629-1664)
+    @staticmethod
+    def _rms_frames(x, frame=512, hop=256):
+        if x.shape[0] < frame:
+            return x.new_zeros(0)
+        return x.unfold(0, frame, hop).pow(2).mean(dim=1).sqrt()
+
+    def _find_head_threshold_offsets(self, audio, threshold=0.02, search_len=64000, margin=3200):
+        head = audio[:search_len]
+        idx = torch.nonzero(self._rms_frames(head) > threshold)
+        return max(0, int(idx[0]) * 256 - margin) if idx.numel() else head.shape[0]
+
+    def _find_tail_threshold_offsets(self, audio, threshold=0.01, search_len=64000, margin=3200):
+        tail = audio[-search_len:]
+        idx = torch.nonzero(self._rms_frames(tail) > threshold)
+        return max(1, tail.shape[0] - int(idx[-1]) * 256 - margin) if idx.numel() else tail.shape[0]
+
+    @staticmethod
+    def _check_pause(text):
+        return len(text) > 0 and text[-1] in PAUSE_MARKS
+
+    # ------------------------------------------------------------------ inference
+    @torch.inference_mode()
+    def infer(self, spk_audio_path, prompt_audio_path, prompt_audio_text, text, return_subtitles=False, top_k=15,
+              top_p=1.0, temperature=1.0, repetition_penalty=1.35, noise_scale=0.5, speed=1.0, gpt_model=None,
+              sovits_model=None):
+        if return_subtitles:
+            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
+        with self._infer_lock:
+            try:
+                if not self._check_pause(text):
+                    text += "."
+                gpt_model = self._pick(self.gpt_models, gpt_model, self.default_gpt_path)
+                sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+                if gpt_model not in self.gpt_models:
+                    self.load_gpt_model(gpt_model)
+                if sovits_model not in self.sovits_models:
+                    self.load_sovits_model(sovits_model)
+                t2s = self.gpt_models[gpt_model].t2s_model
+                vq = self.sovits_models[sovits_model].vq_model
+                dev = self.tts_config.device
+                ge = self._ge_for(spk_audio_path, sovits_model)
+                prompt, phones1, bert1 = self._prompt_for(prompt_audio_path, prompt_audio_text)
+                phones2, _, bert2, _ = self._phones_and_bert(text)
+                ids = torch.tensor(phones1 + phones2, dtype=torch.int64, device=dev).unsqueeze(0)
+                bert = torch.cat([bert1, bert2]).unsqueeze(0)
+                pred = t2s.infer(ids, prompt, bert, top_k=top_k, top_p=top_p, temperature=temperature,
+                                 repetition_penalty=repetition_penalty)
+                audio, _ = vq.decode(pred, torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0), ge,
+                                     noise_scale=noise_scale, speed=speed)
+                audio = audio[0, 0, :]
+                audio = audio[self._find_head_threshold_offsets(audio):]
+                audio = audio.float().cpu().numpy()
+                peak = np.abs(audio).max() if audio.size else 0.0
+                if peak > 1:
+                    audio = audio / peak
+                audio = np.concatenate([audio, np.zeros(int(0.2 * self.samplerate), dtype=audio.dtype)])
+                return AudioClip(self.audio_queue, audio, self.samplerate, len(audio) / self.samplerate, [], text)
+            finally:
+                self._empty_cache()
+
+    @torch.inference_mode()
+    def infer_batched(self, spk_audio_paths, prompt_audio_paths, prompt_audio_texts, texts, return_subtitles=False,
+                      is_cut_text=True, cut_minlen=10, cut_mute=0.4,
+                      cut_mute_scale_map={"…": 2.0, ".": 1.5, "。": 1.5, "?": 1.5, "？": 1.5, "!": 1.5, "！": 1.5,
+                                          ",": 1.0, "，": 1.0, ":": 1.0, "：": 1.0, ";": 1.0, "；": 1.0, "~": 1.0,
+                                          "、": 0.8, "・": 0.8},
+                      top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35, noise_scale=0.5, speed=1.0,
+                      bert_batch_size=20, sovits_batch_size=10, gpt_model=None, sovits_model=None):
+        if return_subtitles:
+            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
+        with self._infer_lock:
+            try:
+                if isinstance(texts, str):
+                    texts = [texts]
+                texts = [t if self._check_pause(t) else t + "." for t in texts]
+                if not is_cut_text:
+                    cut_minlen = 10000
+                cut_mute = cut_mute / speed
+                n = len(texts)
+                bc = lambda v, kinds: [v] * n if isinstance(v, kinds) else list(v)
+                spk_audio_paths = bc(spk_audio_paths, (str, dict))
+                prompt_audio_paths = bc(prompt_audio_paths, str)
+                prompt_audio_texts = bc(prompt_audio_texts, str)
+                gpt_model = self._pick(self.gpt_models, gpt_model, self.default_gpt_path)
+                sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+                if gpt_model not in self.gpt_models:
+                    self.load_gpt_model(gpt_model)
+                if sovits_model not in self.sovits_models:
+                    self.load_sovits_model(sovits_model)
+                t2s = self.gpt_models[gpt_model].t2s_model
+                vq = self.sovits_models[sovits_model].vq_model
+                dev = self.tts_config.device
+
+                segs, seg2orig = [], []
+                for i, t in enumerate(texts):
+                    for c in cut_text(t, cut_minlen):
+                        segs.append(c)
+                        seg2orig.append(i)
+                feats = [self._phones_and_bert(s) for s in segs]
+                ids, prompts, berts, ges, phones2_all = [], [], [], [], []
+                for k, (ph2, _, b2, _) in enumerate(feats):
+                    o = seg2orig[k]
+                    prompt, ph1, b1 = self._prompt_for(prompt_audio_paths[o], prompt_audio_texts[o])
+                    ids.append(torch.tensor(ph1 + ph2, dtype=torch.int64, device=dev))
+                    prompts.append(prompt.squeeze(0))
+                    berts.append(torch.cat([b1, b2]))
+                    ges.append(self._ge_for(spk_audio_paths[o], sovits_model).squeeze(0))
+                    phones2_all.append(ph2)
+
+                pred, orig_idx = t2s.infer_batched(ids, prompts, berts, top_k=top_k, top_p=top_p,
+                                                   temperature=temperature, repetition_penalty=repetition_penalty)
+                lengths = torch.tensor([len(p) for p in pred])
+                order = torch.argsort(lengths)
+                m = len(order)
+                inter = torch.zeros(m, dtype=torch.long)          # short/long interleave, TTS.py:709-716
+                inter[0::2] = torch.arange((m + 1) // 2)
+                inter[1::2] = torch.arange((m + 1) // 2, m).flip(0)
+                order = order[inter]
+                pred = [pred[i] for i in order.tolist()]
+                orig_idx = orig_idx.cpu()[order]
+                lengths = lengths[order]
+
+                audios = []
+                for s in range(0, m, sovits_batch_size):
+                    e = min(s + sovits_batch_size, m)
+                    sem = pred[s:e]
+                    oi = orig_idx[s:e].tolist()
+                    ln = lengths[s:e]
+                    ge_cat = torch.cat([ges[o].expand(-1, int(l)) for o, l in zip(oi, ln)], dim=1).unsqueeze(0)
+                    ph_cat = torch.cat([torch.tensor(phones2_all[o], dtype=torch.int64, device=dev) for o in oi]).unsqueeze(0)
+                    plens = torch.tensor([len(phones2_all[o]) for o in oi], device=dev)
+                    ends = torch.cumsum(plens, 0)
+                    pairs = torch.stack([ends - plens, ends], dim=1)
+                    slice_indices = torch.repeat_interleave(pairs, (ln * 2).to(dev), dim=0)
+                    audio, _ = vq.decode(torch.cat(sem).unsqueeze(0).unsqueeze(0), ph_cat, ge_cat, noise_scale=noise_scale,
+                                         speed=speed, cuda_graph=False, slice_indices=slice_indices)
+                    audio = audio[0, 0, :]
+                    peak = audio.abs().max()
+                    if peak > 1.0:
+                        audio = audio / peak
+                    pos = 0.0
+                    for l in ln.tolist():
+                        nxt = pos + l * 2 * vq.samples_per_frame / speed
+                        a = audio[int(pos):int(nxt)]
+                        pos = nxt
+                        h, t = self._find_head_threshold_offsets(a), self._find_tail_threshold_offsets(a)
+                        audios.append(a[h:-t].float().cpu().numpy())
+
+                ordered = [None] * len(audios)
+                for cur, o in enumerate(orig_idx.tolist()):
+                    ordered[o] = audios[cur]
+                per_text = [[] for _ in range(n)]
+                for k, a in enumerate(ordered):
+                    per_text[seg2orig[k]].append(a)
+                    tail = segs[k][-1]
+                    if tail in cut_mute_scale_map:
+                        sc = cut_mute_scale_map[tail]
+                    elif "…" in cut_mute_scale_map and segs[k][-3:] in ("...", "。。。"):
+                        sc = cut_mute_scale_map["…"]
+                    else:
+                        sc = 1.0
+                    per_text[seg2orig[k]].append(np.zeros(int(cut_mute * sc * self.samplerate), dtype=a.dtype))
+                clips = []
+                for parts, t in zip(per_text, texts):
+                    a = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+                    clips.append(AudioClip(self.audio_queue, a, self.samplerate, len(a) / self.samplerate, [], t))
+                return tuple(clips)
+            finally:
+                self._empty_cache()

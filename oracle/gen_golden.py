@@ -216,14 +216,47 @@ def gen_vocoder(Syn):
     np.savez_compressed(os.path.join(GOLD, "vocoder.npz"), seed=1234, **META, **out)
 
 
+def gen_decode(Syn):
+    """SynthesizerTrn.decode end to end (quantizer lookup -> enc_p -> flow -> Generator), noise_scale=0:
+    a single utterance, and the time-concatenated batch form with per-frame ge + slice_indices."""
+    out = {}
+    for ver in ("v2Pro", "v2"):
+        hps = synth.sovits_hps(ver)
+        w = synth.sovits_weights(hps, seed=1234)
+        s = Syn(hps["data"]["filter_length"] // 2 + 1, hps["train"]["segment_size"] // hps["data"]["hop_length"],
+                n_speakers=hps["data"]["n_speakers"], **hps["model"])
+        s.dec.remove_weight_norm()
+        s.load_state_dict({k: tt(v) for k, v in w.items()}, strict=False)
+        s.eval()
+        gin = hps["model"]["gin_channels"]
+        N, P = 19, 13
+        codes = synth.hashed_ints(ver + ".codes", N, 0, 1024)[None, None]
+        text = synth.hashed_ints(ver + ".text", P, 1, 700)[None]
+        ge = synth.synth_ge(0, gin)
+        with torch.inference_mode():
+            o, attn = s.decode(tt(codes), tt(text), tt(ge), noise_scale=0.0, speed=1, cuda_graph=False)
+        out.update({ver + "_codes": codes, ver + "_text": text, ver + "_ge": ge, ver + "_o": o.numpy()[0, 0],
+                    ver + "_attn": attn.numpy()})
+        # two utterances concatenated along time (TTS.py:728-764)
+        n1, n2, p1, p2 = 11, 8, 6, 7
+        ge_cat = np.concatenate([np.repeat(synth.synth_ge(1, gin), n1, axis=2), np.repeat(synth.synth_ge(2, gin), n2, axis=2)], axis=2)
+        pairs = np.array([[0, p1]] * (2 * n1) + [[p1, p1 + p2]] * (2 * n2), np.int64)
+        with torch.inference_mode():
+            ob, _ = s.decode(tt(codes), tt(text), tt(ge_cat), noise_scale=0.0, speed=1, cuda_graph=False, slice_indices=tt(pairs))
+        out.update({ver + "_ge_cat": ge_cat, ver + "_pairs": pairs, ver + "_ob": ob.numpy()[0, 0]})
+        print("decode", ver, o.shape, "std", o.std().item())
+    np.savez_compressed(os.path.join(GOLD, "decode.npz"), seed=1234, **META, **out)
+
+
 if __name__ == "__main__":
     tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "sample", "vocoder"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "sample", "vocoder", "decode"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
     if "sample" in which: gen_sample(sample)
     if "vocoder" in which: gen_vocoder(Syn)
+    if "decode" in which: gen_decode(Syn)
