@@ -110,22 +110,37 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
     a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
     a.res = e.res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
     a.accumulate = e.accumulate; a.Y = Y; a.ldy = ldy; a.n_rows = n_rows;
-    const bool wide_m = pc.mtiles >= 2;
-    const bool wide_n = n_rows > 4096;
-    dim3 blk(256);
-    if (wide_m && wide_n) {
-        dim3 grid(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 2, 2>), grid, blk, 0, st, a);
-    } else if (wide_m) {
-        dim3 grid(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 2, 1>), grid, blk, 0, st, a);
-    } else if (wide_n) {
-        dim3 grid(cdiv(n_rows, 256), pc.mtiles, pc.nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 1, 2>), grid, blk, 0, st, a);
-    } else {
-        dim3 grid(cdiv(n_rows, 128), pc.mtiles, pc.nphase);
-        hipLaunchKernelGGL((tapgemm_kernel<IT, CT, OT, 1, 1>), grid, blk, 0, st, a);
+    // tile choice: wide tiles when there is enough work to fill 256 CUs several times over, else
+    // the smallest tile so that short sequences (prefill, flow, first Generator stage) still spread out
+    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * pc.nphase;
+    const bool wide_m = pc.mtiles >= 2 && tiles11 >= 1024;
+    const bool wide_n = (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * pc.nphase >= 1024;
+    int smin = 1 << 30, smax = -(1 << 30);
+    for (int r = 0; r < pc.nphase; ++r)
+        for (int t = 0; t < pc.ntaps; ++t) { smin = std::min(smin, a.pshift[r] + a.tshift[t]); smax = std::max(smax, a.pshift[r] + a.tshift[t]); }
+    constexpr int KCB = 256;  // staged bytes per row per chunk
+    const int bn = wide_n ? 256 : 128;
+    // per phase the span is at most the global span; size LDS for the worst phase
+    int span = 0;
+    for (int r = 0; r < pc.nphase; ++r) {
+        int lo = 1 << 30, hi = -(1 << 30);
+        for (int t = 0; t < pc.ntaps; ++t) { lo = std::min(lo, a.pshift[r] + a.tshift[t]); hi = std::max(hi, a.pshift[r] + a.tshift[t]); }
+        span = std::max(span, hi - lo);
     }
+    const size_t lds = (size_t)(bn + span) * (KCB + 16);
+    if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "tapgemm: tap span %d needs %zu B of LDS", span, lds);
+    dim3 blk(256);
+    auto launch = [&](auto kern, dim3 grid) -> int {
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, blk, lds, st, a);
+        return GSV_OK;
+    };
+    int rc;
+    if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase));
+    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase));
+    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2>, dim3(cdiv(n_rows, 256), pc.mtiles, pc.nphase));
+    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1>, dim3(cdiv(n_rows, 128), pc.mtiles, pc.nphase));
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }

@@ -153,22 +153,62 @@ template <> struct Out4<bf16_t> {
     }
 };
 
-// IT: input element type, CT: MFMA operand / packed-weight type, OT: output (and residual) type
+// Staging: `n` elements of IT from global -> CT in LDS with the leaky-ReLU prologue applied once
+// (instead of once per tap).  16 bytes of CT per call.
+template <typename IT, typename CT> struct Stage16;
+template <> struct Stage16<float, float> {
+    static constexpr int E = 4;
+    static __device__ __forceinline__ u32x4 load(const float* p, bool ok, float slope) {
+        return __builtin_bit_cast(u32x4, BFrag<float, float>::load(p, ok, slope));
+    }
+};
+template <> struct Stage16<float, bf16_t> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ u32x4 load(const float* p, bool ok, float slope) {
+        return BFrag<float, bf16_t>::load(p, ok, slope);
+    }
+};
+template <> struct Stage16<bf16_t, bf16_t> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ u32x4 load(const bf16_t* p, bool ok, float slope) {
+        return BFrag<bf16_t, bf16_t>::load(p, ok, slope);
+    }
+};
+
+// IT: input element type, CT: MFMA operand / packed-weight type, OT: output (and residual) type.
+// Block = 4 waves side by side along rows; wave tile = (WM*32 channels) x (WN*32 rows).
+// The input rows the block needs for ALL taps of its phase ([n0+smin, n0+BN+smax)) are staged in LDS
+// in chunks of KC channels (row stride KC*sizeof(CT)+16 bytes: consecutive rows land on consecutive
+// 16-byte slots, so the 32-row B-fragment read is conflict-free); B fragments come from LDS, A
+// fragments (fragment-ordered weights, L2-resident, identical for the 4 waves) from global with a
+// one-iteration register prefetch.
 template <typename IT, typename CT, typename OT, int WM, int WN>
 __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
     constexpr int KS = MfmaK<CT>::KS;
-    constexpr int E = KS / 2;  // elements per lane per fragment
+    constexpr int E = KS / 2;                 // elements per lane per fragment
+    constexpr int KC = 256 / (int)sizeof(CT); // channels staged per chunk: 128 bf16 / 64 f32 (256 B)
+    constexpr int RS = KC * (int)sizeof(CT) + 16;  // LDS row stride in bytes
+    constexpr int BN = 4 * WN * 32;
     using AF = typename BFrag<IT, CT>::type;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int phase = blockIdx.z;
-    const int n0 = (blockIdx.x * 4 + wid) * (WN * 32);
+    const int nb0 = blockIdx.x * BN;          // first output row of the block
+    const int n0 = nb0 + wid * (WN * 32);     // first output row of the wave
     const int mt0 = blockIdx.y * WM;
-    if (n0 >= a.n_rows) return;
     const int j = lane & 31, hf = lane >> 5;
     const int ksteps = a.cin / KS;
     const IT* X = reinterpret_cast<const IT*>(a.X);
-    // packed weights: 16 bytes per lane per (phase, tap, mtile, kstep)
     const uint4* Wp = reinterpret_cast<const uint4*>(a.W);
+
+    int smin = 1 << 30, smax = -(1 << 30);
+    for (int t = 0; t < a.ntaps; ++t) {
+        const int sh = a.pshift[phase] + a.tshift[t];
+        smin = min(smin, sh);
+        smax = max(smax, sh);
+    }
+    const int rows = BN + smax - smin;        // staged rows
+    const int row_base = nb0 + smin;          // global row of staged row 0
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -178,34 +218,58 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][k][q] = 0.f;
 
-    for (int t = 0; t < a.ntaps; ++t) {
-        const int sh = a.pshift[phase] + a.tshift[t];
-        const IT* xrow[WN];
-        bool ok[WN];
-#pragma unroll
-        for (int k = 0; k < WN; ++k) {
-            const int row = n0 + k * 32 + j + sh;
-            ok[k] = (row >= 0) && (row < a.n_in);
-            xrow[k] = X + (size_t)(ok[k] ? row : 0) * a.ldx + hf * E;
+    const bool wave_live = n0 < a.n_rows;
+    for (int c0 = 0; c0 < a.cin; c0 += KC) {
+        const int kc = min(KC, a.cin - c0);           // channels in this chunk (multiple of KS)
+        const int vec_per_row = kc / Stage16<IT, CT>::E;
+        __syncthreads();                               // previous chunk's readers are done
+        for (int v = tid; v < rows * vec_per_row; v += 256) {
+            const int r = v / vec_per_row, cv = v - r * vec_per_row;
+            const int grow = row_base + r;
+            const bool ok = grow >= 0 && grow < a.n_in;
+            const u32x4 val = Stage16<IT, CT>::load(X + (size_t)(ok ? grow : 0) * a.ldx + c0 + cv * Stage16<IT, CT>::E,
+                                                    ok, a.in_slope);
+            *reinterpret_cast<u32x4*>(lds + (size_t)r * RS + cv * 16) = val;
         }
-        const uint4* wt = Wp + ((size_t)(phase * a.ntaps + t) * a.mtiles) * ksteps * 64 + lane;
-#pragma unroll 2
-        for (int ks = 0; ks < ksteps; ++ks) {
-            AF bf[WN];
+        __syncthreads();
+        if (wave_live) {
+            const int kst = kc / KS;                   // k-steps in this chunk
+            const int ks0 = c0 / KS;
+            const int NI = a.ntaps * kst;
+            // A fragments for iteration `it`: tap t = it / kst, k-step ks0 + it % kst
+            auto a_ptr = [&](int it, int i) {
+                const int t = it / kst, ks = ks0 + it - t * kst;
+                const int mt = min(mt0 + i, a.mtiles - 1);
+                return Wp + (((size_t)(phase * a.ntaps + t) * a.mtiles + mt) * ksteps + ks) * 64 + lane;
+            };
+            uint4 wa[WM], wn[WM];
 #pragma unroll
-            for (int k = 0; k < WN; ++k) bf[k] = BFrag<IT, CT>::load(xrow[k] + ks * KS, ok[k], a.in_slope);
+            for (int i = 0; i < WM; ++i) wa[i] = *a_ptr(0, i);
+            for (int it = 0; it < NI; ++it) {
+                if (it + 1 < NI) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const int mt = mt0 + i;
-                if (mt < a.mtiles) {
-                    uint4 wa = wt[((size_t)mt * ksteps + ks) * 64];
-                    AF af = __builtin_bit_cast(AF, wa);
+                    for (int i = 0; i < WM; ++i) wn[i] = *a_ptr(it + 1, i);
+                }
+                const int t = it / kst, ks = it - t * kst;
+                const int sh = a.pshift[phase] + a.tshift[t] - smin;
+                AF bf[WN];
+#pragma unroll
+                for (int k = 0; k < WN; ++k) {
+                    const int r = wid * (WN * 32) + k * 32 + j + sh;
+                    bf[k] = __builtin_bit_cast(AF, *reinterpret_cast<const u32x4*>(lds + (size_t)r * RS + (ks * KS + hf * E) * sizeof(CT)));
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const AF af = __builtin_bit_cast(AF, wa[i]);
 #pragma unroll
                     for (int k = 0; k < WN; ++k) Mma<CT>::run(acc[i][k], af, bf[k]);
                 }
+#pragma unroll
+                for (int i = 0; i < WM; ++i) wa[i] = wn[i];
             }
         }
     }
+    if (!wave_live) return;
 
     // epilogue
     OT* Y = reinterpret_cast<OT*>(a.Y);
