@@ -110,24 +110,23 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
     a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
     a.res = e.res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
     a.accumulate = e.accumulate; a.Y = Y; a.ldy = ldy; a.n_rows = n_rows;
-    // tile choice: wide tiles when there is enough work to fill 256 CUs several times over, else
-    // the smallest tile so that short sequences (prefill, flow, first Generator stage) still spread out
-    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * pc.nphase;
-    const bool wide_m = pc.mtiles >= 2 && tiles11 >= 1024;
-    const bool wide_n = (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * pc.nphase >= 1024;
-    int smin = 1 << 30, smax = -(1 << 30);
-    for (int r = 0; r < pc.nphase; ++r)
-        for (int t = 0; t < pc.ntaps; ++t) { smin = std::min(smin, a.pshift[r] + a.tshift[t]); smax = std::max(smax, a.pshift[r] + a.tshift[t]); }
-    constexpr int KCB = 256;  // staged bytes per row per chunk
-    const int bn = wide_n ? 256 : 128;
-    // per phase the span is at most the global span; size LDS for the worst phase
+    // tile choice.  Enough rows to fill the chip several times over -> wide tiles (weights reused
+    // across 64 rows/channels per wave); short sequences (prefill, flow, conditioning GEMV) ->
+    // one 32x32 tile per block with the 4 waves splitting K.
     int span = 0;
     for (int r = 0; r < pc.nphase; ++r) {
         int lo = 1 << 30, hi = -(1 << 30);
         for (int t = 0; t < pc.ntaps; ++t) { lo = std::min(lo, a.pshift[r] + a.tshift[t]); hi = std::max(hi, a.pshift[r] + a.tshift[t]); }
         span = std::max(span, hi - lo);
     }
-    const size_t lds = (size_t)(bn + span) * (KCB + 16);
+    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * pc.nphase;   // blocks at (WM,WN) = (1,1)
+    const bool splitk = tiles11 < 256;
+    const bool wide_m = !splitk && pc.mtiles >= 2 && tiles11 >= 1024;
+    const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * pc.nphase >= 1024;
+    const int bn = splitk ? 32 : (wide_n ? 256 : 128);
+    const int kcb = wide_n ? 128 : 256;               // staged bytes per row per chunk
+    size_t lds = (size_t)(bn + span) * (kcb + 16);
+    if (splitk) lds = std::max(lds, (size_t)3 * 16 * 64 * sizeof(float));
     if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "tapgemm: tap span %d needs %zu B of LDS", span, lds);
     dim3 blk(256);
     auto launch = [&](auto kern, dim3 grid) -> int {
@@ -136,10 +135,11 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
         return GSV_OK;
     };
     int rc;
-    if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase));
-    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase));
-    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2>, dim3(cdiv(n_rows, 256), pc.mtiles, pc.nphase));
-    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1>, dim3(cdiv(n_rows, 128), pc.mtiles, pc.nphase));
+    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, true>, dim3(cdiv(n_rows, 32), pc.mtiles, pc.nphase));
+    else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase));
+    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase));
+    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, pc.nphase));
+    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, false>, dim3(cdiv(n_rows, 128), pc.mtiles, pc.nphase));
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -398,7 +398,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     float* fbuf = ybuf + (size_t)M * kD;
     float* hlast = fbuf + (size_t)M * kF;
     const size_t layer_elems = (size_t)s.batch * kH * T * kDh;
-    const int qsplit = nrows >= 16 ? 1 : (nrows >= 4 ? 2 : 4);
+    const int qsplit = std::max(1, std::min(16, 256 / (kH * nrows)));
     const size_t lds = sizeof(float) * ((size_t)l_max * 33 + (size_t)l_max * 32 + 4 * (size_t)l_max + 128 + 8);
     if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
     HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

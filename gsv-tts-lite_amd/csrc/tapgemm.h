@@ -182,19 +182,23 @@ template <> struct Stage16<bf16_t, bf16_t> {
 // 16-byte slots, so the 32-row B-fragment read is conflict-free); B fragments come from LDS, A
 // fragments (fragment-ordered weights, L2-resident, identical for the 4 waves) from global with a
 // one-iteration register prefetch.
-template <typename IT, typename CT, typename OT, int WM, int WN>
+// SPLITK: the 4 waves of a block share ONE (WM x WN) output tile and split the k-steps of every
+// chunk between them (partials merged through LDS in wave order, wave 0 runs the epilogue): 4x the
+// parallelism and a 4x shorter dependent chain for short sequences (prefill GEMMs, flow, GEMV).
+template <typename IT, typename CT, typename OT, int WM, int WN, int KCB = 256, bool SPLITK = false>
 __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
     constexpr int KS = MfmaK<CT>::KS;
     constexpr int E = KS / 2;                 // elements per lane per fragment
-    constexpr int KC = 256 / (int)sizeof(CT); // channels staged per chunk: 128 bf16 / 64 f32 (256 B)
+    constexpr int KC = KCB / (int)sizeof(CT); // channels staged per chunk
     constexpr int RS = KC * (int)sizeof(CT) + 16;  // LDS row stride in bytes
-    constexpr int BN = 4 * WN * 32;
+    constexpr int BN = (SPLITK ? 1 : 4) * WN * 32;
     using AF = typename BFrag<IT, CT>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int phase = blockIdx.z;
     const int nb0 = blockIdx.x * BN;          // first output row of the block
-    const int n0 = nb0 + wid * (WN * 32);     // first output row of the wave
+    const int wrow = SPLITK ? 0 : wid * (WN * 32);  // first row of the wave inside the block tile
+    const int n0 = nb0 + wrow;                // first output row of the wave
     const int mt0 = blockIdx.y * WM;
     const int j = lane & 31, hf = lane >> 5;
     const int ksteps = a.cin / KS;
@@ -245,17 +249,23 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
             uint4 wa[WM], wn[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i) wa[i] = *a_ptr(0, i);
-            for (int it = 0; it < NI; ++it) {
-                if (it + 1 < NI) {
+            constexpr int STEP = SPLITK ? 4 : 1;
+            const int it0 = SPLITK ? wid : 0;
+            if (SPLITK && it0 < NI) {
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) wn[i] = *a_ptr(it + 1, i);
+                for (int i = 0; i < WM; ++i) wa[i] = *a_ptr(it0, i);
+            }
+            for (int it = it0; it < NI; it += STEP) {
+                if (it + STEP < NI) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) wn[i] = *a_ptr(it + STEP, i);
                 }
                 const int t = it / kst, ks = it - t * kst;
                 const int sh = a.pshift[phase] + a.tshift[t] - smin;
                 AF bf[WN];
 #pragma unroll
                 for (int k = 0; k < WN; ++k) {
-                    const int r = wid * (WN * 32) + k * 32 + j + sh;
+                    const int r = wrow + k * 32 + j + sh;
                     bf[k] = __builtin_bit_cast(AF, *reinterpret_cast<const u32x4*>(lds + (size_t)r * RS + (ks * KS + hf * E) * sizeof(CT)));
                 }
 #pragma unroll
@@ -268,6 +278,30 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
                 for (int i = 0; i < WM; ++i) wa[i] = wn[i];
             }
         }
+    }
+    if constexpr (SPLITK) {
+        // merge the 4 waves' partial tiles in wave order through the (now free) staging LDS
+        float* red = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        if (wid > 0) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        red[(((wid - 1) * WM * WN + i * WN + k) * 16 + q) * 64 + lane] = acc[i][k][q];
+        }
+        __syncthreads();
+        if (wid > 0) return;
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        acc[i][k][q] += red[((w * WM * WN + i * WN + k) * 16 + q) * 64 + lane];
     }
     if (!wave_live) return;
 
