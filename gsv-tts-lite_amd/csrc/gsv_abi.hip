@@ -98,15 +98,9 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
     memset(&a, 0, sizeof(a));
     a.X = X; a.ldx = ldx; a.n_in = n_in; a.cin = pc.cin; a.W = pc.w; a.cout = pc.cout; a.mtiles = pc.mtiles;
     a.ntaps = pc.ntaps; a.nphase = pc.nphase;
-    if (pc.u > 0) {
-        for (int r = 0; r < pc.u; ++r) a.pshift[r] = (r + pc.pad) / pc.u;
-        for (int t = 0; t < pc.ntaps; ++t) a.tshift[t] = -t;
-        a.omul = pc.u;
-    } else {
-        a.pshift[0] = 0;
-        for (int t = 0; t < pc.ntaps; ++t) a.tshift[t] = t * pc.dil - pc.pad;
-        a.omul = 1;
-    }
+    a.tstep = pc.dil; a.tpad = pc.pad; a.tu = pc.u;
+    a.omul = pc.u > 0 ? pc.u : 1;
+    auto shift_of = [&](int r, int t) { return pc.u > 0 ? (r + pc.pad) / pc.u - t : t * pc.dil - pc.pad; };
     a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
     a.res = e.res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
     a.accumulate = e.accumulate; a.Y = Y; a.ldy = ldy; a.n_rows = n_rows;
@@ -116,7 +110,7 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
     int span = 0;
     for (int r = 0; r < pc.nphase; ++r) {
         int lo = 1 << 30, hi = -(1 << 30);
-        for (int t = 0; t < pc.ntaps; ++t) { lo = std::min(lo, a.pshift[r] + a.tshift[t]); hi = std::max(hi, a.pshift[r] + a.tshift[t]); }
+        for (int t = 0; t < pc.ntaps; ++t) { lo = std::min(lo, shift_of(r, t)); hi = std::max(hi, shift_of(r, t)); }
         span = std::max(span, hi - lo);
     }
     const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * pc.nphase;   // blocks at (WM,WN) = (1,1)

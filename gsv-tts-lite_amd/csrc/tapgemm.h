@@ -36,8 +36,10 @@ struct TapGemmArgs {
     int mtiles;          // ceil(cout / 32)
     int ntaps;           // taps per phase
     int nphase;          // 1 (conv/linear) or u (transposed conv)
-    int pshift[10];      // shift(r,t) = pshift[r] + tshift[t]
-    int tshift[12];
+    // row shift of tap t in phase r: conv (tu == 0): t*tstep - tpad ; transposed conv of stride tu:
+    // (r + tpad)/tu - t.  Arithmetic instead of tables: a dynamically indexed kernarg array goes to
+    // scratch, and the inner loop must not divide.
+    int tstep, tpad, tu;
     float in_slope;      // leaky-relu slope applied to X on load (1 = none)
     // epilogue
     const float* bias;   // [cout] or null
@@ -205,12 +207,10 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
     const IT* X = reinterpret_cast<const IT*>(a.X);
     const uint4* Wp = reinterpret_cast<const uint4*>(a.W);
 
-    int smin = 1 << 30, smax = -(1 << 30);
-    for (int t = 0; t < a.ntaps; ++t) {
-        const int sh = a.pshift[phase] + a.tshift[t];
-        smin = min(smin, sh);
-        smax = max(smax, sh);
-    }
+    const int sbase = a.tu > 0 ? (phase + a.tpad) / a.tu : -a.tpad;   // shift of tap 0
+    const int sstep = a.tu > 0 ? -1 : a.tstep;                          // shift increment per tap
+    const int slast = sbase + (a.ntaps - 1) * sstep;
+    const int smin = min(sbase, slast), smax = max(sbase, slast);
     const int rows = BN + smax - smin;        // staged rows
     const int row_base = nb0 + smin;          // global row of staged row 0
 
@@ -227,8 +227,12 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
         const int kc = min(KC, a.cin - c0);           // channels in this chunk (multiple of KS)
         const int vec_per_row = kc / Stage16<IT, CT>::E;
         __syncthreads();                               // previous chunk's readers are done
-        for (int v = tid; v < rows * vec_per_row; v += 256) {
-            const int r = v / vec_per_row, cv = v - r * vec_per_row;
+        // 2-D walk (row, 16-byte vector): tid -> (row offset, vector) once, then rows advance by rpp
+
+        const int tpr = vec_per_row;                   // threads per row
+        const int rpp = 256 / tpr > 0 ? 256 / tpr : 1; // rows per pass (tpr <= 32 always: KC*sizeof/16 <= 16)
+        const int cv = tid % tpr, r_first = tid / tpr;
+        for (int r = r_first; r < rows && tid < rpp * tpr; r += rpp) {
             const int grow = row_base + r;
             const bool ok = grow >= 0 && grow < a.n_in;
             const u32x4 val = Stage16<IT, CT>::load(X + (size_t)(ok ? grow : 0) * a.ldx + c0 + cv * Stage16<IT, CT>::E,
@@ -239,43 +243,59 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
         if (wave_live) {
             const int kst = kc / KS;                   // k-steps in this chunk
             const int ks0 = c0 / KS;
-            const int NI = a.ntaps * kst;
-            // A fragments for iteration `it`: tap t = it / kst, k-step ks0 + it % kst
-            auto a_ptr = [&](int it, int i) {
-                const int t = it / kst, ks = ks0 + it - t * kst;
-                const int mt = min(mt0 + i, a.mtiles - 1);
-                return Wp + (((size_t)(phase * a.ntaps + t) * a.mtiles + mt) * ksteps + ks) * 64 + lane;
-            };
-            uint4 wa[WM], wn[WM];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) wa[i] = *a_ptr(0, i);
             constexpr int STEP = SPLITK ? 4 : 1;
-            const int it0 = SPLITK ? wid : 0;
-            if (SPLITK && it0 < NI) {
+            // iteration space: (tap t, k-step ks) walked incrementally -- no division in the loop
+            const uint4* wbase[WM];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) wa[i] = *a_ptr(it0, i);
-            }
-            for (int it = it0; it < NI; it += STEP) {
-                if (it + STEP < NI) {
+            for (int i = 0; i < WM; ++i)
+                wbase[i] = Wp + (((size_t)phase * a.ntaps * a.mtiles + min(mt0 + i, a.mtiles - 1)) * ksteps + ks0) * 64 + lane;
+            const size_t tap_stride = (size_t)a.mtiles * ksteps * 64;
+            // Weight fragments come from L2 (~500+ cycles) and a block holds only 1-2 waves per SIMD, so
+            // they are fetched a whole GROUP of PF iterations ahead: PF loads in flight cover PF
+            // iterations of LDS reads + MFMAs.  Two cursors walk (tap, k-step): load and compute.
+            constexpr int PF = SPLITK ? 2 : (WM == 1 ? 8 : 4);
+            int tl = 0, ksl = SPLITK ? wid : 0;          // load cursor
+            while (ksl >= kst) { ksl -= kst; ++tl; }
+            int tc = tl, ksc = ksl;                      // compute cursor
+            uint4 wa[PF][WM], wn[PF][WM];
+            auto fetch = [&](uint4 (&dst)[PF][WM]) {
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) wn[i] = *a_ptr(it + STEP, i);
+                for (int u = 0; u < PF; ++u) {
+                    if (tl < a.ntaps) {
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) dst[u][i] = wbase[i][tl * tap_stride + (size_t)ksl * 64];
+                    }
+                    ksl += STEP;
+                    while (ksl >= kst) { ksl -= kst; ++tl; }
                 }
-                const int t = it / kst, ks = it - t * kst;
-                const int sh = a.pshift[phase] + a.tshift[t] - smin;
-                AF bf[WN];
+            };
+            fetch(wa);
+            while (tc < a.ntaps) {
+                fetch(wn);                               // next group's weights: PF loads in flight
 #pragma unroll
-                for (int k = 0; k < WN; ++k) {
-                    const int r = wrow + k * 32 + j + sh;
-                    bf[k] = __builtin_bit_cast(AF, *reinterpret_cast<const u32x4*>(lds + (size_t)r * RS + (ks * KS + hf * E) * sizeof(CT)));
+                for (int u = 0; u < PF; ++u) {
+                    if (tc < a.ntaps) {
+                        const int sh = sbase + tc * sstep - smin;
+                        AF bf[WN];
+#pragma unroll
+                        for (int k = 0; k < WN; ++k) {
+                            const int r = wrow + k * 32 + j + sh;
+                            bf[k] = __builtin_bit_cast(AF, *reinterpret_cast<const u32x4*>(lds + (size_t)r * RS + (ksc * KS + hf * E) * sizeof(CT)));
+                        }
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) {
+                            const AF af = __builtin_bit_cast(AF, wa[u][i]);
+#pragma unroll
+                            for (int k = 0; k < WN; ++k) Mma<CT>::run(acc[i][k], af, bf[k]);
+                        }
+                    }
+                    ksc += STEP;
+                    while (ksc >= kst) { ksc -= kst; ++tc; }
                 }
 #pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    const AF af = __builtin_bit_cast(AF, wa[i]);
+                for (int u = 0; u < PF; ++u)
 #pragma unroll
-                    for (int k = 0; k < WN; ++k) Mma<CT>::run(acc[i][k], af, bf[k]);
-                }
-#pragma unroll
-                for (int i = 0; i < WM; ++i) wa[i] = wn[i];
+                    for (int i = 0; i < WM; ++i) wa[u][i] = wn[u][i];
             }
         }
     }
