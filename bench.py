@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-runs", type=int, default=30)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CI on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -155,11 +157,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.share_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     else:
         dist = None
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus

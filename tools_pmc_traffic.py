@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; CSV) into per-kernel HBM traffic per launch.
+
+Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE tallies the 128-B requests of a wide coalesced stream at 64 B, i.e. reports exactly 1/2 of the
+bytes fetched -> doubled here; WRITE_SIZE is taken as is (uncalibrated).  Infinity-Cache hits are
+counted, so for weight sets that fit the 256 MiB cache this is fabric traffic, not DRAM traffic.
+usage: tools_pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv, json, re, sys
+from collections import defaultdict
+
+def per_kernel(path):
+    acc = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+def short(name):
+    m = re.search(r"gsv::(\w+)", name)
+    return m.group(1) if m else name[:40]
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+out = {}
+for k, v in fetch.items():
+    w = write.get(k, [0.0])
+    s = short(k)
+    f_bytes = 2.0 * 1024.0 * sum(v) / len(v)
+    w_bytes = 1024.0 * sum(w) / len(w)
+    e = out.setdefault(s, {"launches": 0, "fetch_bytes_per_launch": 0.0, "write_bytes_per_launch": 0.0})
+    n0, n1 = e["launches"], len(v)
+    e["fetch_bytes_per_launch"] = (e["fetch_bytes_per_launch"] * n0 + f_bytes * n1) / (n0 + n1)
+    e["write_bytes_per_launch"] = (e["write_bytes_per_launch"] * n0 + w_bytes * n1) / (n0 + n1)
+    e["launches"] = n0 + n1
+flat = {k: v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in out.items()}
+json.dump({"_detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
+for k in sorted(out, key=lambda k: -out[k]["launches"])[:12]:
+    print("%-28s launches %6d  fetch %10.0f B  write %9.0f B" % (k, out[k]["launches"], out[k]["fetch_bytes_per_launch"], out[k]["write_bytes_per_launch"]))
