@@ -161,3 +161,64 @@ def test_stochastic_sampling_runs_and_respects_rules(dev):
         assert tok.min() >= 0 and tok.max() < 1025 and len(tok) > 0
         assert not set(tok[:8].tolist()) & {280, 486, 1024}
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_bucket_hop_and_full_cache_fp32(dev):
+    """the last sample is taken when the KV cache is exactly full (pre_tokens column T) and a hop
+    between nested buckets changes nothing: [(1,72),(1,100)] must equal [(1,100)] token for token."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=4)
+    w = synth.gpt_weights(cfg, seed=91, eos_gain=0.0)
+    x, y, bert, _ = synth.synth_request(3, 6, 9, 11, seed=91)
+    outs = []
+    for cache in ([(1, 72), (1, 100)], [(1, 100)]):
+        m = _model(cfg, w, cache, torch.float32, dev)
+        outs.append(m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1)[0, 0].cpu().numpy())
+    assert len(outs[0]) == 100 - (len(x) + len(y))          # ran to capacity: max_kv - L tokens
+    assert np.array_equal(outs[0], outs[1])
+    ref = orc.T2SOracle(cfg, w, [(1, 100)]).infer(x, y, bert, top_k=1)
+    assert np.array_equal(outs[0], ref)
+
+
+def test_prompt_too_long_and_bad_args_raise(dev):
+    cfg = synth.gpt_config(n_layer=2)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=1), [(1, 48)], torch.float32, dev)
+    x, y, bert, _ = synth.synth_request(0, 20, 20, 20, seed=1)        # 60 positions > 48
+    with pytest.raises(ValueError):
+        m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1)
+    from gsv_tts_lite_amd import _native as N
+    import ctypes
+    with pytest.raises(RuntimeError):                                 # unknown batch size: no state bound
+        N.check(N.lib().gsv_t2s_decode(m._h, 7, 1, 0, N.current_stream_ptr(dev)))
+    bad = N.T2SConfig(2, 256, 8, 1025, 1024, 4000, 732, 0)            # unsupported hidden size
+    h = ctypes.c_void_p()
+    assert N.lib().gsv_t2s_create(ctypes.byref(bad), ctypes.byref(h)) == 1
+    assert b"unsupported" in N.lib().gsv_last_error()
+
+
+def test_batched_ragged_lengths_vs_oracle_fresh(dev):
+    """ragged batch (lengths 1..) with more requests than slots, oracle computed on this box"""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=5)
+    w = synth.gpt_weights(cfg, seed=17, eos_gain=2.5)
+    cache = [(4, 96), (4, 120)]
+    shapes = [(1, 1, 1), (3, 9, 20), (8, 20, 5), (2, 2, 31), (5, 14, 9), (4, 4, 4), (9, 11, 17)]
+    rs = [synth.synth_request(40 + i, p, t, n, seed=17, bert="random") for i, (p, t, n) in enumerate(shapes)]
+    o = orc.T2SOracle(cfg, w, cache)
+    ref, ref_idx = o.infer_batched([r[0] for r in rs], [r[1] for r in rs], [r[2] for r in rs], top_k=1)
+    m = _model(cfg, w, cache, torch.float32, dev)
+    pred, idx = m.infer_batched([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs], top_k=1)
+    assert idx.tolist() == ref_idx.tolist()
+    for a, b in zip(pred, ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_top_p_and_temperature_path_runs(dev):
+    cfg = synth.gpt_config(n_layer=3)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=2), [(1, 80), (2, 80)], torch.float32, dev)
+    x, y, bert, _ = synth.synth_request(1, 5, 9, 12, seed=2)
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=8, top_p=0.7, temperature=0.8, generator=gen)
+    assert tok.shape[-1] > 0 and int(tok.max()) <= 1024
+    pred, idx = m.infer_batched([_T(x, dev)] * 3, [_T(y, dev)] * 3, [_T(bert, dev)] * 3, top_k=5, generator=gen)
+    assert sorted(idx.tolist()) == [0, 1, 2] and all(len(p) > 0 for p in pred)
