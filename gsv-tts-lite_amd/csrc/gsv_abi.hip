@@ -13,6 +13,7 @@
 
 #include "../../include/gsv_tts_hip.h"
 #include "t2s_decode.h"
+#include "t2s_megastep.h"
 #include "t2s_prefill.h"
 #include "tapgemm.h"
 #include "voc_kernels.h"
@@ -154,7 +155,8 @@ struct T2SLayer {
 
 struct T2SBound {
     gsv_t2s_state st;
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph = nullptr;       // 2-kernels-per-layer step
+    hipGraphExec_t graph_mega = nullptr;  // persistent (megastep) step
 };
 
 struct gsv_t2s {
@@ -172,6 +174,8 @@ struct gsv_t2s {
     TokPart* tokpart = nullptr;
     hipStream_t cap_stream = nullptr;
     unsigned long long* dbg = nullptr;
+    void* mega_layers = nullptr;   // device MegaLayer<WT>[n_layer]
+    unsigned* mega_cnt = nullptr;  // [scratch_b][2*n_layer] + 1 (err)
 };
 
 namespace {
@@ -297,10 +301,14 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     HIPCHK(hipMalloc(&h->zpart, sizeof(float) * B * kNJ * kD));
     HIPCHK(hipMalloc(&h->tokpart, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
+    if (h->mega_cnt) (void)hipFree(h->mega_cnt);
+    HIPCHK(hipMalloc(&h->mega_cnt, sizeof(unsigned) * ((size_t)B * 2 * h->cfg.n_layer + 1)));
+    HIPCHK(hipMemset(h->mega_cnt, 0, sizeof(unsigned) * ((size_t)B * 2 * h->cfg.n_layer + 1)));
     h->scratch_b = B;
     // graphs captured against the old scratch pointers are stale
     for (auto& kv : h->bound)
-        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+        { if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+          if (kv.second.graph_mega) { (void)hipGraphExecDestroy(kv.second.graph_mega); kv.second.graph_mega = nullptr; } }
     return GSV_OK;
 }
 
@@ -367,15 +375,35 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
     a.pre_tokens = s.pre_tokens; a.seen = s.seen; a.step = s.step; a.eos_at = s.eos_at; a.emb = h->emb_audio;
     a.pe = h->pe_audio; a.xcur = h->xcur; a.T = s.max_kv; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.n_pos = h->cfg.n_pos;
     a.advance = advance;
+    a.mega_cnt = h->mega_cnt; a.mega_n = 2 * h->cfg.n_layer;
+    if (a.mega_n > 256) a.mega_cnt = nullptr;
     hipLaunchKernelGGL(t2s_token_kernel, dim3(s.batch), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
 
+constexpr int kMegaMaxBatch = 4;  // 48 blocks per sequence, one block per CU, all co-resident
+
 template <typename WT>
-int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
+int t2s_mega_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st) {
+    const int NL = h->cfg.n_layer, B = s.batch;
+    if (B > kMegaMaxBatch) return fail(GSV_ERR_ARG, "megastep supports batch <= %d", kMegaMaxBatch);
+    if (2 * NL > 256) return fail(GSV_ERR_ARG, "megastep supports at most 128 layers");
+    // hand-off counters are zeroed by the token kernel that precedes this launch in every step
+    MegaArgs<WT> a;
+    a.layers = (const MegaLayer<WT>*)h->mega_layers; a.n_layer = NL; a.xin = xsrc; a.xbuf = h->xbuf; a.x1buf = h->x1buf;
+    a.ypart = h->ypart; a.zpart = h->zpart; a.kc = (WT*)s.k_cache; a.vc = (WT*)s.v_cache;
+    a.layer_elems = (size_t)B * kH * s.max_kv * kDh; a.T = s.max_kv; a.kv_len = s.kv_len; a.cnt = h->mega_cnt;
+    a.err = h->mega_cnt + (size_t)h->scratch_b * 2 * NL;
+    hipLaunchKernelGGL((t2s_megastep_kernel<WT>), dim3(kMegaRoles, B), dim3(kNT), 0, st, a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+template <typename WT>
+int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, bool mega, hipStream_t st) {
     if (int rc = t2s_token(h, s, 1, st)) return rc;
-    if (int rc = t2s_layers<WT>(h, s, h->xcur, st)) return rc;
+    if (int rc = mega ? t2s_mega_layers<WT>(h, s, h->xcur, st) : t2s_layers<WT>(h, s, h->xcur, st)) return rc;
     return t2s_logits<WT>(h, s, 1, nullptr, 0, s.batch, h->cfg.vocab, 1, st);
 }
 
@@ -484,8 +512,12 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
 int gsv_t2s_destroy(gsv_t2s* h) {
     if (!h) return GSV_OK;
     (void)hipDeviceSynchronize();
-    for (auto& kv : h->bound)
+    for (auto& kv : h->bound) {
         if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
+        if (kv.second.graph_mega) (void)hipGraphExecDestroy(kv.second.graph_mega);
+    }
+    if (h->mega_layers) (void)hipFree(h->mega_layers);
+    if (h->mega_cnt) (void)hipFree(h->mega_cnt);
     for (T2SLayer& L : h->layers) {
         for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
                         (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b})
@@ -525,6 +557,17 @@ int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
     for (int l = 0; l < h->cfg.n_layer; ++l)
         if (h->layers[l].have != 0xfffu) return fail(GSV_ERR_STATE, "layer %d incomplete (mask 0x%x)", l, h->layers[l].have);
     if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
+    {   // device table of per-layer pointers for the persistent step
+        struct Raw { const void *wqkv, *wo, *w1, *w2p; const float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b; };
+        static_assert(sizeof(Raw) == sizeof(MegaLayer<float>) && sizeof(Raw) == sizeof(MegaLayer<bf16_t>), "layout");
+        std::vector<Raw> tab(h->cfg.n_layer);
+        for (int l = 0; l < h->cfg.n_layer; ++l) {
+            const T2SLayer& L = h->layers[l];
+            tab[l] = Raw{L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.bqkv_p, L.bo, L.b1, L.b2, L.ln1g, L.ln1b, L.ln2g, L.ln2b};
+        }
+        if (!h->mega_layers) HIPCHK(hipMalloc(&h->mega_layers, sizeof(Raw) * tab.size()));
+        HIPCHK(hipMemcpy(h->mega_layers, tab.data(), sizeof(Raw) * tab.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipStreamSynchronize(S(stream)));
     h->finalized = true;
     return GSV_OK;
@@ -539,6 +582,7 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     if (int rc = t2s_ensure_scratch(h, st->batch)) return rc;
     T2SBound& b = h->bound[st->batch];
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (b.graph_mega) { (void)hipGraphExecDestroy(b.graph_mega); b.graph_mega = nullptr; }
     b.st = *st;
     return GSV_OK;
 }
@@ -600,24 +644,35 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
     T2SBound* b = t2s_find(h, batch);
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     const bool bf = h->cfg.dtype == GSV_BF16;
-    if (!use_graph) {
+    const bool graph = (use_graph & 1) != 0;
+    const bool mega = (use_graph & 2) != 0 && batch <= kMegaMaxBatch && 2 * h->cfg.n_layer <= 256;
+    if (!graph) {
         for (int i = 0; i < n_steps; ++i)
-            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream)) : t2s_step<float>(h, b->st, S(stream))) return rc;
+            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, mega, S(stream)) : t2s_step<float>(h, b->st, mega, S(stream))) return rc;
         return GSV_OK;
     }
-    if (!b->graph) {
+    hipGraphExec_t& exec = mega ? b->graph_mega : b->graph;
+    if (!exec) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream) : t2s_step<float>(h, b->st, h->cap_stream);
+        int rc = bf ? t2s_step<bf16_t>(h, b->st, mega, h->cap_stream) : t2s_step<float>(h, b->st, mega, h->cap_stream);
         hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
     }
-    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(b->graph, S(stream)));
+    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(exec, S(stream)));
     return GSV_OK;
+}
+
+/* 1 if any persistent-step hand-off ever timed out on this handle (results are then invalid) */
+int gsv_t2s_megastep_error(gsv_t2s* h) {
+    if (!h || !h->mega_cnt) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, h->mega_cnt + (size_t)h->scratch_b * 2 * h->cfg.n_layer, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
 }
 
 int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream) {
@@ -632,7 +687,8 @@ int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
     if (!h) return fail(GSV_ERR_ARG, "null handle");
     h->dbg = (unsigned long long*)buf;
     for (auto& kv : h->bound)
-        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+        { if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+          if (kv.second.graph_mega) { (void)hipGraphExecDestroy(kv.second.graph_mega); kv.second.graph_mega = nullptr; } }
     return GSV_OK;
 }
 

@@ -231,6 +231,26 @@ template <int NPART> struct PartialSum {
             bias = b[t]; resid = r[t]; lng = g[t]; lnb = beta[t];
         }
     }
+    // Same loads for payload another workgroup published INSIDE this launch: device-coherent
+    // (sc1) loads that cannot be served from a stale line of this CU's L1 / this XCD's L2.
+    __device__ __forceinline__ void issue_coherent(const float* part, const float* __restrict__ b, const float* r,
+                                                   const float* __restrict__ g, const float* __restrict__ beta,
+                                                   size_t part_bytes) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(part), 0, (int)part_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const unsigned off = (unsigned)(((wid * NPW + j) * kD + c * 256 + lane * 4) * sizeof(float));
+                p[j][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17));  // sc0 sc1
+            }
+        if (threadIdx.x < kD) {
+            const int t = threadIdx.x;
+            bias = b[t]; lng = g[t]; lnb = beta[t];
+            resid = __hip_atomic_load(r + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     __device__ __forceinline__ void park(float* __restrict__ stage) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -722,11 +742,16 @@ struct TokenArgs {
     const float* pe;         // [n_pos][512] alpha_audio * pe
     float* xcur;             // [B][512]
     int T, V, eos, n_pos, advance;
+    unsigned* mega_cnt;      // [B][mega_n] hand-off counters of the persistent step, zeroed here (or null)
+    int mega_n;
 };
 
 __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x;
+    // re-initialise the persistent step's counters from the kernel that precedes it in the chain
+    // (kernel->kernel ordering; a captured memset node was observed to race with the first replay)
+    if (a.mega_cnt != nullptr && tid < a.mega_n) a.mega_cnt[(size_t)b * a.mega_n + tid] = 0u;
     if (tid == 0) {
         int tok;
         if (a.ctl[0] != 0) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "gsv_version", "gsv_last_error",
     "gsv_t2s_create", "gsv_t2s_destroy", "gsv_t2s_load_tensor", "gsv_t2s_finalize", "gsv_t2s_bind_state",
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_decode_hidden",
-    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug",
+    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_megastep_error",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec",
 ]
@@ -71,6 +71,7 @@ def lib():
         "gsv_t2s_decode": [vp, i, i, i, vp],
         "gsv_t2s_flush": [vp, i, vp],
         "gsv_t2s_set_debug": [vp, vp],
+        "gsv_t2s_megastep_error": [vp],
         "gsv_t2s_time_kernels": [vp, i, i, ctypes.POINTER(ctypes.c_float), vp],
         "gsv_voc_create": [ctypes.POINTER(VocConfig), ctypes.POINTER(vp)],
         "gsv_voc_destroy": [vp],

@@ -90,6 +90,9 @@ class Text2SemanticDecoder:
         self.suppressed_tokens = [280, 486, self.EOS]
         self.cuda_graph_buckets = {}
         self.use_graph = True
+        # persistent decode step (csrc/t2s_megastep.h, batch <= 4): correct and stress-tested, but measured
+        # equal-to-slightly-slower than the per-layer graph (hand-off ~= kernel boundary), so off by default
+        self.use_megastep = False
         self._weights = None
         self._h = None
         self._rt = {}
@@ -225,8 +228,11 @@ class Text2SemanticDecoder:
         return self._rt[batch]["hidden"]
 
     def _decode(self, batch, n):
-        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, 1 if self.use_graph else 0,
-                                       N.current_stream_ptr(self.device)))
+        mode = (1 if self.use_graph else 0) | (2 if self.use_megastep else 0)
+        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, mode, N.current_stream_ptr(self.device)))
+
+    def megastep_error(self) -> bool:
+        return N.lib().gsv_t2s_megastep_error(self._h) != 0
 
     def _flush(self, batch):
         N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))

@@ -118,8 +118,11 @@ int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
  * take the pending token (greedy argmax of the penalised logits, or tok_override), record it in
  * pre_tokens[b][kv_len[b]], build emb + alpha*pe[kv_len - x_len], run the layers, bump kv_len,
  * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
- * When use_graph != 0 the step is replayed from a hipGraph captured on first use. */
+ * `use_graph` is a bit set: bit 0 = replay the step from a hipGraph captured on first use; bit 1 =
+ * persistent step (all layers in one launch with in-kernel hand-offs; batch <= 4, else ignored). */
 int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream);
+/* 1 if a hand-off of the persistent step ever hit its spin bound on this handle (results invalid) */
+int gsv_t2s_megastep_error(gsv_t2s* h);
 /* Measurement aid (bench.py `roofline`): average duration in ms of ONE launch of each decode-step
  * kernel class {attn, ffn, logits, token}, timed with hipEvents on `stream` around `iters`
  * back-to-back sweeps over all layers' launches of that class on the live state (every layer
