@@ -92,32 +92,56 @@ struct Epi {
     bool use_bias = true;
 };
 
+struct Branch {
+    const PackedConv* pc;
+    const void* X;
+    void* Y;
+    const void* res;
+};
+
+// One launch for up to 3 convolutions of the same shape class (same cin/cout/ld/rows, different
+// kernel size, dilation, weights and buffers): blockIdx.z is the branch.
 template <typename IT, typename CT, typename OT>
-int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, int n_rows, const Epi& e,
-             hipStream_t st) {
+int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n_rows, const Epi& e, hipStream_t st) {
+    const PackedConv& pc = *brs[0].pc;
+    if (nbr < 1 || nbr > 3) return fail(GSV_ERR_ARG, "tapgemm: 1..3 branches");
+    for (int i = 1; i < nbr; ++i)
+        if (brs[i].pc->cout != pc.cout || brs[i].pc->cin != pc.cin || brs[i].pc->u != 0 || pc.u != 0)
+            return fail(GSV_ERR_ARG, "tapgemm: branches must be plain convs of one shape");
     TapGemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.X = X; a.ldx = ldx; a.n_in = n_in; a.cin = pc.cin; a.W = pc.w; a.cout = pc.cout; a.mtiles = pc.mtiles;
+    a.X = brs[0].X; a.ldx = ldx; a.n_in = n_in; a.cin = pc.cin; a.W = pc.w; a.cout = pc.cout; a.mtiles = pc.mtiles;
     a.ntaps = pc.ntaps; a.nphase = pc.nphase;
     a.tstep = pc.dil; a.tpad = pc.pad; a.tu = pc.u;
     a.omul = pc.u > 0 ? pc.u : 1;
-    auto shift_of = [&](int r, int t) { return pc.u > 0 ? (r + pc.pad) / pc.u - t : t * pc.dil - pc.pad; };
+    a.nbranch = nbr;
+    if (nbr > 1) { a.X1 = brs[1].X; a.W1 = brs[1].pc->w; a.res1 = brs[1].res; a.bias1 = e.use_bias ? brs[1].pc->bias : nullptr; a.Y1 = brs[1].Y;
+                   a.ntaps1 = brs[1].pc->ntaps; a.tstep1 = brs[1].pc->dil; a.tpad1 = brs[1].pc->pad; }
+    if (nbr > 2) { a.X2 = brs[2].X; a.W2 = brs[2].pc->w; a.res2 = brs[2].res; a.bias2 = e.use_bias ? brs[2].pc->bias : nullptr; a.Y2 = brs[2].Y;
+                   a.ntaps2 = brs[2].pc->ntaps; a.tstep2 = brs[2].pc->dil; a.tpad2 = brs[2].pc->pad; }
     a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
-    a.res = e.res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
-    a.accumulate = e.accumulate; a.Y = Y; a.ldy = ldy; a.n_rows = n_rows;
+    a.res = brs[0].res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
+    a.accumulate = e.accumulate; a.Y = brs[0].Y; a.ldy = ldy; a.n_rows = n_rows;
     // tile choice.  Enough rows to fill the chip several times over -> wide tiles (weights reused
     // across 64 rows/channels per wave); short sequences (prefill, flow, conditioning GEMV) ->
     // one 32x32 tile per block with the 4 waves splitting K.
     int span = 0;
-    for (int r = 0; r < pc.nphase; ++r) {
-        int lo = 1 << 30, hi = -(1 << 30);
-        for (int t = 0; t < pc.ntaps; ++t) { lo = std::min(lo, shift_of(r, t)); hi = std::max(hi, shift_of(r, t)); }
-        span = std::max(span, hi - lo);
+    for (int i = 0; i < nbr; ++i) {
+        const PackedConv& q = *brs[i].pc;
+        for (int r = 0; r < q.nphase; ++r) {
+            int lo = 1 << 30, hi = -(1 << 30);
+            for (int t = 0; t < q.ntaps; ++t) {
+                const int sh = q.u > 0 ? (r + q.pad) / q.u - t : t * q.dil - q.pad;
+                lo = std::min(lo, sh); hi = std::max(hi, sh);
+            }
+            span = std::max(span, hi - lo);
+        }
     }
-    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * pc.nphase;   // blocks at (WM,WN) = (1,1)
+    const int nz = nbr > 1 ? nbr : pc.nphase;
+    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * nz;   // blocks at (WM,WN) = (1,1)
     const bool splitk = tiles11 < 256;
     const bool wide_m = !splitk && pc.mtiles >= 2 && tiles11 >= 1024;
-    const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * pc.nphase >= 1024;
+    const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * nz >= 1024;
     const int bn = splitk ? 32 : (wide_n ? 256 : 128);
     const int kcb = wide_n ? 128 : 256;               // staged bytes per row per chunk
     size_t lds = (size_t)(bn + span) * (kcb + 16);
@@ -130,14 +154,21 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
         return GSV_OK;
     };
     int rc;
-    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, true>, dim3(cdiv(n_rows, 32), pc.mtiles, pc.nphase));
-    else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), pc.nphase));
-    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), pc.nphase));
-    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, pc.nphase));
-    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, false>, dim3(cdiv(n_rows, 128), pc.mtiles, pc.nphase));
+    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, true>, dim3(cdiv(n_rows, 32), pc.mtiles, nz));
+    else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), nz));
+    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), nz));
+    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
+    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, false>, dim3(cdiv(n_rows, 128), pc.mtiles, nz));
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return GSV_OK;
+}
+
+template <typename IT, typename CT, typename OT>
+int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, int n_rows, const Epi& e,
+             hipStream_t st) {
+    Branch b{&pc, X, Y, e.res};
+    return run_conv_multi<IT, CT, OT>(&b, 1, ldx, n_in, ldy, n_rows, e, st);
 }
 
 }  // namespace
@@ -737,7 +768,7 @@ struct VocWs {
     // channels-last buffers (element type AT unless noted)
     void *zin, *zflip, *h, *outp, *a, *acts, *ge_cl;
     float *gc, *condbuf;
-    void* st[5];  // stage ping-pong: xu, xa, xb, t1, xs
+    void* st[11];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}
     size_t bytes;
 };
 
@@ -758,7 +789,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H);
     w.condbuf = (float*)take(sizeof(float) * (size_t)Tg * c.upsample_initial_channel);
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
-    for (int i = 0; i < 5; ++i) w.st[i] = take(sizeof(AT) * se);
+    for (int i = 0; i < 11; ++i) w.st[i] = take(sizeof(AT) * se);
     w.bytes = off;
     return w;
 }
@@ -804,39 +835,44 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
     const int C0 = c.upsample_initial_channel;
     Epi ec;
     if (int rc = run_conv<AT, AT, float>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, Tg, ec, st)) return rc;
-    AT* x = (AT*)w.st[4];
+    AT* x = (AT*)w.st[1];
     Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0;
     if (int rc = run_conv<AT, AT, AT>(v->conv_pre, w.zin, c.inter_channels, T, x, ld_of(C0), T, ep, st)) return rc;
     int Tc = T;
-    AT *xu = (AT*)w.st[0], *xa = (AT*)w.st[1], *xb = (AT*)w.st[2], *t1 = (AT*)w.st[3];
+    AT* xu = (AT*)w.st[0];
+    const int NB = (int)v->stages[0].rb.size();
+    if (NB != 3) return fail(GSV_ERR_ARG, "the fused branch launch expects 3 resblock kernels per stage");
     for (size_t i = 0; i < v->stages.size(); ++i) {
         VocStage& sg = v->stages[i];
         const int ldi = ld_of(sg.cin), ldo = ld_of(sg.cout);
         const int Tn = Tc * sg.u;
         if (ldo != sg.cout) {  // pad channels feed zero-weight k-steps but must not hold NaN/Inf bit patterns
-            for (AT* p : {xu, xa, xb, t1}) HIPCHK(hipMemsetAsync(p, 0, sizeof(AT) * (size_t)Tn * ldo, st));
+            for (int q = 0; q < 11; ++q)
+                if (q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
         }
         Epi eu; eu.in_slope = 0.1f;
         if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
-        AT* xs = x;  // the stage input buffer is dead once the upsample has read it: accumulate the mean there
-        if (ldo != sg.cout) HIPCHK(hipMemsetAsync(xs, 0, sizeof(AT) * (size_t)Tn * ldo, st));
-        const float inv = 1.0f / (float)sg.rb.size();
-        for (size_t j = 0; j < sg.rb.size(); ++j) {
-            VocResBlock& rb = sg.rb[j];
-            const AT* cur = xu;
-            for (int d = 0; d < 3; ++d) {
-                Epi e1; e1.in_slope = 0.1f;
-                if (int rc = run_conv<AT, AT, AT>(rb.c1[d], cur, ldo, Tn, t1, ldo, Tn, e1, st)) return rc;
-                Epi e2; e2.in_slope = 0.1f; e2.res = cur; e2.ld_res = ldo;
-                AT* dst = (d == 0) ? xa : (d == 1 ? xb : xs);
-                if (d == 2) { e2.scale = inv; e2.accumulate = j > 0; }
-                if (int rc = run_conv<AT, AT, AT>(rb.c2[d], t1, ldo, Tn, dst, ldo, Tn, e2, st)) return rc;
-                cur = dst;
+        if (ldo != sg.cout) HIPCHK(hipMemsetAsync(x, 0, sizeof(AT) * (size_t)Tn * ldo, st));
+        // the three resblocks (k = 3, 7, 11) advance in lock step: one launch per conv position
+        const AT* cur[3] = {xu, xu, xu};
+        for (int d = 0; d < 3; ++d) {
+            Branch b1[3], b2[3];
+            for (int j = 0; j < 3; ++j) {
+                AT* t1 = (AT*)w.st[2 + 3 * j];
+                AT* dst = (AT*)w.st[2 + 3 * j + 1 + (d & 1)];
+                b1[j] = Branch{&sg.rb[j].c1[d], cur[j], t1, nullptr};
+                b2[j] = Branch{&sg.rb[j].c2[d], t1, dst, cur[j]};
             }
+            Epi e1; e1.in_slope = 0.1f;
+            if (int rc = run_conv_multi<AT, AT, AT>(b1, 3, ldo, Tn, ldo, Tn, e1, st)) return rc;
+            Epi e2; e2.in_slope = 0.1f; e2.ld_res = ldo;
+            if (int rc = run_conv_multi<AT, AT, AT>(b2, 3, ldo, Tn, ldo, Tn, e2, st)) return rc;
+            for (int j = 0; j < 3; ++j) cur[j] = (const AT*)b2[j].Y;
         }
-        x = xs;
+        const size_t n = (size_t)Tn * ldo;
+        hipLaunchKernelGGL((avg3_kernel<AT>), dim3((unsigned)std::min<size_t>(4096, (n / 8 + 255) / 256)), dim3(256), 0, st,
+                           cur[0], cur[1], cur[2], x, n);
         Tc = Tn;
-        // stage output lives where the stage input was; next stage's xu etc. stay distinct
     }
     Epi eo; eo.in_slope = 0.01f; eo.act = ACT_TANH; eo.use_bias = false;
     if (int rc = run_conv<AT, AT, float>(v->conv_post, x, ld_of(v->stages.back().cout), Tc, out, 1, Tc, eo, st)) return rc;

@@ -55,6 +55,14 @@ struct TapGemmArgs {
     int ldy;
     int n_rows;          // rows n computed per phase: n in [0, n_rows)
     int omul;            // output row = n*omul + phase
+    // Up to 3 independent convolutions of the same shape class in ONE launch (blockIdx.z selects
+    // the branch; only for nphase == 1): the three resblocks of a Generator stage share input
+    // shape and channel counts but differ in kernel size / dilation / weights / buffers.
+    int nbranch;
+    const void *X1, *X2, *W1, *W2, *res1, *res2;
+    const float *bias1, *bias2;
+    void *Y1, *Y2;
+    int ntaps1, ntaps2, tstep1, tstep2, tpad1, tpad2;
 };
 
 template <typename CT> struct MfmaK;
@@ -197,19 +205,29 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
     using AF = typename BFrag<IT, CT>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int phase = blockIdx.z;
+    // branch select (scalar): branches exist only for plain convs, where the phase index is 0
+    const int br = a.nbranch > 1 ? (int)blockIdx.z : 0;
+    const int phase = a.nbranch > 1 ? 0 : (int)blockIdx.z;
+    const void* Xv = br == 0 ? a.X : (br == 1 ? a.X1 : a.X2);
+    const void* Wv = br == 0 ? a.W : (br == 1 ? a.W1 : a.W2);
+    const void* Rv = br == 0 ? a.res : (br == 1 ? a.res1 : a.res2);
+    void* Yv = br == 0 ? a.Y : (br == 1 ? a.Y1 : a.Y2);
+    const float* Bv = br == 0 ? a.bias : (br == 1 ? a.bias1 : a.bias2);
+    const int ntaps = br == 0 ? a.ntaps : (br == 1 ? a.ntaps1 : a.ntaps2);
+    const int tstep = br == 0 ? a.tstep : (br == 1 ? a.tstep1 : a.tstep2);
+    const int tpad = br == 0 ? a.tpad : (br == 1 ? a.tpad1 : a.tpad2);
     const int nb0 = blockIdx.x * BN;          // first output row of the block
     const int wrow = SPLITK ? 0 : wid * (WN * 32);  // first row of the wave inside the block tile
     const int n0 = nb0 + wrow;                // first output row of the wave
     const int mt0 = blockIdx.y * WM;
     const int j = lane & 31, hf = lane >> 5;
     const int ksteps = a.cin / KS;
-    const IT* X = reinterpret_cast<const IT*>(a.X);
-    const uint4* Wp = reinterpret_cast<const uint4*>(a.W);
+    const IT* X = reinterpret_cast<const IT*>(Xv);
+    const uint4* Wp = reinterpret_cast<const uint4*>(Wv);
 
-    const int sbase = a.tu > 0 ? (phase + a.tpad) / a.tu : -a.tpad;   // shift of tap 0
-    const int sstep = a.tu > 0 ? -1 : a.tstep;                          // shift increment per tap
-    const int slast = sbase + (a.ntaps - 1) * sstep;
+    const int sbase = a.tu > 0 ? (phase + tpad) / a.tu : -tpad;       // shift of tap 0
+    const int sstep = a.tu > 0 ? -1 : tstep;                            // shift increment per tap
+    const int slast = sbase + (ntaps - 1) * sstep;
     const int smin = min(sbase, slast), smax = max(sbase, slast);
     const int rows = BN + smax - smin;        // staged rows
     const int row_base = nb0 + smin;          // global row of staged row 0
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
             const uint4* wbase[WM];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                wbase[i] = Wp + (((size_t)phase * a.ntaps * a.mtiles + min(mt0 + i, a.mtiles - 1)) * ksteps + ks0) * 64 + lane;
+                wbase[i] = Wp + (((size_t)phase * ntaps * a.mtiles + min(mt0 + i, a.mtiles - 1)) * ksteps + ks0) * 64 + lane;
             const size_t tap_stride = (size_t)a.mtiles * ksteps * 64;
             // Weight fragments come from L2 (~500+ cycles) and a block holds only 1-2 waves per SIMD, so
             // they are fetched a whole GROUP of PF iterations ahead: PF loads in flight cover PF
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
             auto fetch = [&](uint4 (&dst)[PF][WM]) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
-                    if (tl < a.ntaps) {
+                    if (tl < ntaps) {
 #pragma unroll
                         for (int i = 0; i < WM; ++i) dst[u][i] = wbase[i][tl * tap_stride + (size_t)ksl * 64];
                     }
@@ -270,11 +288,11 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
                 }
             };
             fetch(wa);
-            while (tc < a.ntaps) {
+            while (tc < ntaps) {
                 fetch(wn);                               // next group's weights: PF loads in flight
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
-                    if (tc < a.ntaps) {
+                    if (tc < ntaps) {
                         const int sh = sbase + tc * sstep - smin;
                         AF bf[WN];
 #pragma unroll
@@ -326,8 +344,8 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
     if (!wave_live) return;
 
     // epilogue
-    OT* Y = reinterpret_cast<OT*>(a.Y);
-    const OT* R = reinterpret_cast<const OT*>(a.res);
+    OT* Y = reinterpret_cast<OT*>(Yv);
+    const OT* R = reinterpret_cast<const OT*>(Rv);
     const float* A = reinterpret_cast<const float*>(a.add);
 #pragma unroll
     for (int k = 0; k < WN; ++k) {
@@ -347,9 +365,9 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmArgs a) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][k][4 * g + e];
-                if (a.bias) {
+                if (Bv) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (full || m + e < a.cout) ? a.bias[m + e] : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] += (full || m + e < a.cout) ? Bv[m + e] : 0.f;
                 }
                 if (A) {
                     const float* ap = A + (a.ld_add ? orow * (size_t)a.ld_add : (size_t)0) + m;

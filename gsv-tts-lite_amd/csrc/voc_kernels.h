@@ -64,6 +64,24 @@ __global__ void gate_kernel(const AT* __restrict__ a, AT* __restrict__ acts, int
     }
 }
 
+// mean of the three resblock branches (models.py:121-127): y = (a + b + c) / 3, 8 elements per thread
+template <typename AT>
+__global__ void avg3_kernel(const AT* __restrict__ a, const AT* __restrict__ b, const AT* __restrict__ c,
+                            AT* __restrict__ y, size_t n) {
+    constexpr int V = 16 / sizeof(AT);
+    const size_t nv = n / V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        float fa[V], fb[V], fc[V];
+        Ld<AT, V>::load(a + i * V, fa);
+        Ld<AT, V>::load(b + i * V, fb);
+        Ld<AT, V>::load(c + i * V, fc);
+        AT o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = from_f32<AT>(((fa[e] + fb[e]) + fc[e]) / 3.0f);
+        *reinterpret_cast<u32x4*>(y + i * V) = *reinterpret_cast<const u32x4*>(o);
+    }
+}
+
 // W = v * (g / ||v||) per output row (torch.nn.utils.weight_norm, dim=0); one block per row
 __global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                         float* __restrict__ w, int row_elems, float sign) {
