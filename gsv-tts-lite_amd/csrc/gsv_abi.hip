@@ -16,6 +16,7 @@
 #include "t2s_megastep.h"
 #include "t2s_prefill.h"
 #include "tapgemm.h"
+#include "wconv.h"
 #include "voc_kernels.h"
 
 using namespace gsv;
@@ -65,7 +66,9 @@ int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_
     pc.mtiles = cdiv(cout, 32);
     if (pc.nphase > 10 || pc.ntaps > 12) return fail(GSV_ERR_ARG, "tapgemm: too many phases/taps");
     const size_t elems = (size_t)pc.nphase * pc.ntaps * pc.mtiles * (cin / KS) * 64 * (KS / 2);
-    HIPCHK(hipMalloc(&pc.w, elems * sizeof(CT)));
+    // + one all-zero fragment: what the pipelined loop fetches for iterations past the end
+    HIPCHK(hipMalloc(&pc.w, (elems + 64 * (KS / 2)) * sizeof(CT)));
+    HIPCHK(hipMemsetAsync((CT*)pc.w + elems, 0, 64 * (KS / 2) * sizeof(CT), st));
     const int blocks = (int)std::min<size_t>(2048, (elems + 255) / 256);
     hipLaunchKernelGGL((tapgemm_pack_kernel<CT>), dim3(blocks), dim3(256), 0, st, src, (CT*)pc.w, cout, cin, k, sm, sc,
                        sk, pc.nphase, pc.ntaps, u, pad, pc.mtiles);
@@ -169,6 +172,59 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
              hipStream_t st) {
     Branch b{&pc, X, Y, e.res};
     return run_conv_multi<IT, CT, OT>(&b, 1, ldx, n_in, ldy, n_rows, e, st);
+}
+
+// The weights-in-registers path for the Generator's resblock convs (wconv.h).  Returns 1 when the
+// launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
+template <typename AT>
+int run_wconv(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
+    (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
+    return -1;
+}
+template <>
+int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
+    const int C = brs[0].pc->cout;
+    if (C != 16 && C != 32 && C != 64 && C != 128) return -1;
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) {
+        const PackedConv& q = *brs[i].pc;
+        if (q.cin != C || q.cout != C || q.u != 0 || (q.k != 3 && q.k != 7 && q.k != 11) || q.dil < 1 || q.dil > 5 ||
+            q.pad != (q.k - 1) / 2 * q.dil || ld < C)
+            return -1;
+    }
+    std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
+    // blocks are dealt in proportion to taps + a per-tile overhead (staging, epilogue) in tap units; both the
+    // overhead and the block count per shape are measured (tools/tg_bench.hip)
+    const int nblk = C == 128 ? 256 : (C == 64 ? 256 : (C == 32 ? 512 : 768));
+    const double ovh = C == 128 ? 8.0 : (C == 64 ? 14.0 : 50.0);
+    double tot = 0;
+    for (int i = 0; i < 3; ++i) tot += brs[i].pc->k + ovh;
+    int nb[3], used = 0;
+    for (int i = 0; i < 3; ++i) { nb[i] = std::max(1, (int)(nblk * (brs[order[i]].pc->k + ovh) / tot)); used += nb[i]; }
+    nb[0] += nblk - used;
+    WConvArgs a;
+    memset(&a, 0, sizeof(a));
+    const Branch &b0 = brs[order[0]], &b1 = brs[order[1]], &b2 = brs[order[2]];
+    a.X0 = (const bf16_t*)b0.X; a.X1 = (const bf16_t*)b1.X; a.X2 = (const bf16_t*)b2.X;
+    a.W0 = (const uint4*)b0.pc->w; a.W1 = (const uint4*)b1.pc->w; a.W2 = (const uint4*)b2.pc->w;
+    a.b0 = b0.pc->bias; a.b1 = b1.pc->bias; a.b2 = b2.pc->bias;
+    a.R0 = (const bf16_t*)b0.res; a.R1 = (const bf16_t*)b1.res; a.R2 = (const bf16_t*)b2.res;
+    a.Y0 = (bf16_t*)b0.Y; a.Y1 = (bf16_t*)b1.Y; a.Y2 = (bf16_t*)b2.Y;
+    a.k0 = b0.pc->k; a.k1 = b1.pc->k; a.k2 = b2.pc->k;
+    a.d0 = b0.pc->dil; a.d1 = b1.pc->dil; a.d2 = b2.pc->dil;
+    a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
+    a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
+    if ((b0.res == nullptr) != (b1.res == nullptr) || (b0.res == nullptr) != (b2.res == nullptr)) return -1;
+    auto launch = [&](auto kern, size_t lds) -> int {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    };
+    if (C == 128) return launch(wconv_kernel<128, 4, 64>, wconv_lds_bytes<128, 4, 64>());
+    if (C == 64) return launch(wconv_kernel<64, 2, 128>, wconv_lds_bytes<64, 2, 128>());
+    if (C == 32) return launch(wconv_kernel<32, 1, 256>, wconv_lds_bytes<32, 1, 256>());
+    return launch(wconv_kernel<16, 1, 256>, wconv_lds_bytes<16, 1, 256>());
 }
 
 }  // namespace
@@ -863,10 +919,20 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
                 b1[j] = Branch{&sg.rb[j].c1[d], cur[j], t1, nullptr};
                 b2[j] = Branch{&sg.rb[j].c2[d], t1, dst, cur[j]};
             }
-            Epi e1; e1.in_slope = 0.1f;
-            if (int rc = run_conv_multi<AT, AT, AT>(b1, 3, ldo, Tn, ldo, Tn, e1, st)) return rc;
-            Epi e2; e2.in_slope = 0.1f; e2.ld_res = ldo;
-            if (int rc = run_conv_multi<AT, AT, AT>(b2, 3, ldo, Tn, ldo, Tn, e2, st)) return rc;
+            // bf16, 16..128 channels: weights-in-registers kernel; the first conv writes lrelu(t1), which is
+            // the only form its consumer reads, so the second conv stages its input without arithmetic
+            int rw = run_wconv<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
+            if (rw > 0) return rw;
+            if (rw == 0) {
+                rw = run_wconv<AT>(b2, ldo, Tn, 1.0f, 1.0f, st);
+                if (rw > 0) return rw;
+                if (rw != 0) return fail(GSV_ERR_STATE, "wconv accepted the first conv of a pair but not the second");
+            } else {
+                Epi e1; e1.in_slope = 0.1f;
+                if (int rc = run_conv_multi<AT, AT, AT>(b1, 3, ldo, Tn, ldo, Tn, e1, st)) return rc;
+                Epi e2; e2.in_slope = 0.1f; e2.ld_res = ldo;
+                if (int rc = run_conv_multi<AT, AT, AT>(b2, 3, ldo, Tn, ldo, Tn, e2, st)) return rc;
+            }
             for (int j = 0; j < 3; ++j) cur[j] = (const AT*)b2[j].Y;
         }
         const size_t n = (size_t)Tn * ldo;

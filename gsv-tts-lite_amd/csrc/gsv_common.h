@@ -24,6 +24,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32, gfx950)
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }

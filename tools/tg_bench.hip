@@ -1,0 +1,188 @@
+// Stand-alone tile-shape sweep for tapgemm on the Generator's resblock convolutions (gfx950).
+// Not part of the product: a bench/diagnostic harness (hipcc tools/tg_bench.hip -o tools/tg_bench).
+//   tg_bench C N        -> 3-branch launch (k = 11, 7, 3; dilation 5) of a CxC conv over N rows
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include "../gsv-tts-lite_amd/csrc/wconv.h"
+
+using namespace gsv;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+struct Conv { bf16_t* w; float* bias; int k, dil, pad; };
+
+template <int WM, int WN, int KCB, int MB, int OCC, int PF = 4>
+float run(const char* name, TapGemmArgs a, int C, int N, int span, int reps, bf16_t* yref, size_t ny, int nbr) {
+    constexpr int NBW = 4 / MB;
+    constexpr int BN = NBW * WN * 32;
+    size_t lds = (size_t)(BN + span) * (KCB + 16);
+    auto kern = tapgemm_kernel<bf16_t, bf16_t, bf16_t, WM, WN, KCB, false, MB, OCC, PF>;
+    if (lds > 160 * 1024) { printf("%-28s LDS %zu too large\n", name, lds); return 0; }
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(cdiv(N, BN), cdiv(a.mtiles, MB * WM), nbr);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const float us = ms * 1e3f / reps;
+    // compare with reference output
+    std::vector<bf16_t> y(ny);
+    CK(hipMemcpy(y.data(), a.Y, ny * 2, hipMemcpyDeviceToHost));
+    double maxd = 0;
+    if (yref) {
+        for (size_t i = 0; i < ny; ++i) {
+            uint32_t ua = (uint32_t)y[i] << 16, ub = (uint32_t)yref[i] << 16;
+            float fa, fb; memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+            maxd = std::max(maxd, (double)fabsf(fa - fb));
+        }
+    }
+    double flops = 0;
+    const int ks[3] = {11, 7, 3};
+    for (int b = 0; b < nbr; ++b) flops += 2.0 * C * C * ks[b] * N;
+    printf("%-28s grid %5d %2d %d lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g\n", name, grid.x, grid.y, grid.z, lds, us,
+           flops / us * 1e-6, maxd);
+    fflush(stdout);
+    return us;
+}
+
+template <int C, int MS, int BN>
+void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf16_t** Yd, size_t ny, int total_blocks, double ovh) {
+    auto kern = wconv_kernel<C, MS, BN>;
+    const size_t lds = wconv_lds_bytes<C, MS, BN>();
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // deal blocks to branches in proportion to cost (taps + fixed overhead)
+    const int ks[3] = {w.k0, w.k1, w.k2};
+    double tot = 0; for (int b = 0; b < 3; ++b) tot += ks[b] + ovh;
+    int nb[3]; int used = 0;
+    for (int b = 0; b < 3; ++b) { nb[b] = std::max(1, (int)(total_blocks * (ks[b] + ovh) / tot)); used += nb[b]; }
+    nb[0] += total_blocks - used;
+    w.nb0 = nb[0]; w.nb1 = nb[1]; w.nb2 = nb[2];
+    dim3 grid(total_blocks);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, w);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, w);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const float us = ms * 1e3f / reps;
+    double maxd = 0; int nbad = 0;
+    std::vector<bf16_t> y(ny);
+    for (int b = 0; b < 3; ++b) {
+        CK(hipMemcpy(y.data(), Yd[b], ny * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ny; ++i) {
+            uint32_t ua = (uint32_t)y[i] << 16, ub = (uint32_t)yref[b][i] << 16;
+            float fa, fb; memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+            if (fabsf(fa - fb) > 0.1f && nbad < 6) { printf("  bad br %d n %zu m %zu got %g want %g\n", b, i / C, i % C, fa, fb); ++nbad; }
+            maxd = std::max(maxd, (double)fabsf(fa - fb));
+        }
+        CK(hipMemset(Yd[b], 0, ny * 2));
+    }
+    double flops = 0;
+    for (int b = 0; b < 3; ++b) flops += 2.0 * C * C * ks[b] * N;
+    printf("%-20s ovh %5.1f grid %5d (%d/%d/%d) lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g\n", name, ovh, total_blocks, nb[0], nb[1], nb[2], lds, us,
+           flops / us * 1e-6, maxd);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const int C = argc > 1 ? atoi(argv[1]) : 128;
+    const int N = argc > 2 ? atoi(argv[2]) : 40000;
+    const int nbr = argc > 3 ? atoi(argv[3]) : 3;
+    const int reps = 20;
+    const int ks[3] = {11, 7, 3};
+    const int dil = 5;
+    const int mtiles = cdiv(C, 32);
+    const int ld = C;
+    srand(1);
+    // activations
+    std::vector<bf16_t> hx((size_t)N * ld);
+    for (auto& v : hx) { float f = (rand() / (float)RAND_MAX - 0.5f) * 2.f; uint32_t u; memcpy(&u, &f, 4); v = (bf16_t)(u >> 16); }
+    bf16_t *X[3], *Y[3], *R[3];
+    Conv cv[3];
+    std::vector<float> HW[3], HB[3];
+    for (int b = 0; b < 3; ++b) {
+        CK(hipMalloc(&X[b], hx.size() * 2)); CK(hipMemcpy(X[b], hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&Y[b], hx.size() * 2)); CK(hipMemset(Y[b], 0, hx.size() * 2));
+        CK(hipMalloc(&R[b], hx.size() * 2)); CK(hipMemcpy(R[b], hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        const int k = ks[b];
+        std::vector<float> hw((size_t)C * C * k), hb(C);
+        for (auto& v : hw) v = (rand() / (float)RAND_MAX - 0.5f) * 0.1f;
+        for (auto& v : hb) v = (rand() / (float)RAND_MAX - 0.5f);
+        float *dw, *db; CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&db, C * 4));
+        CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), C * 4, hipMemcpyHostToDevice));
+        const int ksteps = C / 16;
+        const size_t total = (size_t)k * mtiles * ksteps * 64 * 8;
+        bf16_t* pw; CK(hipMalloc(&pw, (total + 512) * 2)); CK(hipMemset(pw, 0, (total + 512) * 2));
+        hipLaunchKernelGGL((tapgemm_pack_kernel<bf16_t>), dim3(256), dim3(256), 0, 0, dw, pw, C, C, k, (int64_t)C * k, (int64_t)k,
+                           (int64_t)1, 1, k, 0, 0, mtiles);
+        CK(hipDeviceSynchronize());
+        cv[b] = Conv{pw, db, k, dil, (k - 1) / 2 * dil};
+        HW[b] = hw; HB[b] = hb;
+    }
+    TapGemmArgs a; memset(&a, 0, sizeof(a));
+    a.ldx = ld; a.n_in = N; a.cin = C; a.cout = C; a.mtiles = mtiles; a.nphase = 1; a.tu = 0; a.omul = 1;
+    a.in_slope = 0.1f; a.ld_res = ld; a.scale = 1.f; a.ldy = ld; a.n_rows = N; a.nbranch = nbr > 1 ? nbr : 1;
+    a.X = X[0]; a.W = cv[0].w; a.bias = cv[0].bias; a.res = R[0]; a.Y = Y[0]; a.ntaps = cv[0].k; a.tstep = dil; a.tpad = cv[0].pad;
+    a.X1 = X[1]; a.W1 = cv[1].w; a.bias1 = cv[1].bias; a.res1 = R[1]; a.Y1 = Y[1]; a.ntaps1 = cv[1].k; a.tstep1 = dil; a.tpad1 = cv[1].pad;
+    a.X2 = X[2]; a.W2 = cv[2].w; a.bias2 = cv[2].bias; a.res2 = R[2]; a.Y2 = Y[2]; a.ntaps2 = cv[2].k; a.tstep2 = dil; a.tpad2 = cv[2].pad;
+    const int span = 10 * dil;
+    const size_t ny = hx.size();
+    printf("C=%d N=%d branches=%d\n", C, N, nbr);
+    run<1, 1, 256, 1, 1, 4>("ref 1x1 kc256", a, C, N, span, reps, nullptr, ny, nbr);
+    std::vector<bf16_t> yref(ny);
+    CK(hipMemcpy(yref.data(), Y[0], ny * 2, hipMemcpyDeviceToHost));
+    std::vector<bf16_t> yr[3]; bf16_t* yrp[3];
+    for (int b = 0; b < 3; ++b) { yr[b].resize(ny); CK(hipMemcpy(yr[b].data(), Y[b], ny * 2, hipMemcpyDeviceToHost)); yrp[b] = yr[b].data(); CK(hipMemset(Y[b], 0, ny * 2)); }
+    {   // pin the reference itself against a direct CPU evaluation of sampled outputs
+        auto bf = [](bf16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; };
+        auto rnd = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; float r; memcpy(&r, &u, 4); return r; };
+        double worst = 0;
+        for (int b = 0; b < 3; ++b) {
+            const int k = ks[b], pad = (k - 1) / 2 * dil;
+            for (int s = 0; s < 300; ++s) {
+                const int n = (s < 20) ? s : (s < 40 ? N - 1 - (s - 20) : rand() % N);
+                const int m = rand() % C;
+                double acc = 0;
+                for (int t = 0; t < k; ++t) {
+                    const int r = n + t * dil - pad;
+                    if (r < 0 || r >= N) continue;
+                    for (int c = 0; c < C; ++c) {
+                        float x = bf(hx[(size_t)r * ld + c]);
+                        x = rnd(x >= 0 ? x : x * 0.1f);
+                        acc += (double)rnd(HW[b][((size_t)m * C + c) * k + t]) * x;
+                    }
+                }
+                const float want = (float)acc + HB[b][m] + bf(hx[(size_t)n * ld + m]);
+                const float got = bf(yr[b][(size_t)n * ld + m]);
+                worst = std::max(worst, (double)fabsf(want - got) / (1.0 + fabsf(want)));
+            }
+        }
+        printf("reference vs CPU (sampled, relative): %.3g\n", worst);
+    }
+    WConvArgs w; memset(&w, 0, sizeof(w));
+    w.X0 = X[0]; w.X1 = X[1]; w.X2 = X[2];
+    w.W0 = (const uint4*)cv[0].w; w.W1 = (const uint4*)cv[1].w; w.W2 = (const uint4*)cv[2].w;
+    w.b0 = cv[0].bias; w.b1 = cv[1].bias; w.b2 = cv[2].bias;
+    w.R0 = R[0]; w.R1 = R[1]; w.R2 = R[2];
+    w.Y0 = Y[0]; w.Y1 = Y[1]; w.Y2 = Y[2];
+    w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
+    w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
+    for (int nblk : {256, 512, 768})
+      for (double ovh : {3.0, 8.0, 14.0, 25.0, 50.0, 100.0}) {
+        if (C == 128 && nblk == 256) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, nblk, ovh);
+        if (C == 64 && nblk < 768) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, nblk, ovh);
+        if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, nblk, ovh);
+        if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, nblk, ovh);
+    }
+    return 0;
+}
