@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -17,6 +18,7 @@
 #include "t2s_prefill.h"
 #include "tapgemm.h"
 #include "wconv.h"
+#include "flowfuse.h"
 #include "voc_kernels.h"
 
 using namespace gsv;
@@ -794,6 +796,9 @@ int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream) {
 struct VocFlow {
     PackedConv pre, cond, post;      // post packed NEGATED: x1 + (-(W out + b)) in the epilogue
     PackedConv in_l[4], rs_res[3], rs_skip[4];
+    void* ff_w = nullptr;            // flowfuse.h weight arena (bf16 mode, hidden 192 / half 96 only)
+    float* ff_b = nullptr;           // flowfuse.h bias arena
+    int parity = 0;                  // 1: this layer sees the tensor channel-reversed (odd number of Flips before it)
 };
 struct VocResBlock {
     PackedConv c1[3], c2[3];
@@ -811,6 +816,8 @@ struct gsv_voc {
     bool finalized = false;
     std::vector<VocFlow> flows;
     PackedConv conv_pre, cond, conv_post;
+    PackedConv cond_all;             // every flow's cond_layer stacked: one launch for the whole flow
+    bool fused_flow = false;
     std::vector<VocStage> stages;
     int total_up = 1;
     int max_stage_elems_per_frame = 0;  // max over stages of ld(C) * time multiplier
@@ -842,7 +849,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.a = take(sizeof(AT) * (size_t)T * 2 * H);
     w.acts = take(sizeof(AT) * (size_t)T * H);
     w.ge_cl = take(sizeof(AT) * (size_t)Tg * c.gin_channels);
-    w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H);
+    w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H * std::max(1, c.n_flows));
     w.condbuf = (float*)take(sizeof(float) * (size_t)Tg * c.upsample_initial_channel);
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
     for (int i = 0; i < 11; ++i) w.st[i] = take(sizeof(AT) * se);
@@ -856,6 +863,38 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
     const int H = c.hidden_channels, C = c.inter_channels, half = C / 2;
     AT* x = (AT*)w.zin;
     AT* xf = (AT*)w.zflip;
+    if (v->fused_flow && sizeof(AT) == 2) {
+        // one launch for every flow's conditioning, then one fused kernel per coupling layer; no Flip passes
+        const int ldg_all = 8 * H * c.n_flows;
+        Epi ec;
+        if (int rc = run_conv<AT, AT, float>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, Tg, ec, st)) return rc;
+        HIPCHK(hipFuncSetAttribute((const void*)flowfuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS_TOTAL));
+        for (int f = c.n_flows - 1; f >= 0; --f) {
+            VocFlow& F = v->flows[f];
+            FlowFuseArgs a;
+            a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
+            a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
+            a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
+            const int nt = cdiv(T, FF_VR), nx = std::min(8, cdiv(nt, 32));
+            a.per_xcd = cdiv(nt, nx);
+            a.dbg = nullptr;
+            static const bool ff_debug = getenv("GSV_FF_DEBUG") != nullptr;
+            long long* dbg = nullptr;
+            if (ff_debug) { HIPCHK(hipMalloc(&dbg, 32 * sizeof(long long))); HIPCHK(hipMemset(dbg, 0, 32 * sizeof(long long))); a.dbg = dbg; }
+            hipLaunchKernelGGL(flowfuse_kernel, dim3(8 * a.per_xcd), dim3(256), FF_LDS_TOTAL, st, a);
+            if (ff_debug) {
+                long long h[32];
+                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[flowfuse f=%d]", f);
+                for (int i = 1; i < 32 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+                fprintf(stderr, "\n");
+                (void)hipFree(dbg);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    }
     const int ew = std::min(2048, cdiv(T * H, 256));
     for (int f = c.n_flows - 1; f >= 0; --f) {
         VocFlow& F = v->flows[f];
@@ -1001,18 +1040,57 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
     };
     int rc = GSV_OK;
     v->flows.resize(c.n_flows);
+    // the fused coupling-layer kernel (flowfuse.h): bf16, hidden 192, 96 + 96 channels, even flow count
+    const bool fuse = sizeof(CT) == 2 && H == FF_H && half == FF_HALF && c.n_flows % 2 == 0 && c.n_flows > 0;
+    float* cond_w_all = nullptr;
+    float* cond_b_all = nullptr;
+    float* skip_b = nullptr;   // the four skip biases of the layer being packed (stream-ordered reuse)
+    if (fuse) {
+        HIPCHK(hipMalloc(&cond_w_all, sizeof(float) * (size_t)c.n_flows * 8 * H * gin));
+        HIPCHK(hipMalloc(&cond_b_all, sizeof(float) * (size_t)c.n_flows * 8 * H));
+        temps.push_back(cond_w_all); temps.push_back(cond_b_all);
+        HIPCHK(hipMalloc(&skip_b, sizeof(float) * 4 * FF_H));
+        temps.push_back(skip_b);
+    }
+    // pack one conv of a fused layer into its weight arena at fragment offset `frag`
+    auto ff_pack = [&](VocFlow& F, int frag, const float* src, int cout, int cin, int k, int64_t sm, int64_t sc, int64_t sk, int pad) {
+        const int mt = cdiv(cout, 32);
+        const size_t elems = (size_t)k * mt * (cin / 16) * 64 * 8;
+        hipLaunchKernelGGL((tapgemm_pack_kernel<bf16_t>), dim3((unsigned)std::min<size_t>(2048, (elems + 255) / 256)), dim3(256), 0, st,
+                           src, (bf16_t*)F.ff_w + (size_t)frag * 512, cout, cin, k, sm, sc, sk, 1, k, 0, pad, mt);
+    };
+    auto ff_bias = [&](VocFlow& F, int off, const float* src, int n, float scale, bool reverse) {
+        hipLaunchKernelGGL(scale_copy_rev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, F.ff_b + off, n, scale, reverse ? 1 : 0);
+    };
     for (int f = 0; f < c.n_flows && !rc; ++f) {
         VocFlow& F = v->flows[f];
         const std::string p = "flow.flows." + std::to_string(2 * f) + ".";
         const float *w, *b;
+        F.parity = (c.n_flows - f) % 2;
+        if (fuse) {
+            if (!F.ff_w) HIPCHK(hipMalloc(&F.ff_w, (size_t)FF_W_TOTAL * 1024));
+            if (!F.ff_b) HIPCHK(hipMalloc(&F.ff_b, sizeof(float) * FF_T_TOTAL));
+        }
         if ((rc = get(p + "pre.weight", (int64_t)H * half, &w)) || (rc = get(p + "pre.bias", H, &b))) break;
         if ((rc = pack_conv<CT>(F.pre, w, H, half, 1, half, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+        if (fuse) {   // parity 1: the conv-input half is stored channel-reversed
+            ff_pack(F, FF_W_PRE, F.parity ? w + (half - 1) : w, H, half, 1, half, F.parity ? -1 : 1, 0, 0);
+            ff_bias(F, FF_T_PRE, b, H, 1.f, false);
+        }
         if ((rc = folded(p + "enc.cond_layer", 8 * H, gin, 1.f, &w)) || (rc = get(p + "enc.cond_layer.bias", 8 * H, &b))) break;
         if ((rc = pack_conv<CT>(F.cond, w, 8 * H, gin, 1, gin, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+        if (fuse) {
+            HIPCHK(hipMemcpyAsync(cond_w_all + (size_t)f * 8 * H * gin, w, sizeof(float) * (size_t)8 * H * gin, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(cond_b_all + (size_t)f * 8 * H, b, sizeof(float) * 8 * H, hipMemcpyDeviceToDevice, st));
+        }
         for (int l = 0; l < 4 && !rc; ++l) {
             const std::string il = p + "enc.in_layers." + std::to_string(l), rl = p + "enc.res_skip_layers." + std::to_string(l);
             if ((rc = folded(il, 2 * H, H * 5, 1.f, &w)) || (rc = get(il + ".bias", 2 * H, &b))) break;
             if ((rc = pack_conv<CT>(F.in_l[l], w, 2 * H, H, 5, (int64_t)H * 5, 5, 1, 1, 2, 0, b, 1.f, st))) break;
+            if (fuse) {
+                ff_pack(F, FF_W_IN + l * FF_W_IN_L, w, 2 * H, H, 5, (int64_t)H * 5, 5, 1, 2);
+                ff_bias(F, FF_T_IN + l * 384, b, 2 * H, 1.f, false);
+            }
             const int R = l < 3 ? 2 * H : H;
             if ((rc = folded(rl, R, H, 1.f, &w)) || (rc = get(rl + ".bias", R, &b))) break;
             if (l < 3) {
@@ -1020,6 +1098,15 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
                 if ((rc = pack_conv<CT>(F.rs_skip[l], w + (size_t)H * H, H, H, 1, H, 1, 0, 1, 0, 0, b + H, 1.f, st))) break;
             } else {
                 if ((rc = pack_conv<CT>(F.rs_skip[l], w, H, H, 1, H, 1, 0, 1, 0, 0, b, 1.f, st))) break;
+            }
+            if (fuse) {
+                if (l < 3) {
+                    ff_pack(F, FF_W_RES + l * 6 * FF_KSH, w, H, H, 1, H, 1, 0, 0);
+                    ff_bias(F, FF_T_RES + l * 192, b, H, 1.f, false);
+                }
+                ff_pack(F, FF_W_SKIP + l * 6 * FF_KSH, l < 3 ? w + (size_t)H * H : w, H, H, 1, H, 1, 0, 0);
+                hipLaunchKernelGGL(scale_copy_rev_kernel, dim3(1), dim3(256), 0, st, l < 3 ? b + H : b, skip_b + l * 192, H, 1.f, 0);
+                if (l == 3) hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(256), 0, st, (const float*)skip_b, F.ff_b + FF_T_SKIP, H);
             }
         }
         if (rc) break;
@@ -1029,7 +1116,16 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
         temps.push_back(neg);
         hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(half * H, 256)), dim3(256), 0, st, w, neg, (size_t)half * H, -1.0f);
         if ((rc = pack_conv<CT>(F.post, neg, half, H, 1, H, 1, 0, 1, 0, 0, b, -1.f, st))) break;
+        if (fuse) {   // parity 1: the updated half is stored channel-reversed -> reversed output rows and bias
+            ff_pack(F, FF_W_POST, F.parity ? neg + (size_t)(half - 1) * H : neg, half, H, 1, F.parity ? -(int64_t)H : (int64_t)H, 1, 0, 0);
+            ff_bias(F, FF_T_POST, b, half, -1.f, F.parity != 0);
+        }
     }
+    if (!rc && fuse) {
+        free_conv(v->cond_all);
+        rc = pack_conv<CT>(v->cond_all, cond_w_all, c.n_flows * 8 * H, gin, 1, gin, 1, 0, 1, 0, 0, cond_b_all, 1.f, st);
+    }
+    v->fused_flow = fuse && !rc;
     const int C0 = c.upsample_initial_channel;
     const float *w = nullptr, *b = nullptr;
     if (!rc) rc = get("dec.conv_pre.weight", (int64_t)C0 * C * 7, &w);
@@ -1111,11 +1207,14 @@ void voc_free(gsv_voc* v) {
     v->staged.clear();
     for (VocFlow& F : v->flows) {
         free_conv(F.pre); free_conv(F.cond); free_conv(F.post);
+        if (F.ff_w) (void)hipFree(F.ff_w);
+        if (F.ff_b) (void)hipFree(F.ff_b);
+        F.ff_w = nullptr; F.ff_b = nullptr;
         for (auto& p : F.in_l) free_conv(p);
         for (auto& p : F.rs_res) free_conv(p);
         for (auto& p : F.rs_skip) free_conv(p);
     }
-    free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post);
+    free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post); free_conv(v->cond_all);
     for (VocStage& s : v->stages) {
         free_conv(s.up);
         for (VocResBlock& r : s.rb)

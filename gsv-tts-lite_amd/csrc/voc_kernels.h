@@ -100,6 +100,18 @@ __global__ void scale_copy_kernel(const float* __restrict__ src, float* __restri
         dst[i] = src[i] * s;
 }
 
+// dst[i] = s * src[i]  or, reversed, s * src[n-1-i]
+__global__ void scale_copy_rev_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float s, int reverse) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = s * src[reverse ? n - 1 - i : i];
+}
+
+// dst[c] = (t[c] + t[n+c]) + (t[2n+c] + t[3n+c])
+__global__ void sum4_kernel(const float* __restrict__ t, float* __restrict__ dst, int n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) dst[c] = (t[c] + t[n + c]) + (t[2 * n + c] + t[3 * n + c]);
+}
+
 template <typename WT>
 __global__ void convert_kernel(const float* __restrict__ src, WT* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

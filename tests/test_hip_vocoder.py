@@ -93,3 +93,38 @@ def test_flow_dec_bf16_bounded(golden_dir, dev, ver, T, tag):
     err = np.abs(o - ref)
     assert np.isfinite(o).all()
     assert err.max() < 8e-2 and err.mean() < 8e-3, (err.max(), err.mean())
+
+
+def test_flow_bf16_fused_vs_oracle_ragged(dev):
+    """The bf16 flow runs the fused coupling-layer kernel (csrc/flowfuse.h): one tile, several tiles,
+    lengths that are not multiples of the 48-row tile, a tail masked to zero, broadcast and per-frame
+    conditioning -- against the fp32 oracle flow.  Tolerance = bf16 activations (8 mantissa bits)
+    through 16 gated layers; masked rows must come back exactly zero."""
+    from oracle import oracle as orc
+    v, hps, w = _voc("v2Pro", 11, torch.bfloat16, dev)
+    vo = orc.VocoderOracle(hps, w)
+    for T, per_frame in [(1, False), (37, False), (48, True), (49, False), (131, True), (500, False)]:
+        z = synth.hashed_uniform("ff.z%d" % T, (1, 192, T), 11) * np.float32(1.3)
+        mask = np.ones(T, np.float32)
+        if T > 20:
+            mask[T - 9:] = 0
+        ge = synth.synth_ge(3, 1024, 11)
+        if per_frame:
+            ge = np.concatenate([np.repeat(synth.synth_ge(i, 1024, 11), n, axis=2) for i, n in ((3, 20), (4, T - 20))], axis=2)
+        ref = vo.flow(z[0], mask, ge[0])
+        out = v.flow(_T(z, dev), _T(mask, dev).reshape(1, 1, T), _T(ge, dev))[0].cpu().numpy()
+        assert out.shape == ref.shape and np.isfinite(out).all()
+        err = np.abs(out - ref)
+        assert err.max() < 6e-2 and err.mean() < 6e-3, (T, err.max(), err.mean())
+        if T > 20:
+            assert np.abs(out[:, T - 9:]).max() == 0.0
+
+
+@pytest.mark.parametrize("ver,T,tag", CASES[:2])
+def test_flow_bf16_fused_matches_reference_golden(golden_dir, dev, ver, T, tag):
+    g = np.load(os.path.join(golden_dir, "vocoder.npz"))
+    v, _, _ = _voc(ver, int(g["seed"]), torch.bfloat16, dev)
+    name = "%s_T%d_%s" % (ver, T, tag)
+    zf = v.flow(_T(g[name + "_z"], dev), torch.ones(1, 1, T, device=dev), _T(g[name + "_ge"], dev)).cpu().numpy()
+    err = np.abs(zf - g[name + "_flow"])
+    assert err.max() < 6e-2 and err.mean() < 6e-3, (err.max(), err.mean())
