@@ -83,6 +83,9 @@ template <typename WT> struct Geo {
 };
 
 __device__ __forceinline__ raw16 ldg16(const void* p) { return *reinterpret_cast<const raw16*>(p); }
+// Weight loads keep the DEFAULT cache policy: measured on MI355X, the non-temporal hint (global_load ... nt)
+// made the bs=1 step 10 % slower (0.404 vs 0.370 ms/token) -- the 152 MB weight set lives in the 256 MiB
+// Infinity Cache between tokens and nt lines are not retained there.
 
 // dot of one lane's slice of a 512-wide weight row (CPR chunks) with the lane's activations.
 // bf16: lane owns x[lane*8 .. +7]; f32: chunks c=0,1 own x[c*256 + lane*4 .. +3].
