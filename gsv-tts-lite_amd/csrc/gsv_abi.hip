@@ -513,6 +513,12 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     const size_t lds = sizeof(float) * ((size_t)l_max * 33 + (size_t)l_max * 32 + 4 * (size_t)l_max + 128 + 8);
     if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
     HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nkt_max = cdiv(l_max, 32);
+    const size_t lds_mfma = (size_t)nkt_max * 32 * 80 + 128 * 80 + (size_t)32 * (nkt_max * 64 + 16);
+    if (sizeof(WT) == 2) {
+        if (lds_mfma > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
+        HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
+    }
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
         Epi e0;
@@ -521,7 +527,15 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
         pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
         pa.T = T; pa.slot0 = slot0; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
-        hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
+        if constexpr (sizeof(WT) == 2) {   // bf16 cache: flash attention on the matrix cores
+            PrefillAttnMfmaArgs pm;
+            pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
+            pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
+            pm.T = T; pm.slot0 = slot0; pm.l_max = l_max; pm.out = attn;
+            hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
+        } else {
+            hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
+        }
         Epi e1; e1.res = xy; e1.ld_res = kD;
         // out_proj bias lives in the decode copy (L.bo); tapgemm bias pointer set per call
         PackedConv go = L.g_out; go.bias = L.bo;

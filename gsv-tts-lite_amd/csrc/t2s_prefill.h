@@ -5,6 +5,7 @@
 // t2s_model.py:335-347,365-381; embeddings t2s_model.py:322-331,353-361.
 #pragma once
 #include "t2s_decode.h"
+#include "tapgemm.h"
 
 namespace gsv {
 
@@ -142,6 +143,153 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_kernel(PrefillAttnArgs<W
         acc += __shfl_xor(acc, 32, 64);
         if (lane < 32) o[lane] = acc;
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same prompt attention on the matrix cores (bf16 cache mode).  One block = (head, sequence, group of
+// 4 query tiles); a wave owns one 32-query tile and runs flash attention over 32-key tiles:
+//   S^T = K Q^T      A = K tile [32 keys][32 d] (2 k-steps), B = Q tile -> D: lane = query, registers = keys
+//   online softmax   per lane over its 16 key registers, the two lane halves of a query combined per tile
+//   O^T += V^T P^T   the probabilities go from D registers to the B operand WITHOUT a shuffle: a
+//                    contraction may enumerate its index in any order, so V^T is staged in LDS with its
+//                    keys permuted into the order the D registers hold them (vpos below).
+// K, V and the scores' Q are rounded to bf16 (what the cache stores / what SDPA does in bf16); softmax
+// statistics and accumulation are fp32.  Masking as t2s_prefill_attn_kernel (appendix A.3).
+struct PrefillAttnMfmaArgs {
+    const float* qkv;    // [nrows][l_max][1536]
+    const int64_t* x_lens;
+    const int64_t* y_lens;
+    bf16_t* kc;          // this layer: [B][16][T][32]
+    bf16_t* vc;
+    int T, slot0, l_max;
+    float* out;          // [nrows][l_max][512]
+};
+
+// position of tile-local key kk inside its 32-key group of the permuted V^T row
+__device__ __forceinline__ int vpos(int kk) {
+    const int hf = (kk >> 2) & 1, blk = kk >> 3;
+    return (blk >> 1) * 16 + 8 * hf + (kk & 3) + 4 * (blk & 1);
+}
+
+__global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnMfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    const int h = blockIdx.x, r = blockIdx.y, qg = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int lx = (int)a.x_lens[r], L = lx + (int)a.y_lens[r];
+    const int q0 = (qg * 4 + wid) * 32;                      // first query of the wave's tile
+    const int qb0 = qg * 128;                                // first query of the block
+    if (qb0 >= a.l_max) return;
+    // keys the block can see: text queries see [0, lx), audio query i sees [0, i]
+    const int qlast = min(qb0 + 128, L) - 1;
+    const int nkeys = qlast < 0 ? 0 : (qlast < lx ? lx : max(lx, qlast + 1));
+    const int nkt = (nkeys + 31) / 32;                       // key tiles staged
+    constexpr int KRS = 32 * 2 + 16;                         // K / Q row stride (bytes)
+    const int vrs = nkt * 64 + 16;                           // V^T row stride (bytes)
+    unsigned char* Ks = plds;                                // [nkt*32][KRS]
+    unsigned char* Qs = Ks + (size_t)nkt * 32 * KRS;         // [128][KRS]
+    unsigned char* Vt = Qs + 128 * KRS;                      // [32 d][vrs]
+    const float* base = a.qkv + (size_t)r * a.l_max * 1536;
+    bf16_t* Kp = a.kc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
+    bf16_t* Vp = a.vc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
+    // ---- stage K (rows), V (transposed, permuted), Q (rows): one float4 of 4 d per item
+    for (int e = tid; e < nkt * 32 * 8; e += 256) {
+        const int t = e >> 3, d4 = (e & 7) * 4;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (t < L) {
+            kv = *reinterpret_cast<const f32x4*>(base + (size_t)t * 1536 + 512 + h * 32 + d4);
+            vv = *reinterpret_cast<const f32x4*>(base + (size_t)t * 1536 + 1024 + h * 32 + d4);
+        }
+        uint2 kp, vp;
+        kp.x = pack_bf16x2(kv[0], kv[1]); kp.y = pack_bf16x2(kv[2], kv[3]);
+        vp.x = pack_bf16x2(vv[0], vv[1]); vp.y = pack_bf16x2(vv[2], vv[3]);
+        *reinterpret_cast<uint2*>(Ks + (size_t)t * KRS + d4 * 2) = kp;
+        const int pos = (t & ~31) + vpos(t & 31);
+        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 0) * vrs + pos * 2) = (bf16_t)(vp.x & 0xffff);
+        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 1) * vrs + pos * 2) = (bf16_t)(vp.x >> 16);
+        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 2) * vrs + pos * 2) = (bf16_t)(vp.y & 0xffff);
+        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 3) * vrs + pos * 2) = (bf16_t)(vp.y >> 16);
+        if (t >= qb0 && t < qb0 + 128 && t < L && t < a.T) {   // each block writes the cache rows of its own queries: once each
+            *reinterpret_cast<uint2*>(Kp + (size_t)t * kDh + d4) = kp;
+            *reinterpret_cast<uint2*>(Vp + (size_t)t * kDh + d4) = vp;
+        }
+    }
+    for (int e = tid; e < 128 * 8; e += 256) {
+        const int qi = e >> 3, d4 = (e & 7) * 4;
+        const int i = qb0 + qi;
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if (i < L) qv = *reinterpret_cast<const f32x4*>(base + (size_t)i * 1536 + h * 32 + d4);
+        uint2 qp;
+        qp.x = pack_bf16x2(qv[0], qv[1]); qp.y = pack_bf16x2(qv[2], qv[3]);
+        *reinterpret_cast<uint2*>(Qs + (size_t)qi * KRS + d4 * 2) = qp;
+    }
+    __syncthreads();
+    if (q0 >= a.l_max) return;
+    const int i = q0 + j;                                    // this lane's query
+    const bool qvalid = i < L;
+    const int klim = !qvalid ? 0 : (i < lx ? lx : i + 1);    // keys [0, klim) visible
+    // the wave's key tiles: up to the last query of its tile
+    const int wq_last = min(q0 + 31, L - 1);
+    const int wkeys = wq_last < 0 ? 0 : (wq_last < lx ? lx : max(lx, wq_last + 1));
+    const int wkt = (wkeys + 31) / 32;
+    const float scale = 0.17677669529663687f * 1.4426950408889634f;   // 1/sqrt(32) in the exp2 domain
+    u32x4 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = *reinterpret_cast<const u32x4*>(Qs + (size_t)(wid * 32 + j) * KRS + s * 32 + hf * 16);
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[q] = 0.f;
+    float m = -1e30f, l = 0.f;
+    for (int kt = 0; kt < wkt; ++kt) {
+        f32x16 s;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + (size_t)(kt * 32 + j) * KRS + ks * 32 + hf * 16);
+            Mma<bf16_t>::run(s, kf, qf[ks]);
+        }
+        // mask + tile max (register q holds key kt*32 + (q&3) + 8*(q>>2) + 4*hf)
+        float tm = -1e30f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+            s[q] = key < klim ? s[q] * scale : -1e30f;
+            tm = fmaxf(tm, s[q]);
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+        float p[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            p[q] = s[q] > -1e29f ? __builtin_amdgcn_exp2f(s[q] - mn) : 0.f;
+            ps += p[q];
+        }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[q] *= alpha;
+        // O^T += V^T P^T : k-step ks uses registers 8ks .. 8ks+7 as the lane's 8 contraction elements
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[e] = pack_bf16x2(p[8 * ks + 2 * e], p[8 * ks + 2 * e + 1]);
+            const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (size_t)j * vrs + (kt * 32 + ks * 16 + hf * 8) * 2);
+            Mma<bf16_t>::run(o, vf, pf);
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = qvalid && l > 0.f ? 1.0f / l : 0.f;
+    if (i < a.l_max) {
+        float* op = a.out + ((size_t)r * a.l_max + i) * kD + h * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hf) = v;
+        }
     }
 }
 

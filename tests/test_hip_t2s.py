@@ -262,3 +262,30 @@ def test_megastep_handoffs_under_uneven_load(dev):
     for a_, b_ in zip(pred, rref):
         assert np.array_equal(a_.cpu().numpy(), b_)
     assert not m.megastep_error()
+
+
+def test_prefill_bf16_mfma_attention_packed_batch_and_cache(golden_dir, dev):
+    """bf16 mode runs the prompt attention on the matrix cores (t2s_prefill_attn_mfma_kernel): packed ragged
+    batch [x_b | y_b | pad] against the reference's golden hidden states, K/V cache rows written for every
+    prompt position (and only those), finite everywhere incl. the padded rows.  Lengths of the fixture
+    are not multiples of the 32-key / 128-query tiles."""
+    g = np.load(os.path.join(golden_dir, "t2s_layers.npz"))
+    cfg = synth.gpt_config(n_layer=3)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=int(g["seed"])), [(1, 96), (2, 96)], torch.bfloat16, dev)
+    x, y, bert = g["s_x"], g["s_y"], g["s_bert"]
+    L = len(x) + len(y)
+    m._rt[1]["k"].fill_(7.0); m._rt[1]["v"].fill_(7.0)
+    xy, xl, yl, _, _ = m.embed_prompt([_T(x, dev)], [_T(y, dev)], [_T(bert, dev)])
+    m.prefill(1, 0, xy, xl, yl)
+    assert np.abs(xy.cpu().numpy() - g["s_hidden"]).max() < 5e-2
+    k = m._rt[1]["k"].float().cpu().numpy(); v = m._rt[1]["v"].float().cpu().numpy()
+    assert np.abs(k[:, 0, :, :L] - g["s_k"]).max() < 5e-2 and np.abs(v[:, 0, :, :L] - g["s_v"]).max() < 5e-2
+    assert (k[:, 0, :, L:] == 7.0).all() and (v[:, 0, :, L:] == 7.0).all(), "cache rows beyond the prompt were touched"
+    xs = [g["b0_x"], g["b1_x"]]; ys = [g["b0_y"], g["b1_y"]]; bs = [g["b0_bert"], g["b1_bert"]]
+    xy, xl, yl, _, _ = m.embed_prompt([_T(a, dev) for a in xs], [_T(a, dev) for a in ys], [_T(a, dev) for a in bs])
+    m.prefill(2, 0, xy, xl, yl)
+    h = xy.cpu().numpy()
+    assert np.isfinite(h).all()
+    for b in range(2):
+        n = len(xs[b]) + len(ys[b])
+        assert np.abs(h[b, :n] - g["b_hidden"][b, :n]).max() < 5e-2, b
