@@ -519,35 +519,67 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         if (lds_mfma > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
         HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
     }
-    for (int l = 0; l < h->cfg.n_layer; ++l) {
-        T2SLayer& L = h->layers[l];
-        Epi e0;
-        if (int rc = run_conv<float, WT, float>(L.g_qkv, xy, kD, M, qkv, 3 * kD, M, e0, st)) return rc;
-        PrefillAttnArgs<WT> pa;
-        pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
-        pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-        pa.T = T; pa.slot0 = slot0; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
-        if constexpr (sizeof(WT) == 2) {   // bf16 cache: flash attention on the matrix cores
+    if constexpr (sizeof(WT) == 2) {
+        // bf16 mode: latency-shaped GEMMs (rowgemm_kernel), flash attention on the matrix cores, and
+        // bias + residual + LayerNorm in the consumer of the raw (split) GEMM tiles
+        const int rtiles = cdiv(M, 32);
+        bf16_t* fb16 = (bf16_t*)fbuf;                    // FFN hidden as bf16: the GEMM's operand type anyway
+        float* part = qkv;                               // W2 split partials reuse qkv + attn (dead by then): [4][M][512]
+        auto gemm = [&](auto kern, const void* X, int ldx, const PackedConv& pc, const float* bias, int relu, void* Y, int ldy,
+                        int nsplit, size_t split_stride) {
+            RowGemmArgs ra;
+            ra.X = X; ra.ldx = ldx; ra.M = M; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.bias = bias; ra.relu = relu;
+            ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
+            hipLaunchKernelGGL(kern, dim3(rtiles, pc.mtiles, nsplit), dim3(256), 0, st, ra);
+        };
+        for (int l = 0; l < h->cfg.n_layer; ++l) {
+            T2SLayer& L = h->layers[l];
+            gemm(rowgemm_kernel<float, float>, xy, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
             PrefillAttnMfmaArgs pm;
             pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
             pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
             pm.T = T; pm.slot0 = slot0; pm.l_max = l_max; pm.out = attn;
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
-        } else {
-            hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
+            gemm(rowgemm_kernel<float, float>, attn, kD, L.g_out, nullptr, 0, ybuf, kD, 1, 0);
+            hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)ybuf, 1, (size_t)0, (const float*)L.bo,
+                               (const float*)xy, (const float*)L.ln1g, (const float*)L.ln1b, xy, M);
+            gemm(rowgemm_kernel<float, bf16_t>, xy, kD, L.g_w1, L.b1, 1, fb16, kF, 1, 0);
+            gemm(rowgemm_kernel<bf16_t, float>, fb16, kF, L.g_w2, nullptr, 0, part, kD, 4, (size_t)M * kD);
+            hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)part, 4, (size_t)M * kD, (const float*)L.b2,
+                               (const float*)xy, (const float*)L.ln2g, (const float*)L.ln2b, xy, M);
         }
-        Epi e1; e1.res = xy; e1.ld_res = kD;
-        // out_proj bias lives in the decode copy (L.bo); tapgemm bias pointer set per call
-        PackedConv go = L.g_out; go.bias = L.bo;
-        if (int rc = run_conv<float, WT, float>(go, attn, kD, M, ybuf, kD, M, e1, st)) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln1g, L.ln1b, xy, M);
-        Epi e2; e2.act = ACT_RELU;
-        PackedConv g1 = L.g_w1; g1.bias = L.b1;
-        if (int rc = run_conv<float, WT, float>(g1, xy, kD, M, fbuf, kF, M, e2, st)) return rc;
-        Epi e3; e3.res = xy; e3.ld_res = kD;
-        PackedConv g2 = L.g_w2; g2.bias = L.b2;
-        if (int rc = run_conv<float, WT, float>(g2, fbuf, kF, M, ybuf, kD, M, e3, st)) return rc;
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln2g, L.ln2b, xy, M);
+        HIPCHK(hipGetLastError());
+    } else {
+        for (int l = 0; l < h->cfg.n_layer; ++l) {
+            T2SLayer& L = h->layers[l];
+            Epi e0;
+            if (int rc = run_conv<float, WT, float>(L.g_qkv, xy, kD, M, qkv, 3 * kD, M, e0, st)) return rc;
+            PrefillAttnArgs<WT> pa;
+            pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
+            pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
+            pa.T = T; pa.slot0 = slot0; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
+            if constexpr (sizeof(WT) == 2) {   // bf16 cache: flash attention on the matrix cores
+                PrefillAttnMfmaArgs pm;
+                pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
+                pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
+                pm.T = T; pm.slot0 = slot0; pm.l_max = l_max; pm.out = attn;
+                hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
+            } else {
+                hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
+            }
+            Epi e1; e1.res = xy; e1.ld_res = kD;
+            // out_proj bias lives in the decode copy (L.bo); tapgemm bias pointer set per call
+            PackedConv go = L.g_out; go.bias = L.bo;
+            if (int rc = run_conv<float, WT, float>(go, attn, kD, M, ybuf, kD, M, e1, st)) return rc;
+            hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln1g, L.ln1b, xy, M);
+            Epi e2; e2.act = ACT_RELU;
+            PackedConv g1 = L.g_w1; g1.bias = L.b1;
+            if (int rc = run_conv<float, WT, float>(g1, xy, kD, M, fbuf, kF, M, e2, st)) return rc;
+            Epi e3; e3.res = xy; e3.ld_res = kD;
+            PackedConv g2 = L.g_w2; g2.bias = L.b2;
+            if (int rc = run_conv<float, WT, float>(g2, fbuf, kF, M, ybuf, kD, M, e3, st)) return rc;
+            hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln2g, L.ln2b, xy, M);
+        }
     }
     PrefillFinishArgs fa;
     fa.hidden = xy; fa.x_lens = x_lens; fa.y_lens = y_lens; fa.hlast = hlast; fa.kv_len = s.kv_len; fa.x_len = s.x_len;

@@ -293,6 +293,137 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnM
     }
 }
 
+// ---- prompt GEMMs (bf16 weights): Y[M rows][N] = X[M][K] W^T for a few hundred rows ----------------
+// The generic LDS-staged kernel pays one exposed memory latency per 128-channel chunk (16 chunks for the
+// K = 2048 GEMM: 19 us).  Here nothing is staged: a block owns one 32x32 output tile of one K split, each
+// of its 4 waves takes 8 k-steps (128 channels) and has ALL of its operands in flight at once -- weight
+// fragments (packed as for tapgemm) and the X rows straight from global in B-fragment layout -- so a
+// block costs one memory latency, 8 MFMAs, an LDS reduction and a store.  Splits write raw partial
+// tiles; bias / residual / LayerNorm happen in ln_rows_sum_kernel, which reads them back.
+struct RowGemmArgs {
+    const void* X;        // [M][ldx], float or bf16
+    int ldx, M;
+    const uint4* W;       // fragments [mtile][ksteps][64 lanes]
+    int ksteps;           // K / 16
+    const float* bias;    // epilogue (only for nsplit == 1): + bias, ReLU
+    int relu;
+    void* Y;              // [nsplit][M][ldy], float or bf16
+    int ldy;
+    size_t split_stride;  // elements between the partial outputs of consecutive splits
+};
+
+template <typename XT, typename OT>
+__global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
+    constexpr int KPW = 8;                                  // k-steps per wave
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int rt = blockIdx.x, mt = blockIdx.y, sp = blockIdx.z;
+    const int row = min(rt * 32 + j, a.M - 1);
+    const int ks0 = (sp * 4 + wid) * KPW;
+    const uint4* wp = a.W + ((size_t)mt * a.ksteps + ks0) * 64 + lane;
+    u32x4 wf[KPW], xf[KPW];
+#pragma unroll
+    for (int s = 0; s < KPW; ++s) wf[s] = __builtin_bit_cast(u32x4, wp[(size_t)s * 64]);
+    if constexpr (sizeof(XT) == 2) {
+        const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.X) + (size_t)row * a.ldx + ks0 * 16 + hf * 8;
+#pragma unroll
+        for (int s = 0; s < KPW; ++s) xf[s] = *reinterpret_cast<const u32x4*>(xp + s * 16);
+    } else {
+        const float* xp = reinterpret_cast<const float*>(a.X) + (size_t)row * a.ldx + ks0 * 16 + hf * 8;
+        f32x4 lo[KPW], hi[KPW];
+#pragma unroll
+        for (int s = 0; s < KPW; ++s) {
+            lo[s] = *reinterpret_cast<const f32x4*>(xp + s * 16);
+            hi[s] = *reinterpret_cast<const f32x4*>(xp + s * 16 + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < KPW; ++s) {
+            xf[s][0] = pack_bf16x2(lo[s][0], lo[s][1]);
+            xf[s][1] = pack_bf16x2(lo[s][2], lo[s][3]);
+            xf[s][2] = pack_bf16x2(hi[s][0], hi[s][1]);
+            xf[s][3] = pack_bf16x2(hi[s][2], hi[s][3]);
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KPW; ++s) Mma<bf16_t>::run(acc, wf[s], xf[s]);
+    // the 4 waves' partial tiles are summed in wave order by wave 0
+    if (wid > 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wid - 1][q][lane] = acc[q];
+    }
+    __syncthreads();
+    if (wid > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += red[w][q][lane];
+    const int orow = rt * 32 + j;
+    if (orow >= a.M) return;
+    const int ch = mt * 32 + 16 * hf;                      // register q = channel ch + q (packer's row permutation)
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = acc[q] + (a.bias ? a.bias[ch + q] : 0.f);
+        if (a.relu) v[q] = fmaxf(v[q], 0.f);
+    }
+    if constexpr (sizeof(OT) == 2) {
+        bf16_t* yp = reinterpret_cast<bf16_t*>(a.Y) + (size_t)sp * a.split_stride + (size_t)orow * a.ldy + ch;
+        u32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oa[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            ob[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+        }
+        *reinterpret_cast<u32x4*>(yp) = oa;
+        *reinterpret_cast<u32x4*>(yp + 8) = ob;
+    } else {
+        float* yp = reinterpret_cast<float*>(a.Y) + (size_t)sp * a.split_stride + (size_t)orow * a.ldy + ch;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(yp + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    }
+}
+
+// y[row] = LayerNorm(sum_s P[s][row] + bias + res[row]) over 512 (post-LN block, t2s_model.py:55-63): the
+// consumer of rowgemm's raw (split) tiles; partials are added in split order, then bias, then the residual
+__global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
+                                                          const float* __restrict__ bias, const float* res,
+                                                          const float* __restrict__ g, const float* __restrict__ bta,
+                                                          float* y, int rows) {   // y may alias res (row-wise in place)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8], t[8];
+    Ld<float, 8>::load(P + (size_t)row * kD + lane * 8, v);
+    for (int s = 1; s < nsplit; ++s) {
+        Ld<float, 8>::load(P + (size_t)s * split_stride + (size_t)row * kD + lane * 8, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+    }
+    Ld<float, 8>::load(bias + lane * 8, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += t[i];
+    Ld<float, 8>::load(res + (size_t)row * kD + lane * 8, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += t[i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + kEps);
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = v[i] * rs * g[lane * 8 + i] + bta[lane * 8 + i];
+    *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+
 // hlast[r] = hidden[r][x_len + y_len - 1]; and per-slot state after a (re)fill
 struct PrefillFinishArgs {
     const float* hidden;  // [nrows][l_max][512]

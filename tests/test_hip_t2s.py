@@ -274,7 +274,8 @@ def test_prefill_bf16_mfma_attention_packed_batch_and_cache(golden_dir, dev):
     m = _model(cfg, synth.gpt_weights(cfg, seed=int(g["seed"])), [(1, 96), (2, 96)], torch.bfloat16, dev)
     x, y, bert = g["s_x"], g["s_y"], g["s_bert"]
     L = len(x) + len(y)
-    m._rt[1]["k"].fill_(7.0); m._rt[1]["v"].fill_(7.0)
+    with torch.inference_mode():
+        m._rt[1]["k"].fill_(7.0); m._rt[1]["v"].fill_(7.0)
     xy, xl, yl, _, _ = m.embed_prompt([_T(x, dev)], [_T(y, dev)], [_T(bert, dev)])
     m.prefill(1, 0, xy, xl, yl)
     assert np.abs(xy.cpu().numpy() - g["s_hidden"]).max() < 5e-2
