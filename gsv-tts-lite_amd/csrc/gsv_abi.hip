@@ -464,6 +464,7 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
     a.pre_tokens = s.pre_tokens; a.seen = s.seen; a.step = s.step; a.eos_at = s.eos_at; a.emb = h->emb_audio;
     a.pe = h->pe_audio; a.xcur = h->xcur; a.T = s.max_kv; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.n_pos = h->cfg.n_pos;
     a.advance = advance;
+    a.logits = s.logits; a.fctl = s.fctl;
     a.mega_cnt = h->mega_cnt; a.mega_n = 2 * h->cfg.n_layer;
     if (a.mega_n > 256) a.mega_cnt = nullptr;
     hipLaunchKernelGGL(t2s_token_kernel, dim3(s.batch), dim3(256), 0, st, a);

@@ -747,7 +747,40 @@ struct TokenArgs {
     int T, V, eos, n_pos, advance;
     unsigned* mega_cnt;      // [B][mega_n] hand-off counters of the persistent step, zeroed here (or null)
     int mega_n;
+    const float* logits;     // [B][V] penalised logits of the pending sample (device sampling, ctl[0] == 2)
+    const float* fctl;       // fctl[1] = temperature
 };
+
+// Counter-based uniform in (0, 1): one draw per (seed, slot, absolute position, vocabulary entry).  The
+// reference draws Exp(1) noise from torch's generator (GPT/utils.py:56-59); a device sampler cannot share
+// that stream, so it owns one: lowbias32 over a mix of the counters (documented in INTEGRATION.md).
+__device__ __forceinline__ float t2s_uniform(uint32_t seed_lo, uint32_t seed_hi, uint32_t slot, uint32_t pos, uint32_t step,
+                                             uint32_t v) {
+    uint32_t h = seed_lo ^ (v * 0x9E3779B1u) ^ (pos * 0x85EBCA77u) ^ (slot * 0xC2B2AE3Du) ^ (step * 0x27D4EB2Fu) ^
+                 ((seed_hi << 13) | (seed_hi >> 19));
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    h += seed_hi;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// block-wide (value, lowest index) argmax over 256 threads; every thread gets the winner
+__device__ __forceinline__ void t2s_block_argmax(float& v, int& idx, float* sv, int* si) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(v, m, 64);
+        const int oi = __shfl_xor(idx, m, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[w] = v; si[w] = idx; }
+    __syncthreads();
+    v = sv[0]; idx = si[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (sv[i] > v || (sv[i] == v && si[i] < idx)) { v = sv[i]; idx = si[i]; }
+}
 
 __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     __shared__ int s_tok;
@@ -755,9 +788,61 @@ __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     // re-initialise the persistent step's counters from the kernel that precedes it in the chain
     // (kernel->kernel ordering; a captured memset node was observed to race with the first replay)
     if (a.mega_cnt != nullptr && tid < a.mega_n) a.mega_cnt[(size_t)b * a.mega_n + tid] = 0u;
+    // ---- device sampling (ctl[0] == 2): temperature, top-k with the reference's tie rule, then the
+    // exponential race of GPT/utils.py:56-59 as a Gumbel argmax: argmax p/q, q ~ Exp(1)  ==  argmax (x - log q)
+    int sampled = -1;
+    if (a.ctl[0] == 2) {
+        __shared__ float sv[4];
+        __shared__ int si[4];
+        constexpr int NPT = 8;                           // vocabulary entries per thread (V <= 2048)
+        const float invt = 1.0f / fmaxf(a.fctl[1], 1e-5f);
+        float x[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int v = tid + 256 * i;
+            x[i] = v < a.V ? a.logits[(size_t)b * a.V + v] * invt : -INFINITY;
+        }
+        const int k = a.ctl[4];
+        float pivot = -INFINITY, top = -INFINITY;
+        if (k > 0 && k < a.V) {
+            unsigned removed = 0u;                       // k rounds: take out one maximum per round (duplicates count)
+            for (int r = 0; r < k; ++r) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i)
+                    if (!((removed >> i) & 1u) && (x[i] > bv || (x[i] == bv && tid + 256 * i < bi))) { bv = x[i]; bi = tid + 256 * i; }
+                t2s_block_argmax(bv, bi, sv, si);
+                if (bi < 0x7fffffff && (bi & 255) == tid) removed |= 1u << (bi >> 8);
+                if (r == 0) top = bv;
+                pivot = bv;
+            }
+        } else {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                if (x[i] > bv) { bv = x[i]; bi = tid + 256 * i; }
+            t2s_block_argmax(bv, bi, sv, si);
+            top = bv;
+        }
+        const uint32_t pos = (uint32_t)a.kv_len[b], stp = (uint32_t)a.step[b];
+        float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int v = tid + 256 * i;
+            if (v < a.V && x[i] >= pivot && x[i] > -INFINITY) {   // the pivot keeps ties (logits < pivot -> -inf)
+                const float u = t2s_uniform((uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp, (uint32_t)v);
+                const float sc = (x[i] - top) - logf(-logf(u));
+                if (sc > bv || (sc == bv && v < bi)) { bv = sc; bi = v; }
+            }
+        }
+        t2s_block_argmax(bv, bi, sv, si);
+        sampled = bi < a.V ? bi : 0;
+    }
     if (tid == 0) {
         int tok;
-        if (a.ctl[0] != 0) {
+        if (a.ctl[0] == 2) {
+            tok = sampled;
+        } else if (a.ctl[0] != 0) {
             tok = (int)a.tok_override[b];
         } else {
             float bv = -INFINITY;

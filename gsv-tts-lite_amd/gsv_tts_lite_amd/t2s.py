@@ -93,6 +93,7 @@ class Text2SemanticDecoder:
         # persistent decode step (csrc/t2s_megastep.h, batch <= 4): correct and stress-tested, but measured
         # equal-to-slightly-slower than the per-layer graph (hand-off ~= kernel boundary), so off by default
         self.use_megastep = False
+        self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
         self._weights = None
         self._h = None
         self._rt = {}
@@ -162,7 +163,7 @@ class Text2SemanticDecoder:
                 "logits": torch.zeros(b, self.vocab_size, dtype=torch.float32, device=device),
                 "hidden": torch.zeros(b, self.model_dim, dtype=torch.float32, device=device),
                 "tok_override": torch.zeros(b, dtype=torch.int64, device=device),
-                "ctl": torch.zeros(4, dtype=torch.int32, device=device),
+                "ctl": torch.zeros(8, dtype=torch.int32, device=device),
                 "fctl": torch.ones(4, dtype=torch.float32, device=device),
             }
             st = N.T2SState(b, T, *[rt[k].data_ptr() for k in (
@@ -237,9 +238,25 @@ class Text2SemanticDecoder:
     def _flush(self, batch):
         N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))
 
-    def _set_ctl(self, rt, use_override, suppress_steps, rep_enabled, rep):
-        rt["ctl"].copy_(torch.tensor([int(use_override), int(suppress_steps), int(rep_enabled), 0], dtype=torch.int32))
-        rt["fctl"].copy_(torch.tensor([float(rep), 0.0, 0.0, 0.0], dtype=torch.float32))
+    def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0):
+        """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling"""
+        lo, hi = int(seed) & 0x7fffffff, (int(seed) >> 31) & 0x7fffffff
+        rt["ctl"].copy_(torch.tensor([int(mode), int(suppress_steps), int(rep_enabled), 0, int(top_k or 0), lo, hi, 0],
+                                     dtype=torch.int32))
+        rt["fctl"].copy_(torch.tensor([float(rep), float(temperature), 0.0, 0.0], dtype=torch.float32))
+
+    def _sampling_mode(self, top_k, top_p, generator):
+        """(mode, seed): greedy stays the device argmax; top-k / temperature sampling runs on device unless
+        top_p < 1 (sort + cumsum: host path) or device sampling is switched off."""
+        if top_k == 1:
+            return 0, 0
+        if not self.device_sampling or (top_p is not None and top_p < 1.0) or (top_k is not None and top_k > 256):
+            return 1, 0
+        if generator is not None:   # the caller's generator (CPU or device) seeds the device noise stream
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+        else:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return 2, seed
 
     # ------------------------------------------------------------------ drivers
     @torch.inference_mode()
@@ -256,9 +273,10 @@ class Text2SemanticDecoder:
         n_iter = buckets[-1].max_kv_cache - Lp
         if n_iter < 1:
             raise RuntimeError("no decode iterations: prompt fills the largest bucket")
-        greedy = top_k == 1
+        mode, seed = self._sampling_mode(top_k, top_p, generator)
+        greedy = mode != 1   # the device loop serves greedy and device sampling alike
         rep_on = repetition_penalty != 1.0
-        self._set_ctl(rt, not greedy, initial_suppression_steps, rep_on, repetition_penalty)
+        self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed)
         rt["seen"].zero_()
         if rep_on:
             rt["seen"][0, y[0].to(self.device)] = 1
@@ -311,8 +329,9 @@ class Text2SemanticDecoder:
         buckets = self.cuda_graph_buckets[batch_size]
         caps = [b.max_kv_cache for b in buckets]
         actual = min(B, batch_size)
-        greedy = top_k == 1
-        self._set_ctl(rt, not greedy, 0, False, 1.0)
+        mode, seed = self._sampling_mode(top_k, top_p, generator)
+        greedy = mode != 1
+        self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed)
         dev = self.device
         rt["kv_len"].zero_()
         rt["x_len"].zero_()

@@ -82,9 +82,14 @@ typedef struct {
     int32_t* eos_at;        /* [B]   first step whose sample was EOS, else -1 */
     float* logits;          /* [B][vocab] last logits after suppression/penalty (host sampling) */
     float* hidden;          /* [B][hidden] last final hidden state (Bucket.graph_xy_dec) */
-    int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] != 0 */
-    int32_t* ctl;           /* [4]   {use_override, suppress_steps, rep_enabled, drop_eos_col_steps} */
-    float* fctl;            /* [4]   {repetition_penalty, -, -, -} */
+    int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] == 1 */
+    int32_t* ctl;           /* [8]   {sample_mode, suppress_steps, rep_enabled, drop_eos_col_steps, top_k, seed_lo,
+                               seed_hi, -}; sample_mode 0 = greedy argmax, 1 = tok_override (host sampling),
+                               2 = device sampling: temperature fctl[1], top-k ctl[4] (<= 0: off; ties with the
+                               k-th value are kept, GPT/utils.py:45-48), then argmax(softmax / Exp(1))
+                               (utils.py:56-59) with a counter-based noise stream keyed by
+                               (seed, slot, kv position, step, token id); top_p is host-only */
+    float* fctl;            /* [4]   {repetition_penalty, temperature, -, -} */
 } gsv_t2s_state;
 int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st);
 

@@ -445,3 +445,49 @@ class VocoderOracle:
         """models.py:380-383: o = dec(flow(z_p, mask, ge) * mask, g=ge)."""
         z = self.flow(z_p, y_mask, ge)
         return self.dec(z * _f32(y_mask).reshape(1, -1), ge)
+
+
+# ---- restatement of the DEVICE sampler (csrc/t2s_decode.h: t2s_uniform + the ctl[0] == 2 branch of the
+# token kernel).  The reference draws Exp(1) noise from torch's generator (GPT/utils.py:56-59); the device
+# sampler owns a counter-based stream instead, so the checker restates that stream, not torch's.
+def _lowbias32(h):
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16); h *= np.uint32(0x7feb352d); h ^= h >> np.uint32(15); h *= np.uint32(0x846ca68b); h ^= h >> np.uint32(16)
+    return h
+
+
+def device_uniform(seed, slot, pos, step, V):
+    lo, hi = np.uint32(seed & 0x7fffffff), np.uint32((seed >> 31) & 0x7fffffff)
+    v = np.arange(V, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        h = lo ^ (v * np.uint32(0x9E3779B1)) ^ (np.uint32(pos) * np.uint32(0x85EBCA77)) ^ (np.uint32(slot) * np.uint32(0xC2B2AE3D)) \
+            ^ (np.uint32(step) * np.uint32(0x27D4EB2F)) ^ ((hi << np.uint32(13)) | (hi >> np.uint32(19)))
+        h = _lowbias32(h)
+        h = h + hi
+        h = _lowbias32(h)
+    return ((h >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def device_sample(logits, top_k, temperature, seed, slot, pos, step):
+    """(token, margin): temperature, top-k with ties kept, Gumbel argmax; margin = top-1 minus top-2 score"""
+    x = np.asarray(logits, np.float32) / np.float32(max(temperature, 1e-5))
+    V = x.shape[0]
+    pivot = -np.inf
+    if top_k and 0 < top_k < V:
+        pivot = np.sort(x)[::-1][top_k - 1]
+    keep = (x >= pivot) & np.isfinite(x)
+    u = device_uniform(seed, slot, pos, step, V)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sc = np.where(keep, (x - x.max()) - np.log(-np.log(u)), -np.inf).astype(np.float32)
+    order = np.argsort(-sc, kind="stable")
+    return int(order[0]), float(sc[order[0]] - sc[order[1]]) if V > 1 else np.inf
+
+
+def device_sample_probs(logits, top_k, temperature):
+    """the distribution the device sampler draws from (== GPT/utils.py logits_to_probs with top_p = 1)"""
+    x = np.asarray(logits, np.float64) / max(temperature, 1e-5)
+    if top_k and 0 < top_k < x.shape[0]:
+        pivot = np.sort(x)[::-1][top_k - 1]
+        x = np.where(x < pivot, -np.inf, x)
+    e = np.exp(x - x[np.isfinite(x)].max())
+    return e / e.sum()

@@ -290,3 +290,72 @@ def test_prefill_bf16_mfma_attention_packed_batch_and_cache(golden_dir, dev):
     for b in range(2):
         n = len(xs[b]) + len(ys[b])
         assert np.abs(h[b, :n] - g["b_hidden"][b, :n]).max() < 5e-2, b
+
+
+def test_device_sampler_matches_its_restatement_and_the_reference_distribution(dev):
+    """The token kernel's sampler (ctl[0] == 2): (i) draw by draw against the numpy restatement of the same
+    counter-based noise stream (oracle.device_sample), mismatches allowed only where the top-2 scores are
+    closer than float noise; (ii) the empirical distribution over 6000 draws against the reference's
+    logits_to_probs semantics (temperature, top-k pivot that keeps ties, -inf never drawn) by chi-square."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=1)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=5), [(1, 64)], torch.float32, dev)
+    rt = m._rt[1]
+    V = 1025
+    rng = np.random.default_rng(0)
+    logits = (rng.standard_normal(V) * 2.5).astype(np.float32)
+    logits[[280, 486, 1024]] = -np.inf                    # suppressed entries arrive as -inf
+    logits[7] = logits[11] = np.sort(logits)[::-1][14]    # a tie exactly at the top-15 pivot: both must stay
+    top_k, temp = 15, 0.8
+    ref_p = orc.device_sample_probs(logits, top_k, temp)
+    assert (ref_p > 0).sum() >= 16                        # the tie widened the kept set
+    n, bad = 6000, 0
+    counts = np.zeros(V)
+    with torch.inference_mode():
+        rt["logits"][0].copy_(torch.from_numpy(logits))
+        rt["kv_len"].fill_(3); rt["x_len"].fill_(1); rt["step"].fill_(2)
+        for s in range(n):
+            seed = 1000003 * s + 17
+            m._set_ctl(rt, 2, 0, False, 1.0, top_k, temp, seed)
+            m._flush(1)
+            tok = int(rt["pre_tokens"][0, 3].item())
+            counts[tok] += 1
+            want, margin = orc.device_sample(logits, top_k, temp, seed, 0, 3, 2)
+            if tok != want:
+                assert margin < 1e-4, (s, tok, want, margin)
+                bad += 1
+    assert bad <= 3
+    assert counts[ref_p == 0].sum() == 0, "drew a token outside the kept set"
+    exp = ref_p[ref_p > 0] * n
+    chi2 = (((counts[ref_p > 0] - exp) ** 2) / exp).sum()
+    assert chi2 < 60.0, chi2                              # 15 dof: p ~ 2e-7 at 60
+    # top_k >= V and top_k <= 0 keep everything finite; k = 1 is the argmax
+    with torch.inference_mode():
+        m._set_ctl(rt, 2, 0, False, 1.0, 1, 1.0, 99); m._flush(1)
+        assert int(rt["pre_tokens"][0, 3].item()) == int(np.argmax(logits))
+        m._set_ctl(rt, 2, 0, False, 1.0, 0, 1.0, 99); m._flush(1)
+        assert int(rt["pre_tokens"][0, 3].item()) == orc.device_sample(logits, 0, 1.0, 99, 0, 3, 2)[0]
+
+
+def test_device_and_host_sampling_paths_agree_on_rules(dev):
+    """default-parameter inference (top_k=15, repetition penalty) through the device sampler and through the
+    host (tok_override) path: both deterministic under a seeded generator, tokens in range, no suppressed
+    token in the first steps; infer_batched with slot refill runs on the device sampler."""
+    cfg = synth.gpt_config(n_layer=4)
+    w = synth.gpt_weights(cfg, seed=3)
+    m = _model(cfg, w, [(1, 96), (2, 96)], torch.float32, dev)
+    x, y, bert, _ = synth.synth_request(9, 6, 10, 14, seed=3)
+    for device_sampling in (True, False):
+        m.device_sampling = device_sampling
+        outs = []
+        for _ in range(2):
+            gen = torch.Generator(device=dev); gen.manual_seed(4321)   # the host path draws its noise on the device
+            tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=15, generator=gen)[0, 0].cpu().numpy()
+            outs.append(tok)
+            assert tok.min() >= 0 and tok.max() < 1025 and len(tok) > 0
+            assert not set(tok[:8].tolist()) & {280, 486, 1024}
+        assert np.array_equal(outs[0], outs[1]), device_sampling
+    m.device_sampling = True
+    gen = torch.Generator(device="cpu"); gen.manual_seed(1)
+    pred, idx = m.infer_batched([_T(x, dev)] * 5, [_T(y, dev)] * 5, [_T(bert, dev)] * 5, top_k=15, generator=gen)
+    assert sorted(idx.tolist()) == [0, 1, 2, 3, 4] and all(len(p) > 0 and int(p.max()) < 1025 for p in pred)
