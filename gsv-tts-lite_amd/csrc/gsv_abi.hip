@@ -864,6 +864,8 @@ struct gsv_voc {
     std::vector<VocFlow> flows;
     PackedConv conv_pre, cond, conv_post;
     PackedConv cond_all;             // every flow's cond_layer stacked: one launch for the whole flow
+    float* post_w = nullptr;         // conv_post weight [C][7] fp32 for conv_post_kernel
+    int post_c = 0;
     bool fused_flow = false;
     std::vector<VocStage> stages;
     int total_up = 1;
@@ -873,6 +875,24 @@ struct gsv_voc {
 namespace {
 
 inline int ld_of(int c) { return (c + 15) / 16 * 16; }
+
+// conditioning GEMV / small-row 1x1 convs (bf16 in, fp32 out): the latency-shaped rowgemm when the
+// contraction is 512 or 1024 channels, else the generic kernel
+template <typename AT>
+int run_cond(const PackedConv& pc, const void* X, int ldx, int rows, float* Y, int ldy, hipStream_t st) {
+    if (sizeof(AT) == 2 && pc.u == 0 && pc.k == 1 && (pc.cin == 512 || pc.cin == 1024)) {
+        RowGemmArgs ra;
+        ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.bias = pc.bias; ra.relu = 0;
+        ra.Y = Y; ra.ldy = ldy; ra.split_stride = 0;
+        const dim3 grid(cdiv(rows, 32), pc.mtiles, 1);
+        if (pc.cin == 512) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 8>), grid, dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 16>), grid, dim3(256), 0, st, ra);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    }
+    Epi ec;
+    return run_conv<AT, AT, float>(pc, X, ldx, rows, Y, ldy, rows, ec, st);
+}
 
 struct VocWs {
     // channels-last buffers (element type AT unless noted)
@@ -913,8 +933,7 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
     if (v->fused_flow && sizeof(AT) == 2) {
         // one launch for every flow's conditioning, then one fused kernel per coupling layer; no Flip passes
         const int ldg_all = 8 * H * c.n_flows;
-        Epi ec;
-        if (int rc = run_conv<AT, AT, float>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, Tg, ec, st)) return rc;
+        if (int rc = run_cond<AT>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, st)) return rc;
         HIPCHK(hipFuncSetAttribute((const void*)flowfuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS_TOTAL));
         for (int f = c.n_flows - 1; f >= 0; --f) {
             VocFlow& F = v->flows[f];
@@ -975,8 +994,7 @@ template <typename AT>
 int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st) {
     const gsv_voc_config& c = v->cfg;
     const int C0 = c.upsample_initial_channel;
-    Epi ec;
-    if (int rc = run_conv<AT, AT, float>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, Tg, ec, st)) return rc;
+    if (int rc = run_cond<AT>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, st)) return rc;
     AT* x = (AT*)w.st[1];
     Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0;
     if (int rc = run_conv<AT, AT, AT>(v->conv_pre, w.zin, c.inter_channels, T, x, ld_of(C0), T, ep, st)) return rc;
@@ -1026,8 +1044,14 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
                            cur[0], cur[1], cur[2], x, n);
         Tc = Tn;
     }
-    Epi eo; eo.in_slope = 0.01f; eo.act = ACT_TANH; eo.use_bias = false;
-    if (int rc = run_conv<AT, AT, float>(v->conv_post, x, ld_of(v->stages.back().cout), Tc, out, 1, Tc, eo, st)) return rc;
+    if (sizeof(AT) == 2 && v->post_w && (v->post_c == 16 || v->post_c == 24)) {
+        const int ldp = ld_of(v->post_c);
+        if (v->post_c == 16) hipLaunchKernelGGL((conv_post_kernel<AT, 16>), dim3(cdiv(Tc, 256)), dim3(256), 0, st, (const AT*)x, ldp, (const float*)v->post_w, out, Tc);
+        else hipLaunchKernelGGL((conv_post_kernel<AT, 24>), dim3(cdiv(Tc, 256)), dim3(256), 0, st, (const AT*)x, ldp, (const float*)v->post_w, out, Tc);
+    } else {
+        Epi eo; eo.in_slope = 0.01f; eo.act = ACT_TANH; eo.use_bias = false;
+        if (int rc = run_conv<AT, AT, float>(v->conv_post, x, ld_of(v->stages.back().cout), Tc, out, 1, Tc, eo, st)) return rc;
+    }
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
@@ -1239,6 +1263,12 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
             wsrc = padded;
         }
         rc = pack_conv<CT>(v->conv_post, wsrc, 1, cpad, 7, (int64_t)cpad * 7, 7, 1, 1, 3, 0, nullptr, 1.f, st);
+        if (!rc) {   // plain fp32 copy [ch][7] for the one-output-channel tail kernel
+            if (v->post_w) (void)hipFree(v->post_w);
+            HIPCHK(hipMalloc(&v->post_w, sizeof(float) * (size_t)ch * 7));
+            HIPCHK(hipMemcpyAsync(v->post_w, w, sizeof(float) * (size_t)ch * 7, hipMemcpyDeviceToDevice, st));
+            v->post_c = ch;
+        }
     }
     (void)hipStreamSynchronize(st);
     for (float* t : temps) (void)hipFree(t);
@@ -1262,6 +1292,8 @@ void voc_free(gsv_voc* v) {
         for (auto& p : F.rs_skip) free_conv(p);
     }
     free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post); free_conv(v->cond_all);
+    if (v->post_w) (void)hipFree(v->post_w);
+    v->post_w = nullptr;
     for (VocStage& s : v->stages) {
         free_conv(s.up);
         for (VocResBlock& r : s.rb)

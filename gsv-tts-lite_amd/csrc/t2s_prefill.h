@@ -312,9 +312,8 @@ struct RowGemmArgs {
     size_t split_stride;  // elements between the partial outputs of consecutive splits
 };
 
-template <typename XT, typename OT>
+template <typename XT, typename OT, int KPW = 8>       // KPW: k-steps per wave (K = 64 * KPW * nsplit channels)
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
-    constexpr int KPW = 8;                                  // k-steps per wave
     __shared__ float red[3][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;

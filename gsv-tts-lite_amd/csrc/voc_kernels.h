@@ -82,6 +82,40 @@ __global__ void avg3_kernel(const AT* __restrict__ a, const AT* __restrict__ b, 
     }
 }
 
+// Generator tail (SoVITS/models.py:129-131): y[n] = tanh( sum_t sum_c w[c][t] * lrelu_{0.01}(x[n + t - 3][c]) ), one output
+// channel, k = 7, no bias.  One sample per thread, rows staged (after the leaky-ReLU, fp32) in LDS with a
+// 4-float skew; the 32x32 MFMA tile of the generic kernel would waste 31 of its 32 output rows here.
+template <typename AT, int C>
+__global__ __launch_bounds__(256) void conv_post_kernel(const AT* __restrict__ x, int ld, const float* __restrict__ w,
+                                                        float* __restrict__ y, int n_rows) {
+    constexpr int RS = C + 4;
+    __shared__ float xs[(256 + 6) * RS];
+    __shared__ float ws[C * 7];
+    const int tid = threadIdx.x, n0 = blockIdx.x * 256;
+    for (int i = tid; i < C * 7; i += 256) ws[i] = w[i];
+    constexpr int VPR = C / (16 / (int)sizeof(AT));          // 16-byte vectors per row
+    constexpr int EPV = 16 / (int)sizeof(AT);
+    for (int e = tid; e < (256 + 6) * VPR; e += 256) {
+        const int r = e / VPR, cv = e % VPR;
+        const int g = n0 - 3 + r;
+        float v[EPV];
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) v[i] = 0.f;
+        if (g >= 0 && g < n_rows) Ld<AT, EPV>::load(x + (size_t)g * ld + cv * EPV, v);
+#pragma unroll
+        for (int i = 0; i < EPV; ++i) xs[r * RS + cv * EPV + i] = fmaxf(v[i], v[i] * 0.01f);
+    }
+    __syncthreads();
+    const int n = n0 + tid;
+    if (n >= n_rows) return;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(ws[c * 7 + t], xs[(tid + t) * RS + c], acc);
+    y[n] = tanhf(acc);
+}
+
 // W = v * (g / ||v||) per output row (torch.nn.utils.weight_norm, dim=0); one block per row
 __global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                         float* __restrict__ w, int row_elems, float sign) {
