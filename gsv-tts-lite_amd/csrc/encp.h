@@ -1,0 +1,246 @@
+// enc_p (TextEncoder.infer, reference SoVITS/models.py:196-224; attentions.py:58-220; mrte_model.py:20-38)
+// on gfx950: the dense layers run on tapgemm (channels-last activations), this file holds what is left --
+// the attention with windowed relative positions, the channel LayerNorm and the two gathers.  bf16
+// activations / operands, fp32 softmax statistics and accumulation (production mode; the fp32 parity
+// mode keeps the torch restatement in sovits_encoder.py).
+#pragma once
+#include "tapgemm.h"
+
+namespace gsv {
+
+// rows of a table -> channels-last bf16 rows; `rep` consecutive output rows per index (x2 nearest upsampling
+// of the codebook vectors, models.py:388-392)
+__global__ void encp_gather_kernel(const int64_t* __restrict__ idx, int n_idx, int n_rows_table, const float* __restrict__ table,
+                                   int C, int rep, bf16_t* __restrict__ out) {
+    const int r = blockIdx.x;                                // output row
+    int id = (int)idx[r / rep];
+    id = min(max(id, 0), n_rows_table - 1);
+    for (int c = threadIdx.x * 2; c < C; c += blockDim.x * 2) {
+        const float a = table[(size_t)id * C + c], b = table[(size_t)id * C + c + 1];
+        *reinterpret_cast<uint32_t*>(out + (size_t)r * C + c) = pack_bf16x2(a, b);
+    }
+}
+
+// modules.LayerNorm over the channel axis (attentions.py / modules.py:14-27): y[t] = LN(x[t]) * gamma + beta, one
+// wave per row, C <= 512, two-pass like F.layer_norm
+__global__ __launch_bounds__(256) void encp_ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8];
+    int n = 0;
+    for (int c = lane; c < C; c += 64) v[n++] = bf16_to_f32(x[(size_t)row * C + c]);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+    n = 0;
+    for (int c = lane; c < C; c += 64) { y[(size_t)row * C + c] = f32_to_bf16(v[n] * rs * gamma[c] + beta[c]); ++n; }
+}
+
+// a + b (+ per-row or broadcast fp32 row g) -> bf16 : the MRTE sum  attn_out + ssl_enc + ge  (mrte_model.py:35-36)
+__global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg,
+                                 bf16_t* __restrict__ y, int rows, int C) {
+    const size_t n = (size_t)rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        y[i] = f32_to_bf16(bf16_to_f32(a[i]) + bf16_to_f32(b[i]) + g[(ldg ? r * (size_t)ldg : (size_t)0) + c]);
+    }
+}
+
+struct EncAttnArgs {
+    const bf16_t* Q; int ldq;      // [Tq][ldq], head h at column qoff + h*D
+    const bf16_t* K; int ldk;      // [Tk][ldk]
+    const bf16_t* V; int ldv;
+    int qoff, koff, voff;
+    bf16_t* O; int ldo;            // [Tq][ldo], head h at column h*D
+    int Tq, Tk, H;
+    float scale;                   // 1/sqrt(D) (the reference scales q before both products)
+    const float* relk;             // [2w+1][D] fp32 or null (emb_rel_k[0])
+    const float* relv;
+    int window;
+    const int64_t* slice;          // [Tq][2] or null: key j visible iff slice[i][0] <= j < slice[i][1] or j == Tk-1
+    float* P;                      // [H][Tq][Tk] softmax probabilities (cross_attention.attn) or null
+};
+
+// One block = (head, 128 queries); a wave owns 32 queries.  Two passes over 32-key tiles staged in LDS:
+//   A  S^T = K Q^T on the matrix cores (+ relative-position logits, mask) -> row max m and row sum l
+//   B  S^T again, p = exp(s - m) / l -> optional P output, band probabilities for the relative-value term,
+//      O^T += V^T P^T with V^T staged key-permuted so the D registers feed the B operand directly.
+template <int D>
+__global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
+    constexpr int KST = D / 16;                              // k-steps of the score product
+    constexpr int MT = D / 32;                               // 32-row tiles of O^T
+    constexpr int KRS = D * 2 + 16;                          // K tile row stride (bytes)
+    constexpr int VRS = 32 * 2 + 16;                         // V^T tile row stride
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * KRS];
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[D * VRS];
+    __shared__ float rl[128][9];                             // q_i . rel_k[b] * scale
+    __shared__ float pb[128][9];                             // p[i][i + b - w]
+    const int h = blockIdx.x, qb0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int q0 = qb0 + wid * 32;
+    const int i = q0 + j;                                    // the lane's query
+    const int ic = min(i, a.Tq - 1);
+    const int w = a.window;
+    const float LOG2E = 1.4426950408889634f;
+    // Q fragments of the lane's query
+    u32x4 qf[KST];
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks)
+        qf[ks] = *reinterpret_cast<const u32x4*>(a.Q + (size_t)ic * a.ldq + a.qoff + h * D + ks * 16 + hf * 8);
+    for (int e = tid; e < 128 * 9; e += 256) { (&rl[0][0])[e] = 0.f; (&pb[0][0])[e] = 0.f; }
+    int s0 = 0, s1 = a.Tk;
+    if (a.slice) { s0 = (int)a.slice[(size_t)ic * 2]; s1 = (int)a.slice[(size_t)ic * 2 + 1]; }
+    const int nkt = (a.Tk + 31) / 32;
+
+    auto stage_k = [&](const bf16_t* src, int ld, int off, int row0, int nrows_valid, bool is_rel) {
+        // 32 rows x D bf16 (rel: fp32 [9][D] -> bf16 rows 0..8, zeros after)
+        for (int e = tid; e < 32 * (D / 8); e += 256) {
+            const int r = e / (D / 8), cv = e % (D / 8);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < nrows_valid) {
+                if (is_rel) {
+                    const float* rp = a.relk + (size_t)r * D + cv * 8;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) v[x] = pack_bf16x2(rp[2 * x], rp[2 * x + 1]);
+                } else {
+                    v = *reinterpret_cast<const u32x4*>(src + (size_t)(row0 + r) * ld + off + h * D + cv * 8);
+                }
+            }
+            *reinterpret_cast<u32x4*>(Ks + r * KRS + cv * 16) = v;
+        }
+    };
+    auto scores = [&](f32x16& s) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + j * KRS + ks * 32 + hf * 16);
+            Mma<bf16_t>::run(s, kf, qf[ks]);
+        }
+    };
+
+    // ---- relative-position logits: one extra "key tile" holding rel_k
+    if (a.relk) {
+        __syncthreads();
+        stage_k(nullptr, 0, 0, 0, 2 * w + 1, true);
+        __syncthreads();
+        f32x16 s;
+        scores(s);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int b = (q & 3) + 8 * (q >> 2) + 4 * hf;
+            if (b < 2 * w + 1) rl[wid * 32 + j][b] = s[q] * a.scale;
+        }
+    }
+    // score of (query i, key) with mask and relative logits; -1e30 = not visible
+    auto finish = [&](float raw, int key) -> float {
+        if (key >= a.Tk || i >= a.Tq) return -1e30f;
+        if (a.slice && !((key >= s0 && key < s1) || key == a.Tk - 1)) return -1e30f;
+        float v = raw * a.scale;
+        const int b = key - i + w;
+        if (a.relk && b >= 0 && b <= 2 * w) v += rl[wid * 32 + j][b];
+        return v * LOG2E;
+    };
+    // ---- pass A: row max and row sum
+    float m = -1e30f, l = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_k(a.K, a.ldk, a.koff, kt * 32, min(32, a.Tk - kt * 32), false);
+        __syncthreads();
+        f32x16 s;
+        scores(s);
+        float sv[16], tm = -1e30f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            sv[q] = finish(s[q], kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf);
+            tm = fmaxf(tm, sv[q]);
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mn = fmaxf(m, tm);
+        float ps = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ps += sv[q] > -1e29f ? __builtin_amdgcn_exp2f(sv[q] - mn) : 0.f;
+        l = l * __builtin_amdgcn_exp2f(m - mn) + ps;
+        m = mn;
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    // ---- pass B: probabilities, P output, band terms, O^T += V^T P^T
+    f32x16 o[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[t][q] = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        const int nv = min(32, a.Tk - kt * 32);
+        stage_k(a.K, a.ldk, a.koff, kt * 32, nv, false);
+        for (int e = tid; e < 32 * (D / 8); e += 256) {      // V^T tile, keys permuted into D-register order
+            const int r = e / (D / 8), cv = e % (D / 8);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r < nv) v = *reinterpret_cast<const u32x4*>(a.V + (size_t)(kt * 32 + r) * a.ldv + a.voff + h * D + cv * 8);
+            const int hh = (r >> 2) & 1, blk = r >> 3;
+            const int pos = (blk >> 1) * 16 + 8 * hh + (r & 3) + 4 * (blk & 1);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * x) * VRS + pos * 2) = (bf16_t)(v[x] & 0xffff);
+                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * x + 1) * VRS + pos * 2) = (bf16_t)(v[x] >> 16);
+            }
+        }
+        __syncthreads();
+        f32x16 s;
+        scores(s);
+        float p[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int key = kt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+            const float sv = finish(s[q], key);
+            p[q] = sv > -1e29f ? __builtin_amdgcn_exp2f(sv - m) * inv : 0.f;
+            if (a.P && i < a.Tq && key < a.Tk) a.P[((size_t)h * a.Tq + i) * a.Tk + key] = p[q];
+            const int b = key - i + w;
+            if (a.relv && b >= 0 && b <= 2 * w && key < a.Tk) pb[wid * 32 + j][b] = p[q];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf[e] = pack_bf16x2(p[8 * ks + 2 * e], p[8 * ks + 2 * e + 1]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(Vt + (t * 32 + j) * VRS + (ks * 16 + hf * 8) * 2);
+                Mma<bf16_t>::run(o[t], vf, pf);
+            }
+        }
+    }
+    __syncthreads();                                         // band probabilities of both lane halves are in pb
+    if (i >= a.Tq) return;
+    // out[i][d] = O^T[d][i] + sum_b p[i][i+b-w] * rel_v[b][d]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[t][4 * g + e];
+            const int d0 = t * 32 + 8 * g + 4 * hf;
+            if (a.relv) {
+                for (int b = 0; b <= 2 * w; ++b) {
+                    const float pw = pb[wid * 32 + j][b];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(pw, a.relv[(size_t)b * D + d0 + e], v[e]);
+                }
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(a.O + (size_t)i * a.ldo + h * D + d0) = pk;
+        }
+}
+
+}  // namespace gsv

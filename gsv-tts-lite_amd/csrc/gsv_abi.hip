@@ -19,6 +19,7 @@
 #include "tapgemm.h"
 #include "wconv.h"
 #include "flowfuse.h"
+#include "encp.h"
 #include "voc_kernels.h"
 
 using namespace gsv;
@@ -857,6 +858,19 @@ struct VocStage {
     int cin = 0, cout = 0, u = 1;
 };
 
+struct EncLayer {
+    PackedConv qkv, o, c1, c2;
+    float *relk = nullptr, *relv = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+struct EncP {
+    bool ready = false;
+    PackedConv ssl_proj, c_pre, text_pre, c_post, proj, xq, xkv, xo;
+    float *text_emb = nullptr, *codebook = nullptr;
+    int n_text = 0, n_code = 0;
+    std::vector<EncLayer> ssl, text, enc2;
+    std::vector<float*> owned;       // small fp32 tensors (norms, relative embeddings, tables)
+};
+
 struct gsv_voc {
     gsv_voc_config cfg;
     std::map<std::string, std::pair<float*, int64_t>> staged;
@@ -867,6 +881,7 @@ struct gsv_voc {
     float* post_w = nullptr;         // conv_post weight [C][7] fp32 for conv_post_kernel
     int post_c = 0;
     bool fused_flow = false;
+    EncP enc;                        // enc_p in HIP (bf16 mode, when its tensors were loaded)
     std::vector<VocStage> stages;
     int total_up = 1;
     int max_stage_elems_per_frame = 0;  // max over stages of ld(C) * time multiplier
@@ -1086,6 +1101,195 @@ int voc_run(gsv_voc* v, int what, const float* z, const float* mask, const float
     return voc_dec_impl<AT>(v, w, T, Tg, out, st);
 }
 
+// ---- enc_p (bf16): weights -------------------------------------------------------------------
+int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
+    EncP& E = v->enc;
+    auto get = [&](const std::string& n, int64_t numel, const float** out) -> int {
+        auto it = v->staged.find(n);
+        if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing tensor '%s'", n.c_str());
+        if (numel > 0 && it->second.second != numel) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", n.c_str(), (long long)it->second.second, (long long)numel);
+        *out = it->second.first;
+        return GSV_OK;
+    };
+    auto keep = [&](const std::string& n, int64_t numel, float** out) -> int {   // private fp32 copy
+        const float* s;
+        if (int rc = get(n, numel, &s)) return rc;
+        float* d;
+        HIPCHK(hipMalloc(&d, sizeof(float) * (size_t)v->staged[n].second));
+        HIPCHK(hipMemcpyAsync(d, s, sizeof(float) * (size_t)v->staged[n].second, hipMemcpyDeviceToDevice, st));
+        E.owned.push_back(d);
+        *out = d;
+        return GSV_OK;
+    };
+    auto conv = [&](PackedConv& pc, const std::string& base, int cout, int cin, int k) -> int {
+        const float *w, *b;
+        if (int rc = get(base + ".weight", (int64_t)cout * cin * k, &w)) return rc;
+        if (int rc = get(base + ".bias", cout, &b)) return rc;
+        return pack_conv<bf16_t>(pc, w, cout, cin, k, (int64_t)cin * k, k, 1, 1, (k - 1) / 2, 0, b, 1.f, st);
+    };
+    // several 1x1 convs of one input stacked along the output channels (q|k|v)
+    auto stacked = [&](PackedConv& pc, const std::vector<std::string>& bases, int cout_each, int cin) -> int {
+        const int n = (int)bases.size();
+        float *w, *b;
+        HIPCHK(hipMalloc(&w, sizeof(float) * (size_t)n * cout_each * cin));
+        HIPCHK(hipMalloc(&b, sizeof(float) * (size_t)n * cout_each));
+        temps.push_back(w); temps.push_back(b);
+        for (int i = 0; i < n; ++i) {
+            const float *ws, *bs;
+            if (int rc = get(bases[i] + ".weight", (int64_t)cout_each * cin, &ws)) return rc;
+            if (int rc = get(bases[i] + ".bias", cout_each, &bs)) return rc;
+            HIPCHK(hipMemcpyAsync(w + (size_t)i * cout_each * cin, ws, sizeof(float) * (size_t)cout_each * cin, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(b + (size_t)i * cout_each, bs, sizeof(float) * cout_each, hipMemcpyDeviceToDevice, st));
+        }
+        return pack_conv<bf16_t>(pc, w, n * cout_each, cin, 1, cin, 1, 0, 1, 0, 0, b, 1.f, st);
+    };
+    const int Hc = v->cfg.hidden_channels;                   // 192
+    const int Fc = 4 * Hc;                                   // filter channels (768)
+    auto encoder = [&](std::vector<EncLayer>& Ls, const std::string& pre, int n_layers) -> int {
+        Ls.resize(n_layers);
+        for (int i = 0; i < n_layers; ++i) {
+            EncLayer& L = Ls[i];
+            const std::string a = pre + "attn_layers." + std::to_string(i) + ".";
+            if (int rc = stacked(L.qkv, {a + "conv_q", a + "conv_k", a + "conv_v"}, Hc, Hc)) return rc;
+            if (int rc = conv(L.o, a + "conv_o", Hc, Hc, 1)) return rc;
+            if (int rc = keep(a + "emb_rel_k", 0, &L.relk)) return rc;
+            if (int rc = keep(a + "emb_rel_v", 0, &L.relv)) return rc;
+            if (v->staged[a + "emb_rel_k"].second != 9 * (Hc / 2)) return fail(GSV_ERR_ARG, "enc_p: expected window 4, 2 heads");
+            const std::string s = std::to_string(i);
+            if (int rc = keep(pre + "norm_layers_1." + s + ".gamma", Hc, &L.g1)) return rc;
+            if (int rc = keep(pre + "norm_layers_1." + s + ".beta", Hc, &L.b1)) return rc;
+            if (int rc = keep(pre + "norm_layers_2." + s + ".gamma", Hc, &L.g2)) return rc;
+            if (int rc = keep(pre + "norm_layers_2." + s + ".beta", Hc, &L.b2)) return rc;
+            auto it = v->staged.find(pre + "ffn_layers." + s + ".conv_1.weight");
+            if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing enc_p ffn tensors");
+            const int k = (int)(it->second.second / ((int64_t)Fc * Hc));
+            if (k != 3) return fail(GSV_ERR_ARG, "enc_p: FFN kernel size %d (expected 3)", k);
+            if (int rc = conv(L.c1, pre + "ffn_layers." + s + ".conv_1", Fc, Hc, k)) return rc;
+            if (int rc = conv(L.c2, pre + "ffn_layers." + s + ".conv_2", Hc, Fc, k)) return rc;
+        }
+        return GSV_OK;
+    };
+    int nl = 0;
+    while (v->staged.count("enc_p.encoder_text.attn_layers." + std::to_string(nl) + ".conv_q.weight")) ++nl;
+    if (nl < 2 || nl % 2) return fail(GSV_ERR_ARG, "enc_p: %d text encoder layers", nl);
+    if (int rc = conv(E.ssl_proj, "enc_p.ssl_proj", Hc, 768, 1)) return rc;
+    if (int rc = encoder(E.ssl, "enc_p.encoder_ssl.", nl / 2)) return rc;
+    if (int rc = encoder(E.text, "enc_p.encoder_text.", nl)) return rc;
+    if (int rc = encoder(E.enc2, "enc_p.encoder2.", nl / 2)) return rc;
+    if (int rc = keep("enc_p.text_embedding.weight", 0, &E.text_emb)) return rc;
+    E.n_text = (int)(v->staged["enc_p.text_embedding.weight"].second / Hc);
+    if (int rc = keep("quantizer.vq.layers.0._codebook.embed", 0, &E.codebook)) return rc;
+    E.n_code = (int)(v->staged["quantizer.vq.layers.0._codebook.embed"].second / 768);
+    const std::string m = "enc_p.mrte.";
+    if (int rc = conv(E.c_pre, m + "c_pre", 512, Hc, 1)) return rc;
+    if (int rc = conv(E.text_pre, m + "text_pre", 512, Hc, 1)) return rc;
+    if (int rc = conv(E.c_post, m + "c_post", Hc, 512, 1)) return rc;
+    if (int rc = conv(E.xq, m + "cross_attention.conv_q", 512, 512, 1)) return rc;
+    if (int rc = stacked(E.xkv, {m + "cross_attention.conv_k", m + "cross_attention.conv_v"}, 512, 512)) return rc;
+    if (int rc = conv(E.xo, m + "cross_attention.conv_o", 512, 512, 1)) return rc;
+    if (int rc = conv(E.proj, "enc_p.proj", 2 * v->cfg.inter_channels, Hc, 1)) return rc;
+    E.ready = true;
+    return GSV_OK;
+}
+
+void encp_free(gsv_voc* v) {
+    EncP& E = v->enc;
+    for (PackedConv* p : {&E.ssl_proj, &E.c_pre, &E.text_pre, &E.c_post, &E.proj, &E.xq, &E.xkv, &E.xo}) free_conv(*p);
+    for (auto* Ls : {&E.ssl, &E.text, &E.enc2})
+        for (EncLayer& L : *Ls) { free_conv(L.qkv); free_conv(L.o); free_conv(L.c1); free_conv(L.c2); }
+    for (float* p : E.owned) (void)hipFree(p);
+    E.owned.clear();
+    E.ready = false;
+}
+
+// ---- enc_p (bf16): run ------------------------------------------------------------------------
+struct EncWs {
+    bf16_t *y768, *y, *t, *qkv, *att, *tmp, *ffn, *ssl512, *text512, *xq, *xkv, *xatt, *xo, *xsum;
+    float* stats;
+    size_t bytes;
+};
+EncWs encp_layout(const gsv_voc* v, int T, int P, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    const int Hc = v->cfg.hidden_channels, R = std::max(T, P);
+    EncWs w;
+    w.y768 = (bf16_t*)take(2 * (size_t)T * 768);
+    w.y = (bf16_t*)take(2 * (size_t)T * Hc);
+    w.t = (bf16_t*)take(2 * (size_t)P * Hc);
+    w.qkv = (bf16_t*)take(2 * (size_t)R * 3 * Hc);
+    w.att = (bf16_t*)take(2 * (size_t)R * Hc);
+    w.tmp = (bf16_t*)take(2 * (size_t)R * Hc);
+    w.ffn = (bf16_t*)take(2 * (size_t)R * 4 * Hc);
+    w.ssl512 = (bf16_t*)take(2 * (size_t)T * 512);
+    w.text512 = (bf16_t*)take(2 * (size_t)P * 512);
+    w.xq = (bf16_t*)take(2 * (size_t)T * 512);
+    w.xkv = (bf16_t*)take(2 * (size_t)P * 1024);
+    w.xatt = (bf16_t*)take(2 * (size_t)T * 512);
+    w.xo = (bf16_t*)take(2 * (size_t)T * 512);
+    w.xsum = (bf16_t*)take(2 * (size_t)T * 512);
+    w.stats = (float*)take(4 * (size_t)T * 2 * v->cfg.inter_channels);
+    w.bytes = off;
+    return w;
+}
+
+int encp_encoder(gsv_voc* v, std::vector<EncLayer>& Ls, bf16_t* x, int R, EncWs& w, hipStream_t st) {
+    const int Hc = v->cfg.hidden_channels;
+    for (EncLayer& L : Ls) {
+        Epi e0;
+        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.qkv, x, Hc, R, w.qkv, 3 * Hc, R, e0, st)) return rc;
+        EncAttnArgs a;
+        a.Q = w.qkv; a.ldq = 3 * Hc; a.K = w.qkv; a.ldk = 3 * Hc; a.V = w.qkv; a.ldv = 3 * Hc;
+        a.qoff = 0; a.koff = Hc; a.voff = 2 * Hc; a.O = w.att; a.ldo = Hc; a.Tq = R; a.Tk = R; a.H = 2;
+        a.scale = 1.0f / sqrtf((float)(Hc / 2)); a.relk = L.relk; a.relv = L.relv; a.window = 4; a.slice = nullptr; a.P = nullptr;
+        hipLaunchKernelGGL(encp_attn_kernel<96>, dim3(2, cdiv(R, 128)), dim3(256), 0, st, a);
+        Epi e1; e1.res = x; e1.ld_res = Hc;
+        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.o, w.att, Hc, R, w.tmp, Hc, R, e1, st)) return rc;
+        hipLaunchKernelGGL(encp_ln_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const bf16_t*)w.tmp, (const float*)L.g1, (const float*)L.b1, x, R, Hc);
+        Epi e2; e2.act = ACT_RELU;
+        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.c1, x, Hc, R, w.ffn, 4 * Hc, R, e2, st)) return rc;
+        Epi e3; e3.res = x; e3.ld_res = Hc;
+        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.c2, w.ffn, 4 * Hc, R, w.tmp, Hc, R, e3, st)) return rc;
+        hipLaunchKernelGGL(encp_ln_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const bf16_t*)w.tmp, (const float*)L.g2, (const float*)L.b2, x, R, Hc);
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg,
+             const int64_t* slice, float* m_p, float* logs_p, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
+    EncP& E = v->enc;
+    const int Hc = v->cfg.hidden_channels, C = v->cfg.inter_channels, T = 2 * n_codes;
+    if (Hc != 192) return fail(GSV_ERR_ARG, "enc_p: hidden_channels %d (the attention kernel is built for 2 heads of 96)", Hc);
+    EncWs w = encp_layout(v, T, P, (char*)ws);
+    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "enc_p workspace %zu < %zu", ws_bytes, w.bytes);
+    hipLaunchKernelGGL(encp_gather_kernel, dim3(T), dim3(128), 0, st, codes, n_codes, E.n_code, (const float*)E.codebook, 768, 2, w.y768);
+    hipLaunchKernelGGL(encp_gather_kernel, dim3(P), dim3(96), 0, st, text, P, E.n_text, (const float*)E.text_emb, Hc, 1, w.t);
+    Epi e;
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.ssl_proj, w.y768, 768, T, w.y, Hc, T, e, st)) return rc;
+    if (int rc = encp_encoder(v, E.ssl, w.y, T, w, st)) return rc;
+    if (int rc = encp_encoder(v, E.text, w.t, P, w, st)) return rc;
+    // MRTE (mrte_model.py:20-38)
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.c_pre, w.y, Hc, T, w.ssl512, 512, T, e, st)) return rc;
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.text_pre, w.t, Hc, P, w.text512, 512, P, e, st)) return rc;
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xq, w.ssl512, 512, T, w.xq, 512, T, e, st)) return rc;
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xkv, w.text512, 512, P, w.xkv, 1024, P, e, st)) return rc;
+    EncAttnArgs a;
+    a.Q = w.xq; a.ldq = 512; a.K = w.xkv; a.ldk = 1024; a.V = w.xkv; a.ldv = 1024; a.qoff = 0; a.koff = 0; a.voff = 512;
+    a.O = w.xatt; a.ldo = 512; a.Tq = T; a.Tk = P; a.H = 4; a.scale = 1.0f / sqrtf(128.0f); a.relk = nullptr; a.relv = nullptr;
+    a.window = 0; a.slice = slice; a.P = attn;
+    hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 128)), dim3(256), 0, st, a);
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xo, w.xatt, 512, T, w.xo, 512, T, e, st)) return rc;
+    hipLaunchKernelGGL(encp_add3_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const bf16_t*)w.xo, (const bf16_t*)w.ssl512, ge512,
+                       Tg == 1 ? 0 : 512, w.xsum, T, 512);
+    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.c_post, w.xsum, 512, T, w.y, Hc, T, e, st)) return rc;
+    if (int rc = encp_encoder(v, E.enc2, w.y, T, w, st)) return rc;
+    if (int rc = run_conv<bf16_t, bf16_t, float>(E.proj, w.y, Hc, T, w.stats, 2 * C, T, e, st)) return rc;
+    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats, m_p, C, T, 2 * C);
+    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats + C, logs_p, C, T, 2 * C);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
 template <typename CT>
 int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
     const gsv_voc_config& c = v->cfg;
@@ -1270,6 +1474,7 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
             v->post_c = ch;
         }
     }
+    if (!rc && sizeof(CT) == 2 && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize(v, temps, st);
     (void)hipStreamSynchronize(st);
     for (float* t : temps) (void)hipFree(t);
     if (rc) return rc;
@@ -1292,6 +1497,7 @@ void voc_free(gsv_voc* v) {
         for (auto& p : F.rs_skip) free_conv(p);
     }
     free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post); free_conv(v->cond_all);
+    encp_free(v);
     if (v->post_w) (void)hipFree(v->post_w);
     v->post_w = nullptr;
     for (VocStage& s : v->stages) {
@@ -1333,7 +1539,8 @@ int gsv_voc_load_tensor(gsv_voc* v, const char* name, const float* data, int64_t
     if (!v || !name || !data || numel < 1) return fail(GSV_ERR_ARG, "null argument");
     if (v->finalized) return fail(GSV_ERR_STATE, "vocoder already finalized");
     std::string n(name);
-    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0) return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow/dec", name);
+    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0 && n.compare(0, 6, "enc_p.") != 0 && n.compare(0, 10, "quantizer.") != 0)
+        return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow / dec / enc_p / quantizer", name);
     auto it = v->staged.find(n);
     if (it != v->staged.end()) { (void)hipFree(it->second.first); v->staged.erase(it); }
     float* p;
@@ -1347,6 +1554,23 @@ int gsv_voc_finalize(gsv_voc* v, void* stream) {
     if (!v) return fail(GSV_ERR_ARG, "null handle");
     if (v->finalized) return GSV_OK;
     return v->cfg.dtype == GSV_BF16 ? voc_finalize_impl<bf16_t>(v, S(stream)) : voc_finalize_impl<float>(v, S(stream));
+}
+
+int gsv_voc_has_enc_p(gsv_voc* v) { return v && v->finalized && v->enc.ready ? 1 : 0; }
+
+size_t gsv_voc_enc_workspace(gsv_voc* v, int n_codes, int n_text) {
+    if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1) return 0;
+    return encp_layout(v, 2 * n_codes, n_text, nullptr).bytes;
+}
+
+int gsv_voc_enc_p(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge512, int Tg,
+                  const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    if (!v || !v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
+    if (!v->enc.ready) return fail(GSV_ERR_STATE, "enc_p tensors were not loaded (or the handle is not bf16)");
+    if (!codes || !text || !ge512 || !m_p || !logs_p || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != 2 * n_codes)) return fail(GSV_ERR_ARG, "enc_p: bad lengths");
+    return encp_run(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
 }
 
 size_t gsv_voc_workspace(gsv_voc* v, int T) {

@@ -21,7 +21,7 @@ EXPORTS = [
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_decode_hidden",
     "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_megastep_error",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
-    "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec",
+    "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
         "gsv_voc_flow_dec": [vp, vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_flow": [vp, vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_dec": [vp, vp, vp, i, i, vp, vp, sz, vp],
+        "gsv_voc_has_enc_p": [vp],
+        "gsv_voc_enc_p": [vp, vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, sz, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -89,6 +91,8 @@ def lib():
     L.gsv_t2s_prefill_workspace.restype = sz
     L.gsv_voc_workspace.argtypes = [vp, i]
     L.gsv_voc_workspace.restype = sz
+    L.gsv_voc_enc_workspace.argtypes = [vp, i, i]
+    L.gsv_voc_enc_workspace.restype = sz
     _LIB = L
     return L
 

@@ -58,12 +58,15 @@ class _VocoderNative:
         self._h = h
         stream = N.current_stream_ptr(self.device)
         for name, t in weights.items():
-            if not (name.startswith("dec.") or name.startswith("flow.")):
+            enc = name.startswith("enc_p.") or name == "quantizer.vq.layers.0._codebook.embed"
+            if not (name.startswith("dec.") or name.startswith("flow.") or (enc and dtype == torch.bfloat16)):
                 continue
             d = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
             N.check(L.gsv_voc_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
         N.check(L.gsv_voc_finalize(h, stream))
         self._ws = None
+        self._ews = None
+        self.has_enc_p = bool(L.gsv_voc_has_enc_p(h))
 
     def __del__(self):
         try:
@@ -107,6 +110,29 @@ class _VocoderNative:
                                      ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
         return out
 
+    def enc_p(self, codes, text, ge512, slice_indices=None):
+        """codes int64 [N], text int64 [P], ge512 fp32 [1, 512, Tg] -> m_p, logs_p [1, inter, 2N], attn [4, 2N, P]"""
+        L = N.lib()
+        codes = codes.to(device=self.device, dtype=torch.int64).contiguous()
+        text = text.to(device=self.device, dtype=torch.int64).contiguous()
+        n, P = codes.numel(), text.numel()
+        T = 2 * n
+        g = ge512.to(device=self.device, dtype=torch.float32)[0].transpose(0, 1).contiguous()   # [Tg][512]
+        Tg = g.shape[0]
+        sl = None if slice_indices is None else slice_indices.to(device=self.device, dtype=torch.int64).contiguous()
+        m_p = torch.empty(1, self.inter, T, dtype=torch.float32, device=self.device)
+        logs_p = torch.empty_like(m_p)
+        attn = torch.empty(4, T, P, dtype=torch.float32, device=self.device)
+        need = L.gsv_voc_enc_workspace(self._h, n, P)
+        if need == 0:
+            raise RuntimeError("gsv_voc_enc_workspace failed")
+        if self._ews is None or self._ews.numel() < need:
+            self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)
+        N.check(L.gsv_voc_enc_p(self._h, codes.data_ptr(), n, text.data_ptr(), P, g.data_ptr(), Tg,
+                                0 if sl is None else sl.data_ptr(), m_p.data_ptr(), logs_p.data_ptr(), attn.data_ptr(),
+                                self._ews.data_ptr(), self._ews.numel(), N.current_stream_ptr(self.device)))
+        return m_p, logs_p, attn
+
     def dec(self, z, ge):
         z, ge, T, Tg = self._prep(z, ge)
         out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
@@ -140,6 +166,7 @@ class SynthesizerTrn:
         self._weights = None
         self._voc = None
         self.enc_p = None
+        self.native_enc_p = True   # bf16: run enc_p on device when its tensors are loaded (fp32 keeps the torch path)
 
     def load_state_dict(self, sd, strict=False):
         self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
@@ -177,14 +204,20 @@ class SynthesizerTrn:
         if self.enc_p is None:
             raise RuntimeError("decode() needs the enc_p / quantizer tensors in the state dict")
         w = self._weights
-        quantized = self._codebook_decode(w, codes.to(self.device))
-        quantized = F.interpolate(quantized, size=quantized.shape[-1] * 2, mode="nearest")
         ge = ge.to(device=self.device, dtype=torch.float32)
         if ge.shape[-1] != 1:
             ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
         ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
-        m_p, logs_p, y_mask = self.enc_p.infer(quantized, text.to(self.device), ge_in, speed, stream_mode,
-                                               valid_start_idx, overlap_len, slice_indices)
+        if self.native_enc_p and self._voc.has_enc_p and speed == 1 and not stream_mode and codes.shape[0] == 1 and codes.shape[1] == 1:
+            # enc_p on device (csrc/encp.h): quantizer lookup, x2 upsampling, the three encoders and MRTE
+            m_p, logs_p, attn = self._voc.enc_p(codes[0, 0], text[0], ge_in, slice_indices)
+            y_mask = torch.ones(1, 1, m_p.shape[-1], dtype=torch.float32, device=self.device)
+            self.enc_p.mrte.cross_attention.attn = attn[None]
+        else:
+            quantized = self._codebook_decode(w, codes.to(self.device))
+            quantized = F.interpolate(quantized, size=quantized.shape[-1] * 2, mode="nearest")
+            m_p, logs_p, y_mask = self.enc_p.infer(quantized, text.to(self.device), ge_in, speed, stream_mode,
+                                                   valid_start_idx, overlap_len, slice_indices)
         if speed != 1 and ge.shape[-1] != 1:
             ge = F.interpolate(ge, size=m_p.shape[-1], mode="nearest")
         if noise_scale != 0:

@@ -158,8 +158,9 @@ typedef struct {
 /* replaces SynthesizerTrn.{flow,dec} construction + Loader.get_sovits_weights (Loader.py:59-103) */
 int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out);
 int gsv_voc_destroy(gsv_voc* h);
-/* fp32 device tensor under its state-dict name: "dec.*" (weight-norm removed, Loader.py:95) and
- * "flow.flows.{0,2,4,6}.*" (weight_g/weight_v still separate; folded by finalize) */
+/* fp32 device tensor under its state-dict name: "dec.*" (weight-norm removed, Loader.py:95),
+ * "flow.flows.{0,2,4,6}.*" (weight_g/weight_v still separate; folded by finalize) and, optionally,
+ * "enc_p.*" + "quantizer.vq.layers.0._codebook.embed" (enables gsv_voc_enc_p on bf16 handles) */
 int gsv_voc_load_tensor(gsv_voc* h, const char* name, const float* data, int64_t numel, void* stream);
 int gsv_voc_finalize(gsv_voc* h, void* stream);
 
@@ -176,6 +177,20 @@ int gsv_voc_flow(gsv_voc* h, const float* z_p, const float* y_mask, const float*
                  float* z_out, void* workspace, size_t workspace_bytes, void* stream);
 int gsv_voc_dec(gsv_voc* h, const float* z, const float* ge, int T, int Tg, float* out, void* workspace,
                 size_t workspace_bytes, void* stream);
+
+/* enc_p on device (bf16 handles that were given the "enc_p.*" and "quantizer.vq.layers.0._codebook.embed"
+ * tensors): replaces quantizer.decode + the x2 nearest upsampling + TextEncoder.infer for speed == 1,
+ * non-streaming calls (SoVITS/models.py:196-224, 387-400; attentions.py:58-220; mrte_model.py:20-38).
+ *   codes int64 [n_codes], text int64 [n_text], ge512 fp32 channels-LAST [Tg][512] (ge_to512(ge) for v2Pro /
+ *   v2ProPlus, ge itself for v2), Tg in {1, 2*n_codes}; slice_indices int64 [2*n_codes][2] or NULL
+ *   (per-frame phoneme range of the time-concatenated batch, mrte_model.py:27-33)
+ *   -> m_p, logs_p fp32 [inter][T] channels-first, T = 2*n_codes; attn fp32 [4][T][n_text] or NULL
+ *   (enc_p.mrte.cross_attention.attn, read by TTS for subtitles).  y_mask is all ones (batch of one). */
+int gsv_voc_has_enc_p(gsv_voc* h);
+size_t gsv_voc_enc_workspace(gsv_voc* h, int n_codes, int n_text);
+int gsv_voc_enc_p(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge512, int Tg,
+                  const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 #ifdef __cplusplus
 }
