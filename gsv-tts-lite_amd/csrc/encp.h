@@ -66,53 +66,90 @@ struct EncAttnArgs {
     float* P;                      // [H][Tq][Tk] softmax probabilities (cross_attention.attn) or null
 };
 
-// One block = (head, 128 queries); a wave owns 32 queries.  Two passes over 32-key tiles staged in LDS:
-//   A  S^T = K Q^T on the matrix cores (+ relative-position logits, mask) -> row max m and row sum l
+// One block = (head, 32 queries); its 4 waves split the 32-key tiles between them (tile kt belongs to wave
+// kt % 4), each staging its own tiles in a wave-private LDS patch -- no block barrier inside the loops, and the
+// dependent chain is a quarter of the key tiles.  Two passes:
+//   A  S^T = K Q^T on the matrix cores (+ relative-position logits, mask) -> per-wave row max / row sum,
+//      merged across the waves through LDS
 //   B  S^T again, p = exp(s - m) / l -> optional P output, band probabilities for the relative-value term,
-//      O^T += V^T P^T with V^T staged key-permuted so the D registers feed the B operand directly.
+//      O^T += V^T P^T with V^T staged key-permuted so the D registers feed the B operand directly;
+//      the waves' partial O^T are summed through LDS.
+template <int D> constexpr int encp_attn_lds_bytes() {
+    return 4 * (32 * (D * 2 + 16) + D * (32 * 2 + 16)) + 4 * 32 * 9 * 4 + 32 * 9 * 4 + 2 * 4 * 32 * 4;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
     constexpr int KST = D / 16;                              // k-steps of the score product
     constexpr int MT = D / 32;                               // 32-row tiles of O^T
     constexpr int KRS = D * 2 + 16;                          // K tile row stride (bytes)
     constexpr int VRS = 32 * 2 + 16;                         // V^T tile row stride
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[32 * KRS];
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[D * VRS];
-    __shared__ float rl[128][9];                             // q_i . rel_k[b] * scale
-    __shared__ float pb[128][9];                             // p[i][i + b - w]
-    const int h = blockIdx.x, qb0 = blockIdx.y * 128;
+    constexpr int WB = 32 * KRS + D * VRS;                   // wave-private staging bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char alds[];
+    const int h = blockIdx.x, q0 = blockIdx.y * 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
-    const int q0 = qb0 + wid * 32;
+    unsigned char* Ks = alds + wid * WB;
+    unsigned char* Vt = Ks + 32 * KRS;
+    float* rl = reinterpret_cast<float*>(alds + 4 * WB) + wid * 32 * 9;    // [32][9] per wave: q_i . rel_k[b] * scale
+    float* pb = reinterpret_cast<float*>(alds + 4 * WB) + 4 * 32 * 9;      // [32][9] shared: p[i][i + b - w]
+    float* mls = pb + 32 * 9;                                               // [2][4][32] per-wave (m, l)
     const int i = q0 + j;                                    // the lane's query
     const int ic = min(i, a.Tq - 1);
     const int w = a.window;
     const float LOG2E = 1.4426950408889634f;
-    // Q fragments of the lane's query
     u32x4 qf[KST];
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks)
         qf[ks] = *reinterpret_cast<const u32x4*>(a.Q + (size_t)ic * a.ldq + a.qoff + h * D + ks * 16 + hf * 8);
-    for (int e = tid; e < 128 * 9; e += 256) { (&rl[0][0])[e] = 0.f; (&pb[0][0])[e] = 0.f; }
+    for (int e = tid; e < 32 * 9; e += 256) pb[e] = 0.f;
     int s0 = 0, s1 = a.Tk;
     if (a.slice) { s0 = (int)a.slice[(size_t)ic * 2]; s1 = (int)a.slice[(size_t)ic * 2 + 1]; }
     const int nkt = (a.Tk + 31) / 32;
 
-    auto stage_k = [&](const bf16_t* src, int ld, int off, int row0, int nrows_valid, bool is_rel) {
-        // 32 rows x D bf16 (rel: fp32 [9][D] -> bf16 rows 0..8, zeros after)
-        for (int e = tid; e < 32 * (D / 8); e += 256) {
-            const int r = e / (D / 8), cv = e % (D / 8);
-            u32x4 v = {0u, 0u, 0u, 0u};
+    // 32 rows x D bf16 into the wave's K patch (rel: fp32 [2w+1][D] -> bf16 rows, zeros after)
+    auto stage_k = [&](int row0, int nrows_valid, bool is_rel) {
+        constexpr int NV = 32 * (D / 8) / 64;                // vectors per lane
+        u32x4 v[NV];
+#pragma unroll
+        for (int x = 0; x < NV; ++x) {
+            const int e = lane + x * 64, r = e / (D / 8), cv = e % (D / 8);
+            v[x] = u32x4{0u, 0u, 0u, 0u};
             if (r < nrows_valid) {
                 if (is_rel) {
                     const float* rp = a.relk + (size_t)r * D + cv * 8;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) v[x] = pack_bf16x2(rp[2 * x], rp[2 * x + 1]);
+                    for (int y = 0; y < 4; ++y) v[x][y] = pack_bf16x2(rp[2 * y], rp[2 * y + 1]);
                 } else {
-                    v = *reinterpret_cast<const u32x4*>(src + (size_t)(row0 + r) * ld + off + h * D + cv * 8);
+                    v[x] = *reinterpret_cast<const u32x4*>(a.K + (size_t)(row0 + r) * a.ldk + a.koff + h * D + cv * 8);
                 }
             }
-            *reinterpret_cast<u32x4*>(Ks + r * KRS + cv * 16) = v;
+        }
+#pragma unroll
+        for (int x = 0; x < NV; ++x) {
+            const int e = lane + x * 64;
+            *reinterpret_cast<u32x4*>(Ks + (e / (D / 8)) * KRS + (e % (D / 8)) * 16) = v[x];
+        }
+    };
+    auto stage_v = [&](int row0, int nrows_valid) {          // V^T tile, keys permuted into D-register order
+        constexpr int NV = 32 * (D / 8) / 64;
+        u32x4 v[NV];
+#pragma unroll
+        for (int x = 0; x < NV; ++x) {
+            const int e = lane + x * 64, r = e / (D / 8), cv = e % (D / 8);
+            v[x] = u32x4{0u, 0u, 0u, 0u};
+            if (r < nrows_valid) v[x] = *reinterpret_cast<const u32x4*>(a.V + (size_t)(row0 + r) * a.ldv + a.voff + h * D + cv * 8);
+        }
+#pragma unroll
+        for (int x = 0; x < NV; ++x) {
+            const int e = lane + x * 64, r = e / (D / 8), cv = e % (D / 8);
+            const int hh = (r >> 2) & 1, blk = r >> 3;
+            const int pos = (blk >> 1) * 16 + 8 * hh + (r & 3) + 4 * (blk & 1);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * y) * VRS + pos * 2) = (bf16_t)(v[x][y] & 0xffff);
+                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * y + 1) * VRS + pos * 2) = (bf16_t)(v[x][y] >> 16);
+            }
         }
     };
     auto scores = [&](f32x16& s) {
@@ -125,34 +162,30 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
         }
     };
 
-    // ---- relative-position logits: one extra "key tile" holding rel_k
+    // ---- relative-position logits: one extra "key tile" holding rel_k (every wave keeps its own copy)
     if (a.relk) {
-        __syncthreads();
-        stage_k(nullptr, 0, 0, 0, 2 * w + 1, true);
-        __syncthreads();
+        stage_k(0, 2 * w + 1, true);
         f32x16 s;
         scores(s);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int b = (q & 3) + 8 * (q >> 2) + 4 * hf;
-            if (b < 2 * w + 1) rl[wid * 32 + j][b] = s[q] * a.scale;
+            if (b < 2 * w + 1) rl[j * 9 + b] = s[q] * a.scale;
         }
     }
-    // score of (query i, key) with mask and relative logits; -1e30 = not visible
+    // score of (query i, key) with mask and relative logits, in the exp2 domain; -1e30 = not visible
     auto finish = [&](float raw, int key) -> float {
         if (key >= a.Tk || i >= a.Tq) return -1e30f;
         if (a.slice && !((key >= s0 && key < s1) || key == a.Tk - 1)) return -1e30f;
         float v = raw * a.scale;
         const int b = key - i + w;
-        if (a.relk && b >= 0 && b <= 2 * w) v += rl[wid * 32 + j][b];
+        if (a.relk && b >= 0 && b <= 2 * w) v += rl[j * 9 + b];
         return v * LOG2E;
     };
-    // ---- pass A: row max and row sum
+    // ---- pass A: row max and row sum over the wave's tiles, then across the waves
     float m = -1e30f, l = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
-        stage_k(a.K, a.ldk, a.koff, kt * 32, min(32, a.Tk - kt * 32), false);
-        __syncthreads();
+    for (int kt = wid; kt < nkt; kt += 4) {
+        stage_k(kt * 32, min(32, a.Tk - kt * 32), false);
         f32x16 s;
         scores(s);
         float sv[16], tm = -1e30f;
@@ -170,6 +203,17 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
         m = mn;
     }
     l += __shfl_xor(l, 32, 64);
+    if (hf == 0) { mls[wid * 32 + j] = m; mls[128 + wid * 32 + j] = l; }
+    __syncthreads();
+    {
+        float mg = -1e30f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) mg = fmaxf(mg, mls[x * 32 + j]);
+        float lg = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) lg += mls[128 + x * 32 + j] * __builtin_amdgcn_exp2f(mls[x * 32 + j] - mg);
+        m = mg; l = lg;
+    }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     // ---- pass B: probabilities, P output, band terms, O^T += V^T P^T
     f32x16 o[MT];
@@ -177,23 +221,10 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) o[t][q] = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+    for (int kt = wid; kt < nkt; kt += 4) {
         const int nv = min(32, a.Tk - kt * 32);
-        stage_k(a.K, a.ldk, a.koff, kt * 32, nv, false);
-        for (int e = tid; e < 32 * (D / 8); e += 256) {      // V^T tile, keys permuted into D-register order
-            const int r = e / (D / 8), cv = e % (D / 8);
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r < nv) v = *reinterpret_cast<const u32x4*>(a.V + (size_t)(kt * 32 + r) * a.ldv + a.voff + h * D + cv * 8);
-            const int hh = (r >> 2) & 1, blk = r >> 3;
-            const int pos = (blk >> 1) * 16 + 8 * hh + (r & 3) + 4 * (blk & 1);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * x) * VRS + pos * 2) = (bf16_t)(v[x] & 0xffff);
-                *reinterpret_cast<bf16_t*>(Vt + (cv * 8 + 2 * x + 1) * VRS + pos * 2) = (bf16_t)(v[x] >> 16);
-            }
-        }
-        __syncthreads();
+        stage_k(kt * 32, nv, false);
+        stage_v(kt * 32, nv);
         f32x16 s;
         scores(s);
         float p[16];
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
             p[q] = sv > -1e29f ? __builtin_amdgcn_exp2f(sv - m) * inv : 0.f;
             if (a.P && i < a.Tq && key < a.Tk) a.P[((size_t)h * a.Tq + i) * a.Tk + key] = p[q];
             const int b = key - i + w;
-            if (a.relv && b >= 0 && b <= 2 * w && key < a.Tk) pb[wid * 32 + j][b] = p[q];
+            if (a.relv && b >= 0 && b <= 2 * w && key < a.Tk) pb[j * 9 + b] = p[q];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -218,20 +249,29 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
             }
         }
     }
-    __syncthreads();                                         // band probabilities of both lane halves are in pb
-    if (i >= a.Tq) return;
-    // out[i][d] = O^T[d][i] + sum_b p[i][i+b-w] * rel_v[b][d]
+    // ---- sum the waves' partial O^T through LDS (the staging patches are free now), add the relative-value term
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(alds);             // [4 waves][MT][16][64]
 #pragma unroll
     for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[((wid * MT + t) * 16 + q) * 64 + lane] = o[t][q];
+    __syncthreads();
+    if (i >= a.Tq) return;
+    for (int t = wid; t < MT; t += 4) {                      // wave w finishes tile t = w
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = o[t][4 * g + e];
+            for (int e = 0; e < 4; ++e) {
+                const int q = 4 * g + e;
+                v[e] = (red[((0 * MT + t) * 16 + q) * 64 + lane] + red[((1 * MT + t) * 16 + q) * 64 + lane]) +
+                       (red[((2 * MT + t) * 16 + q) * 64 + lane] + red[((3 * MT + t) * 16 + q) * 64 + lane]);
+            }
             const int d0 = t * 32 + 8 * g + 4 * hf;
             if (a.relv) {
                 for (int b = 0; b <= 2 * w; ++b) {
-                    const float pw = pb[wid * 32 + j][b];
+                    const float pw = pb[j * 9 + b];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(pw, a.relv[(size_t)b * D + d0 + e], v[e]);
                 }
@@ -241,6 +281,7 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
             pk.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(a.O + (size_t)i * a.ldo + h * D + d0) = pk;
         }
+    }
 }
 
 }  // namespace gsv

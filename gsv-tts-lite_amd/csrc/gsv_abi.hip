@@ -1241,7 +1241,7 @@ int encp_encoder(gsv_voc* v, std::vector<EncLayer>& Ls, bf16_t* x, int R, EncWs&
         a.Q = w.qkv; a.ldq = 3 * Hc; a.K = w.qkv; a.ldk = 3 * Hc; a.V = w.qkv; a.ldv = 3 * Hc;
         a.qoff = 0; a.koff = Hc; a.voff = 2 * Hc; a.O = w.att; a.ldo = Hc; a.Tq = R; a.Tk = R; a.H = 2;
         a.scale = 1.0f / sqrtf((float)(Hc / 2)); a.relk = L.relk; a.relv = L.relv; a.window = 4; a.slice = nullptr; a.P = nullptr;
-        hipLaunchKernelGGL(encp_attn_kernel<96>, dim3(2, cdiv(R, 128)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(encp_attn_kernel<96>, dim3(2, cdiv(R, 32)), dim3(256), encp_attn_lds_bytes<96>(), st, a);
         Epi e1; e1.res = x; e1.ld_res = Hc;
         if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.o, w.att, Hc, R, w.tmp, Hc, R, e1, st)) return rc;
         hipLaunchKernelGGL(encp_ln_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const bf16_t*)w.tmp, (const float*)L.g1, (const float*)L.b1, x, R, Hc);
@@ -1262,6 +1262,8 @@ int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text,
     if (Hc != 192) return fail(GSV_ERR_ARG, "enc_p: hidden_channels %d (the attention kernel is built for 2 heads of 96)", Hc);
     EncWs w = encp_layout(v, T, P, (char*)ws);
     if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "enc_p workspace %zu < %zu", ws_bytes, w.bytes);
+    HIPCHK(hipFuncSetAttribute((const void*)encp_attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, encp_attn_lds_bytes<96>()));
+    HIPCHK(hipFuncSetAttribute((const void*)encp_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, encp_attn_lds_bytes<128>()));
     hipLaunchKernelGGL(encp_gather_kernel, dim3(T), dim3(128), 0, st, codes, n_codes, E.n_code, (const float*)E.codebook, 768, 2, w.y768);
     hipLaunchKernelGGL(encp_gather_kernel, dim3(P), dim3(96), 0, st, text, P, E.n_text, (const float*)E.text_emb, Hc, 1, w.t);
     Epi e;
@@ -1277,7 +1279,7 @@ int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text,
     a.Q = w.xq; a.ldq = 512; a.K = w.xkv; a.ldk = 1024; a.V = w.xkv; a.ldv = 1024; a.qoff = 0; a.koff = 0; a.voff = 512;
     a.O = w.xatt; a.ldo = 512; a.Tq = T; a.Tk = P; a.H = 4; a.scale = 1.0f / sqrtf(128.0f); a.relk = nullptr; a.relv = nullptr;
     a.window = 0; a.slice = slice; a.P = attn;
-    hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 128)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 32)), dim3(256), encp_attn_lds_bytes<128>(), st, a);
     if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xo, w.xatt, 512, T, w.xo, 512, T, e, st)) return rc;
     hipLaunchKernelGGL(encp_add3_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const bf16_t*)w.xo, (const bf16_t*)w.ssl512, ge512,
                        Tg == 1 ? 0 : 512, w.xsum, T, 512);
