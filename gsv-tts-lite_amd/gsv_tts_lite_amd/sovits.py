@@ -6,8 +6,9 @@ overlap_len, slice_indices) -> (o, attn)`, `flow_dec(z_p, y_mask, ge) -> o`, and
 TTS reads (`samples_per_frame`, `enc_p.y_overlap`, `enc_p.mrte.cross_attention.attn`).
 
 flow + Generator (models.py:58-65, 113-132 -- the >90% of vocoder time)
-run as hand-written HIP behind `gsv_voc_flow_dec`.  The text/ssl encoder `enc_p` (a "next"
-row) is plain torch in sovits_encoder.py.
+run as hand-written HIP behind `gsv_voc_flow_dec`.  The text/ssl encoder `enc_p` (SURVEY.md 8(f)
+rank 1) runs on device too in bf16 mode (`gsv_voc_enc_p`, csrc/encp.h); its torch restatement in
+sovits_encoder.py serves the fp32 parity mode, speed != 1 and streaming calls.
 """
 from __future__ import annotations
 
