@@ -278,6 +278,28 @@ def main():
         out["ttft_ms_p50"] = float(np.median(tt))
         log("ttft done")
 
+        # ---- extras (not part of `value`): default-parameter sampling, and time to first audio
+        # (first 25-token chunk + 50-frame vocoder pass)
+        try:
+            for _ in range(2):
+                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                tk = t2s.infer(x, y, bert, top_k=15, repetition_penalty=1.35)
+                torch.cuda.synchronize(dev); dt = time.perf_counter() - s0
+            out["sampled_top_k15_ms_per_token"] = dt * 1e3 / max(1, int(tk.shape[-1]))
+            z50, m50 = z_p[:, :, :50].contiguous(), mask[:, :, :50].contiguous()
+            ta = []
+            for _ in range(10):
+                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
+                t2s.prefill(1, 0, xy, xl, yl)
+                t2s._decode(1, 25)
+                voc.flow_dec(z50, m50, ge)
+                torch.cuda.synchronize(dev)
+                ta.append((time.perf_counter() - s0) * 1e3)
+            out["ttfa_ms_p50"] = float(np.median(ta))
+        except Exception as exc:   # extras must never cost the bench line
+            log("extras skipped: %r" % (exc,))
+
         # ---- roofline of the decode-step kernels (HIP events on the launch stream, live state: kv = 450)
         ms = (ctypes.c_float * 4)()
         N.check(N.lib().gsv_t2s_time_kernels(t2s._h, 1, 20, ms, N.current_stream_ptr(dev)))
