@@ -93,6 +93,7 @@ class Text2SemanticDecoder:
         # persistent decode step (csrc/t2s_megastep.h, batch <= 4): correct and stress-tested, but measured
         # equal-to-slightly-slower than the per-layer graph (hand-off ~= kernel boundary), so off by default
         self.use_megastep = False
+        self._eos_pipe = None
         self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
         self._weights = None
         self._h = None
@@ -285,14 +286,33 @@ class Text2SemanticDecoder:
         done = 0
         eos_at = -1
         if greedy:
+            # The reference tests for EOS on the host every `check_interval` steps (t2s_model.py:451-453).  Same
+            # cadence here, but the test of chunk i is read AFTER chunk i+1 has been enqueued (async copy of the
+            # flag into pinned memory + an event), so the GPU never idles on the host round trip.  A chunk that
+            # runs past the EOS costs nothing observable: tokens are cut at the first EOS anyway (:459-462).
+            if self._eos_pipe is None:
+                self._eos_pipe = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            pending = None
+            k = 0
             while done < n_iter:
                 n = min(check_interval, n_iter - done)
                 self._decode(1, n)
                 done += n
                 self._flush(1)
-                eos_at = int(rt["eos_at"][0].item())  # host sync every check_interval steps, like the reference
-                if eos_at >= 0:
-                    break
+                buf, ev = self._eos_pipe[k]
+                k ^= 1
+                buf.copy_(rt["eos_at"][:1], non_blocking=True)
+                ev.record()
+                if pending is not None:
+                    pending[1].synchronize()
+                    if int(pending[0][0]) >= 0:
+                        eos_at = int(pending[0][0])
+                        pending = None
+                        break
+                pending = (buf, ev)
+            if pending is not None:
+                pending[1].synchronize()
+                eos_at = int(pending[0][0])
         else:
             while done < n_iter:
                 tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
