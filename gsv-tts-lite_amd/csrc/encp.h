@@ -40,6 +40,31 @@ __global__ __launch_bounds__(256) void encp_ln_kernel(const bf16_t* __restrict__
     for (int c = lane; c < C; c += 64) { y[(size_t)row * C + c] = f32_to_bf16(v[n] * rs * gamma[c] + beta[c]); ++n; }
 }
 
+// y[t] = LN(sum_s P[s][t] + bias + res[t]) * gamma + beta : consumer of rowgemm's raw (split) fp32 tiles in the encoder
+// layers (x = LN(x + attn_out), x = LN(x + ffn_out), attentions.py:88-101); y may alias res row-wise
+__global__ __launch_bounds__(256) void encp_ln_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
+                                                          const float* __restrict__ bias, const bf16_t* res,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* y, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8];
+    int n = 0;
+    for (int c = lane; c < C; c += 64) {
+        float s = P[(size_t)row * C + c];
+        for (int k = 1; k < nsplit; ++k) s += P[(size_t)k * split_stride + (size_t)row * C + c];
+        v[n++] = s + bias[c] + bf16_to_f32(res[(size_t)row * C + c]);
+    }
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+    n = 0;
+    for (int c = lane; c < C; c += 64) { y[(size_t)row * C + c] = f32_to_bf16(v[n] * rs * gamma[c] + beta[c]); ++n; }
+}
+
 // a + b (+ per-row or broadcast fp32 row g) -> bf16 : the MRTE sum  attn_out + ssl_enc + ge  (mrte_model.py:35-36)
 __global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg,
                                  bf16_t* __restrict__ y, int rows, int C) {

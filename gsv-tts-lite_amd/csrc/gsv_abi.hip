@@ -530,7 +530,8 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         auto gemm = [&](auto kern, const void* X, int ldx, const PackedConv& pc, const float* bias, int relu, void* Y, int ldy,
                         int nsplit, size_t split_stride) {
             RowGemmArgs ra;
-            ra.X = X; ra.ldx = ldx; ra.M = M; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.bias = bias; ra.relu = relu;
+            ra.X = X; ra.ldx = ldx; ra.M = M; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
+            ra.bias = bias; ra.relu = relu;
             ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
             hipLaunchKernelGGL(kern, dim3(rtiles, pc.mtiles, nsplit), dim3(256), 0, st, ra);
         };
@@ -897,7 +898,8 @@ template <typename AT>
 int run_cond(const PackedConv& pc, const void* X, int ldx, int rows, float* Y, int ldy, hipStream_t st) {
     if (sizeof(AT) == 2 && pc.u == 0 && pc.k == 1 && (pc.cin == 512 || pc.cin == 1024)) {
         RowGemmArgs ra;
-        ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.bias = pc.bias; ra.relu = 0;
+        ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
+        ra.bias = pc.bias; ra.relu = 0;
         ra.Y = Y; ra.ldy = ldy; ra.split_stride = 0;
         const dim3 grid(cdiv(rows, 32), pc.mtiles, 1);
         if (pc.cin == 512) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 8>), grid, dim3(256), 0, st, ra);
@@ -1205,7 +1207,7 @@ void encp_free(gsv_voc* v) {
 // ---- enc_p (bf16): run ------------------------------------------------------------------------
 struct EncWs {
     bf16_t *y768, *y, *t, *qkv, *att, *tmp, *ffn, *ssl512, *text512, *xq, *xkv, *xatt, *xo, *xsum;
-    float* stats;
+    float *stats, *part;
     size_t bytes;
 };
 EncWs encp_layout(const gsv_voc* v, int T, int P, char* base) {
@@ -1228,28 +1230,50 @@ EncWs encp_layout(const gsv_voc* v, int T, int P, char* base) {
     w.xo = (bf16_t*)take(2 * (size_t)T * 512);
     w.xsum = (bf16_t*)take(2 * (size_t)T * 512);
     w.stats = (float*)take(4 * (size_t)T * 2 * v->cfg.inter_channels);
+    w.part = (float*)take(4 * (size_t)3 * R * Hc);
     w.bytes = off;
     return w;
 }
 
+// dense layer of enc_p on the latency-shaped rowgemm (bf16 in; bf16 or raw fp32 split partials out)
+int enc_gemm(const PackedConv& pc, const bf16_t* X, int ldx, int rows, bool with_bias, int relu, void* Y, int ldy, bool out_f32,
+             int nsplit, size_t split_stride, hipStream_t st) {
+    RowGemmArgs ra;
+    ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = pc.ntaps; ra.pad = pc.pad;
+    ra.mtiles = pc.mtiles; ra.bias = with_bias ? pc.bias : nullptr; ra.relu = relu; ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
+    const int total = pc.ntaps * (pc.cin / 16);
+    if (pc.u != 0 || pc.dil != 1 || total % (4 * nsplit) != 0 || pc.cout % 32 != 0) return fail(GSV_ERR_ARG, "enc_p: layer shape does not fit rowgemm");
+    const int kpw = total / (4 * nsplit);
+    const dim3 grid(cdiv(rows, 32), pc.mtiles, nsplit);
+#define GSV_ENC_GEMM(K)                                                                                            \
+    if (kpw == K) {                                                                                                  \
+        if (out_f32) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, K>), grid, dim3(256), 0, st, ra);              \
+        else hipLaunchKernelGGL((rowgemm_kernel<bf16_t, bf16_t, K>), grid, dim3(256), 0, st, ra);                    \
+        return GSV_OK;                                                                                               \
+    }
+    GSV_ENC_GEMM(3) GSV_ENC_GEMM(8) GSV_ENC_GEMM(9) GSV_ENC_GEMM(12)
+#undef GSV_ENC_GEMM
+    return fail(GSV_ERR_ARG, "enc_p: no rowgemm instantiation for %d k-steps per wave", kpw);
+}
+
 int encp_encoder(gsv_voc* v, std::vector<EncLayer>& Ls, bf16_t* x, int R, EncWs& w, hipStream_t st) {
     const int Hc = v->cfg.hidden_channels;
+    float* part = w.part;                                    // raw fp32 tiles: [3][R][Hc]
+    const size_t ps = (size_t)R * Hc;
     for (EncLayer& L : Ls) {
-        Epi e0;
-        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.qkv, x, Hc, R, w.qkv, 3 * Hc, R, e0, st)) return rc;
+        if (int rc = enc_gemm(L.qkv, x, Hc, R, true, 0, w.qkv, 3 * Hc, false, 1, 0, st)) return rc;
         EncAttnArgs a;
         a.Q = w.qkv; a.ldq = 3 * Hc; a.K = w.qkv; a.ldk = 3 * Hc; a.V = w.qkv; a.ldv = 3 * Hc;
         a.qoff = 0; a.koff = Hc; a.voff = 2 * Hc; a.O = w.att; a.ldo = Hc; a.Tq = R; a.Tk = R; a.H = 2;
         a.scale = 1.0f / sqrtf((float)(Hc / 2)); a.relk = L.relk; a.relv = L.relv; a.window = 4; a.slice = nullptr; a.P = nullptr;
         hipLaunchKernelGGL(encp_attn_kernel<96>, dim3(2, cdiv(R, 32)), dim3(256), encp_attn_lds_bytes<96>(), st, a);
-        Epi e1; e1.res = x; e1.ld_res = Hc;
-        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.o, w.att, Hc, R, w.tmp, Hc, R, e1, st)) return rc;
-        hipLaunchKernelGGL(encp_ln_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const bf16_t*)w.tmp, (const float*)L.g1, (const float*)L.b1, x, R, Hc);
-        Epi e2; e2.act = ACT_RELU;
-        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.c1, x, Hc, R, w.ffn, 4 * Hc, R, e2, st)) return rc;
-        Epi e3; e3.res = x; e3.ld_res = Hc;
-        if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(L.c2, w.ffn, 4 * Hc, R, w.tmp, Hc, R, e3, st)) return rc;
-        hipLaunchKernelGGL(encp_ln_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const bf16_t*)w.tmp, (const float*)L.g2, (const float*)L.b2, x, R, Hc);
+        if (int rc = enc_gemm(L.o, w.att, Hc, R, false, 0, part, Hc, true, 1, 0, st)) return rc;
+        hipLaunchKernelGGL(encp_ln_sum_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const float*)part, 1, (size_t)0, (const float*)L.o.bias,
+                           (const bf16_t*)x, (const float*)L.g1, (const float*)L.b1, x, R, Hc);
+        if (int rc = enc_gemm(L.c1, x, Hc, R, true, 1, w.ffn, 4 * Hc, false, 1, 0, st)) return rc;
+        if (int rc = enc_gemm(L.c2, w.ffn, 4 * Hc, R, false, 0, part, Hc, true, 3, ps, st)) return rc;
+        hipLaunchKernelGGL(encp_ln_sum_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const float*)part, 3, ps, (const float*)L.c2.bias,
+                           (const bf16_t*)x, (const float*)L.g2, (const float*)L.b2, x, R, Hc);
     }
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -1266,26 +1290,25 @@ int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text,
     HIPCHK(hipFuncSetAttribute((const void*)encp_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, encp_attn_lds_bytes<128>()));
     hipLaunchKernelGGL(encp_gather_kernel, dim3(T), dim3(128), 0, st, codes, n_codes, E.n_code, (const float*)E.codebook, 768, 2, w.y768);
     hipLaunchKernelGGL(encp_gather_kernel, dim3(P), dim3(96), 0, st, text, P, E.n_text, (const float*)E.text_emb, Hc, 1, w.t);
-    Epi e;
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.ssl_proj, w.y768, 768, T, w.y, Hc, T, e, st)) return rc;
+    if (int rc = enc_gemm(E.ssl_proj, w.y768, 768, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
     if (int rc = encp_encoder(v, E.ssl, w.y, T, w, st)) return rc;
     if (int rc = encp_encoder(v, E.text, w.t, P, w, st)) return rc;
     // MRTE (mrte_model.py:20-38)
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.c_pre, w.y, Hc, T, w.ssl512, 512, T, e, st)) return rc;
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.text_pre, w.t, Hc, P, w.text512, 512, P, e, st)) return rc;
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xq, w.ssl512, 512, T, w.xq, 512, T, e, st)) return rc;
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xkv, w.text512, 512, P, w.xkv, 1024, P, e, st)) return rc;
+    if (int rc = enc_gemm(E.c_pre, w.y, Hc, T, true, 0, w.ssl512, 512, false, 1, 0, st)) return rc;
+    if (int rc = enc_gemm(E.text_pre, w.t, Hc, P, true, 0, w.text512, 512, false, 1, 0, st)) return rc;
+    if (int rc = enc_gemm(E.xq, w.ssl512, 512, T, true, 0, w.xq, 512, false, 1, 0, st)) return rc;
+    if (int rc = enc_gemm(E.xkv, w.text512, 512, P, true, 0, w.xkv, 1024, false, 1, 0, st)) return rc;
     EncAttnArgs a;
     a.Q = w.xq; a.ldq = 512; a.K = w.xkv; a.ldk = 1024; a.V = w.xkv; a.ldv = 1024; a.qoff = 0; a.koff = 0; a.voff = 512;
     a.O = w.xatt; a.ldo = 512; a.Tq = T; a.Tk = P; a.H = 4; a.scale = 1.0f / sqrtf(128.0f); a.relk = nullptr; a.relv = nullptr;
     a.window = 0; a.slice = slice; a.P = attn;
     hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 32)), dim3(256), encp_attn_lds_bytes<128>(), st, a);
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.xo, w.xatt, 512, T, w.xo, 512, T, e, st)) return rc;
+    if (int rc = enc_gemm(E.xo, w.xatt, 512, T, true, 0, w.xo, 512, false, 1, 0, st)) return rc;
     hipLaunchKernelGGL(encp_add3_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const bf16_t*)w.xo, (const bf16_t*)w.ssl512, ge512,
                        Tg == 1 ? 0 : 512, w.xsum, T, 512);
-    if (int rc = run_conv<bf16_t, bf16_t, bf16_t>(E.c_post, w.xsum, 512, T, w.y, Hc, T, e, st)) return rc;
+    if (int rc = enc_gemm(E.c_post, w.xsum, 512, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
     if (int rc = encp_encoder(v, E.enc2, w.y, T, w, st)) return rc;
-    if (int rc = run_conv<bf16_t, bf16_t, float>(E.proj, w.y, Hc, T, w.stats, 2 * C, T, e, st)) return rc;
+    if (int rc = enc_gemm(E.proj, w.y, Hc, T, true, 0, w.stats, 2 * C, true, 1, 0, st)) return rc;
     hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats, m_p, C, T, 2 * C);
     hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats + C, logs_p, C, T, 2 * C);
     HIPCHK(hipGetLastError());

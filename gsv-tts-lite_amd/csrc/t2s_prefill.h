@@ -303,8 +303,10 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnM
 struct RowGemmArgs {
     const void* X;        // [M][ldx], float or bf16
     int ldx, M;
-    const uint4* W;       // fragments [mtile][ksteps][64 lanes]
-    int ksteps;           // K / 16
+    const uint4* W;       // fragments [tap][mtile][kpt][64 lanes]
+    int ksteps;           // k-steps per tap (cin / 16)
+    int ntaps, pad;       // Conv1d over the rows: tap t reads row + t - pad (zero outside [0, M)); 1 / 0 for a GEMM
+    int mtiles;
     const float* bias;    // epilogue (only for nsplit == 1): + bias, ReLU
     int relu;
     void* Y;              // [nsplit][M][ldy], float or bf16
@@ -312,29 +314,37 @@ struct RowGemmArgs {
     size_t split_stride;  // elements between the partial outputs of consecutive splits
 };
 
-template <typename XT, typename OT, int KPW = 8>       // KPW: k-steps per wave (K = 64 * KPW * nsplit channels)
+template <typename XT, typename OT, int KPW = 8>       // KPW: k-steps per wave (ntaps * ksteps = 4 * KPW * nsplit)
 __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     __shared__ float red[3][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
     const int rt = blockIdx.x, mt = blockIdx.y, sp = blockIdx.z;
-    const int row = min(rt * 32 + j, a.M - 1);
-    const int ks0 = (sp * 4 + wid) * KPW;
-    const uint4* wp = a.W + ((size_t)mt * a.ksteps + ks0) * 64 + lane;
+    const int row = rt * 32 + j;
+    const int g0 = (sp * 4 + wid) * KPW;                    // first global k-step of the wave: (tap, k-step) = (g / kpt, g % kpt)
     u32x4 wf[KPW], xf[KPW];
+    bool xok[KPW];
+    int xrow[KPW], xks[KPW];
 #pragma unroll
-    for (int s = 0; s < KPW; ++s) wf[s] = __builtin_bit_cast(u32x4, wp[(size_t)s * 64]);
+    for (int s = 0; s < KPW; ++s) {
+        const int g = g0 + s, tap = g / a.ksteps, kc = g - tap * a.ksteps;
+        wf[s] = __builtin_bit_cast(u32x4, a.W[(((size_t)tap * a.mtiles + mt) * a.ksteps + kc) * 64 + lane]);
+        const int r = row + tap - a.pad;
+        xok[s] = r >= 0 && r < a.M;
+        xrow[s] = min(max(r, 0), a.M - 1);
+        xks[s] = kc;
+    }
     if constexpr (sizeof(XT) == 2) {
-        const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.X) + (size_t)row * a.ldx + ks0 * 16 + hf * 8;
+        const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.X) + hf * 8;
 #pragma unroll
-        for (int s = 0; s < KPW; ++s) xf[s] = *reinterpret_cast<const u32x4*>(xp + s * 16);
+        for (int s = 0; s < KPW; ++s) xf[s] = *reinterpret_cast<const u32x4*>(xp + (size_t)xrow[s] * a.ldx + xks[s] * 16);
     } else {
-        const float* xp = reinterpret_cast<const float*>(a.X) + (size_t)row * a.ldx + ks0 * 16 + hf * 8;
+        const float* xp = reinterpret_cast<const float*>(a.X) + hf * 8;
         f32x4 lo[KPW], hi[KPW];
 #pragma unroll
         for (int s = 0; s < KPW; ++s) {
-            lo[s] = *reinterpret_cast<const f32x4*>(xp + s * 16);
-            hi[s] = *reinterpret_cast<const f32x4*>(xp + s * 16 + 4);
+            lo[s] = *reinterpret_cast<const f32x4*>(xp + (size_t)xrow[s] * a.ldx + xks[s] * 16);
+            hi[s] = *reinterpret_cast<const f32x4*>(xp + (size_t)xrow[s] * a.ldx + xks[s] * 16 + 4);
         }
 #pragma unroll
         for (int s = 0; s < KPW; ++s) {
@@ -348,7 +358,11 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-    for (int s = 0; s < KPW; ++s) Mma<bf16_t>::run(acc, wf[s], xf[s]);
+    for (int s = 0; s < KPW; ++s) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[s][e] = xok[s] ? xf[s][e] : 0u;
+        Mma<bf16_t>::run(acc, wf[s], xf[s]);
+    }
     // the 4 waves' partial tiles are summed in wave order by wave 0
     if (wid > 0) {
 #pragma unroll
@@ -360,8 +374,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     for (int w = 0; w < 3; ++w)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] += red[w][q][lane];
-    const int orow = rt * 32 + j;
-    if (orow >= a.M) return;
+    if (row >= a.M) return;
+    const int orow = row;
     const int ch = mt * 32 + 16 * hf;                      // register q = channel ch + q (packer's row permutation)
     float v[16];
 #pragma unroll
