@@ -148,8 +148,11 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
     const bool splitk = tiles11 < 256;
     const bool wide_m = !splitk && pc.mtiles >= 2 && tiles11 >= 1024;
     const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * nz >= 1024;
-    const int bn = splitk ? 32 : (wide_n ? 256 : 128);
-    const int kcb = wide_n ? 128 : 256;               // staged bytes per row per chunk
+    // mid-size problems (the 256-channel resblock stage: 5000 rows x 8 m-tiles x 3 branches): 64-row waves at two
+    // blocks per CU measured 40.9 us vs 48.8 us for the 32-row tile (tools/tg_bench.hip)
+    const bool mid_n = !splitk && !wide_m && !wide_n && (long)cdiv(n_rows, 256) * pc.mtiles * nz >= 256;
+    const int bn = splitk ? 32 : ((wide_n || mid_n) ? 256 : 128);
+    const int kcb = (wide_n || mid_n) ? 128 : 256;    // staged bytes per row per chunk
     size_t lds = (size_t)(bn + span) * (kcb + 16);
     if (splitk) lds = std::max(lds, (size_t)3 * 16 * 64 * sizeof(float));
     if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "tapgemm: tap span %d needs %zu B of LDS", span, lds);
@@ -164,6 +167,7 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
     else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), nz));
     else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), nz));
     else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
+    else if (mid_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false, 1, 2, 4>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
     else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, false>, dim3(cdiv(n_rows, 128), pc.mtiles, nz));
     if (rc) return rc;
     HIPCHK(hipGetLastError());
