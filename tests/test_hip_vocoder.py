@@ -128,3 +128,21 @@ def test_flow_bf16_fused_matches_reference_golden(golden_dir, dev, ver, T, tag):
     zf = v.flow(_T(g[name + "_z"], dev), torch.ones(1, 1, T, device=dev), _T(g[name + "_ge"], dev)).cpu().numpy()
     err = np.abs(zf - g[name + "_flow"])
     assert err.max() < 6e-2 and err.mean() < 6e-3, (err.max(), err.mean())
+
+
+def test_generator_bf16_wconv_odd_lengths_vs_oracle(dev):
+    """bf16 Generator (wconv / tapgemm / conv_post kernels) at lengths that leave ragged last tiles in every
+    stage (T = 1, 7, 131 -> 10 .. 83840 rows), broadcast and per-frame ge, against the fp32 oracle."""
+    from oracle import oracle as orc
+    v, hps, w = _voc("v2Pro", 13, torch.bfloat16, dev)
+    vo = orc.VocoderOracle(hps, w)
+    for T, per_frame in [(1, False), (7, True), (131, False)]:
+        z = synth.hashed_uniform("bfodd.z%d" % T, (1, 192, T), 13) * np.float32(1.2)
+        ge = synth.synth_ge(2, 1024, 13)
+        if per_frame:
+            ge = np.concatenate([np.repeat(synth.synth_ge(i, 1024, 13), n, axis=2) for i, n in ((2, 3), (5, T - 3))], axis=2)
+        ref = vo.dec(z[0], ge[0])
+        out = v.dec(_T(z, dev), _T(ge, dev))[0, 0].cpu().numpy()
+        assert out.shape == ref.shape and np.isfinite(out).all()
+        err = np.abs(out - ref)
+        assert err.max() < 8e-2 and err.mean() < 8e-3, (T, err.max(), err.mean())

@@ -33,6 +33,17 @@ for k, v in fetch.items():
     e["write_bytes_per_launch"] = (e["write_bytes_per_launch"] * n0 + w_bytes * n1) / (n0 + n1)
     e["launches"] = n0 + n1
 flat = {k: v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in out.items()}
+# whole flow + Generator pass: every launch of the vocoder-only kernel classes, divided by the number of passes
+# (one conv_post / one cl->cf per pass)
+def _is_voc(full):
+    return ("wconv_kernel" in full or "flowfuse_kernel" in full or "avg3_kernel" in full or "conv_post_kernel" in full
+            or "cf_to_cl_kernel" in full or ("tapgemm_kernel<unsigned short, unsigned short" in full)
+            or "rowgemm_kernel<unsigned short, float, 16>" in full)   # cond GEMV (gin 1024); <.., 8> is also the prefill's W2
+passes = sum(len(v) for k, v in fetch.items() if "conv_post_kernel" in k)
+if passes:
+    tot = sum(2.0 * 1024.0 * sum(v) for k, v in fetch.items() if _is_voc(k)) + sum(1024.0 * sum(v) for k, v in write.items() if _is_voc(k))
+    flat["vocoder_pass"] = tot / passes
+    flat["vocoder_passes_counted"] = passes
 json.dump({"_detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k]["launches"])[:12]:
     print("%-28s launches %6d  fetch %10.0f B  write %9.0f B" % (k, out[k]["launches"], out[k]["fetch_bytes_per_launch"], out[k]["write_bytes_per_launch"]))
