@@ -333,6 +333,67 @@ class Text2SemanticDecoder:
         out = rt["pre_tokens"][0, Lp + 1: Lp + 1 + n_valid].clone()
         return out.unsqueeze(0).unsqueeze(0)
 
+    def infer_stream(self, x, y, bert_feature, top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
+                     repetition_penalty: float = 1.35, initial_suppression_steps: int = 10, stream_chunk: int = 25,
+                     boost_first_chunk: bool = True, debug: bool = True, generator=None):
+        """t2s_model.py:466-553: generator of (cumulative tokens int64[1,1,n], is_final).  Same quirks as the
+        reference: chunks are cumulative and lag one chunk behind (the first is sent at once when
+        boost_first_chunk), EOS is never part of a chunk, and the final chunk after an EOS is the last `idx`
+        entries of y ++ samples, i.e. it starts with the first sample s0 that infer() drops.  The decode steps
+        run on device in groups of <= 5 (greedy / device sampling); a group that runs past the EOS is harmless."""
+        with torch.inference_mode():
+            rt = self._rt[1]
+            buckets = self.cuda_graph_buckets[1]
+            lx, ly = int(x.shape[1]), int(y.shape[1])
+            Lp = lx + ly
+            if Lp > buckets[-1].max_kv_cache:
+                raise ValueError("prompt of %d positions exceeds the largest KV bucket (%d)" % (Lp, buckets[-1].max_kv_cache))
+            n_iter = buckets[-1].max_kv_cache - Lp
+            if n_iter < 1:
+                raise RuntimeError("no decode iterations: prompt fills the largest bucket")
+            mode, seed = self._sampling_mode(top_k, top_p, generator)
+            rep_on = repetition_penalty != 1.0
+            self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed)
+            rt["seen"].zero_()
+            if rep_on:
+                rt["seen"][0, y[0].to(self.device)] = 1
+            xy, xl, yl, _, _ = self.embed_prompt([x[0]], [y[0]], [bert_feature[0]])
+            self.prefill(1, 0, xy, xl, yl)
+        done, first, pre_chunk = 0, True, None
+        while done < n_iter:
+            with torch.inference_mode():
+                to_boundary = stream_chunk - done % stream_chunk
+                n = min(5 if mode != 1 else 1, to_boundary, n_iter - done)
+                if mode == 1:
+                    tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
+                    rt["tok_override"].copy_(tok)
+                self._decode(1, n)
+                done += n
+                if mode == 1:
+                    tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
+                    rt["tok_override"].copy_(tok)
+                self._flush(1)      # materialises sample s_done; idempotent
+                eos_at = int(rt["eos_at"][0].item())
+                if eos_at >= 0:     # s_eos_at is the EOS: the reference breaks at idx = eos_at
+                    final = rt["pre_tokens"][0, Lp: Lp + eos_at].clone()
+                    break
+                chunk = None
+                if done % stream_chunk == 0:
+                    if pre_chunk is not None:
+                        chunk = pre_chunk
+                    pre_chunk = rt["pre_tokens"][0, Lp + 1: Lp + 1 + done].clone()
+            if done % stream_chunk == 0:
+                if chunk is not None:
+                    yield chunk[None, None], False
+                if boost_first_chunk and first:
+                    first = False
+                    yield pre_chunk[None, None], False
+                    pre_chunk = None
+        else:
+            with torch.inference_mode():
+                final = rt["pre_tokens"][0, Lp + 1: Lp + 1 + n_iter].clone()
+        yield final[None, None], True
+
     @torch.inference_mode()
     def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
                       top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,

@@ -129,6 +129,32 @@ def gen_t2s_infer(T2S):
     np.savez_compressed(os.path.join(GOLD, "t2s_infer.npz"), **META, **out)
 
 
+def gen_t2s_stream(T2S):
+    """greedy infer_stream() (t2s_model.py:466-553): every (cumulative chunk, is_final) the reference yields,
+    for a run that ends on EOS between chunk boundaries (the final chunk then still holds the first sample)
+    and a run that fills the cache; boost_first_chunk on and off."""
+    cfg = synth.gpt_config()
+    out = {}
+    for name, seed, eos_gain, p, t, n, buckets, chunk, boost in [("e", 31, 2.5, 8, 14, 20, [(1, 128)], 10, True),
+                                                                 ("f", 32, -8.0, 6, 9, 16, [(1, 64)], 8, False)]:
+        w = synth.gpt_weights(cfg, seed=seed, eos_gain=eos_gain)
+        m = build_ref_gpt(T2S, cfg, w, buckets)
+        x, y, bert, _ = synth.synth_request(3, p, t, n, seed=seed)
+        with torch.inference_mode():
+            chunks = list(m.infer_stream(tt(x)[None], tt(y)[None], tt(bert)[None], top_k=1, stream_chunk=chunk,
+                                         boost_first_chunk=boost, debug=False))
+        out[name + "_cfg"] = np.array([seed, p, t, n, chunk, int(boost)])
+        out[name + "_eos_gain"] = np.float32(eos_gain)
+        out[name + "_cache"] = np.array(buckets)
+        out[name + "_x"], out[name + "_y"] = x, y
+        out[name + "_n"] = np.array(len(chunks))
+        for i, (c, fin) in enumerate(chunks):
+            out["%s_chunk%d" % (name, i)] = c[0, 0].numpy()
+            out["%s_final%d" % (name, i)] = np.array(int(fin))
+        print("stream", name, [(len(c[0, 0]), bool(f)) for c, f in chunks])
+    np.savez_compressed(os.path.join(GOLD, "t2s_stream.npz"), **META, **out)
+
+
 def gen_t2s_batched(T2S):
     cfg = synth.gpt_config()
     out = {}
@@ -253,10 +279,11 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "sample", "vocoder", "decode"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
+    if "stream" in which: gen_t2s_stream(T2S)
     if "sample" in which: gen_sample(sample)
     if "vocoder" in which: gen_vocoder(Syn)
     if "decode" in which: gen_decode(Syn)

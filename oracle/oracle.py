@@ -263,6 +263,50 @@ class T2SOracle:
         e = np.nonzero(out == self.EOS)[0]
         return out[: e[0]] if e.size else out
 
+    def infer_stream(self, x, y, bert, top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35,
+                     initial_suppression_steps=10, stream_chunk=25, boost_first_chunk=True, rng=None):
+        """t2s_model.py:466-553 as a generator of (cumulative tokens, is_final).  Differences from infer() that
+        are the reference's: EOS is tested on EVERY step and is never appended; chunks are cumulative and lag one
+        chunk behind (the first one is sent at once when boost_first_chunk); the final yield is the last `idx`
+        entries of y ++ samples, which after an EOS break still contains the first sample s0."""
+        x = np.asarray(x, np.int64); y = np.asarray(y, np.int64)
+        lx, ly = len(x), len(y)
+        L = lx + ly
+        xy = np.concatenate([self.embed_text(x, _f32(bert)), self.embed_audio(y)])[None]
+        bks = self.buckets[1]
+        kw = dict(top_k=top_k, top_p=top_p, temperature=temperature, repetition_penalty=repetition_penalty)
+        q = (lambda shape: rng.exponential(size=shape).astype(np.float32)) if rng is not None else (lambda s: None)
+        h = self.prefill(xy, self.single_mask(lx, ly)[None], 1, 0)
+        kv = L
+        lg = self.logits(h[:, -1])
+        lg[:, self.suppressed] = -np.inf
+        pre = y[None].copy()
+        view = lg[:, :-1].copy()
+        s = sample(view, pre, q=q(view.shape), **kw)
+        pre = np.concatenate([pre, s], axis=1)
+        xin = self.next_input(s[:, 0], kv - lx)
+        first, pre_chunk, idx = True, None, 0
+        for idx in range(1, bks[-1] - kv + 1):
+            h = self.decode(xin, 1, [kv])
+            kv += 1
+            lg = self.logits(h)
+            if idx < initial_suppression_steps:
+                lg[:, self.suppressed] = -np.inf
+            s = sample(lg, pre, q=q(lg.shape), **kw)
+            if s[0, 0] == self.EOS:
+                break
+            pre = np.concatenate([pre, s], axis=1)
+            if idx % stream_chunk == 0:
+                if pre_chunk is not None:
+                    yield pre_chunk, False
+                pre_chunk = pre[0, -idx:].copy()
+                if boost_first_chunk and first:
+                    first = False
+                    yield pre_chunk, False
+                    pre_chunk = None
+            xin = self.next_input(s[:, 0], kv - lx)
+        yield pre[0, -idx:].copy(), True
+
     def infer_batched(self, xs, ys, berts, top_k=15, top_p=1.0, temperature=1.0,
                       repetition_penalty=1.35, check_interval=5, rng=None):
         B = len(xs)

@@ -359,3 +359,21 @@ def test_device_and_host_sampling_paths_agree_on_rules(dev):
     gen = torch.Generator(device="cpu"); gen.manual_seed(1)
     pred, idx = m.infer_batched([_T(x, dev)] * 5, [_T(y, dev)] * 5, [_T(bert, dev)] * 5, top_k=15, generator=gen)
     assert sorted(idx.tolist()) == [0, 1, 2, 3, 4] and all(len(p) > 0 and int(p.max()) < 1025 for p in pred)
+
+
+@pytest.mark.parametrize("name", ["e", "f"])
+def test_greedy_infer_stream_fp32_matches_reference_golden(golden_dir, dev, name):
+    """every (cumulative chunk, is_final) of t2s_model.infer_stream, bit-exact in fp32 mode (the final chunk
+    after an EOS still starts with the first sample; chunks lag one behind unless boosted)."""
+    g = np.load(os.path.join(golden_dir, "t2s_stream.npz"))
+    seed, p, t, n, chunk, boost = (int(v) for v in g[name + "_cfg"])
+    cfg = synth.gpt_config()
+    w = synth.gpt_weights(cfg, seed=seed, eos_gain=float(g[name + "_eos_gain"]))
+    m = _model(cfg, w, [tuple(int(v) for v in c) for c in g[name + "_cache"]], torch.float32, dev)
+    x, y = g[name + "_x"], g[name + "_y"]
+    got = list(m.infer_stream(_T(x, dev)[None], _T(y, dev)[None], torch.zeros(1, len(x), 1024, device=dev), top_k=1,
+                              stream_chunk=chunk, boost_first_chunk=bool(boost)))
+    assert len(got) == int(g[name + "_n"])
+    for i, (c, fin) in enumerate(got):
+        assert c.dim() == 3 and c.shape[:2] == (1, 1)
+        assert np.array_equal(c[0, 0].cpu().numpy(), g["%s_chunk%d" % (name, i)]) and int(fin) == int(g["%s_final%d" % (name, i)]), (name, i)

@@ -127,3 +127,19 @@ def test_synth_generator_is_stable():
     ints = synth.hashed_ints("pin", 8, 0, 1024, 1234)
     assert ints.min() >= 0 and ints.max() < 1024
     np.testing.assert_array_equal(ints, synth.hashed_ints("pin", 8, 0, 1024, 1234))
+
+
+@pytest.mark.parametrize("name", ["e", "f"])
+def test_greedy_infer_stream_chunks_match_reference(golden_dir, name):
+    """t2s_model.py:466-553: every (cumulative chunk, is_final) pair, incl. the final chunk after an EOS break
+    that still carries the first sample."""
+    g = _load(golden_dir, "t2s_stream.npz")
+    seed, p, t, n, chunk, boost = (int(v) for v in g[name + "_cfg"])
+    cfg = synth.gpt_config()
+    w = synth.gpt_weights(cfg, seed=seed, eos_gain=float(g[name + "_eos_gain"]))
+    o = orc.T2SOracle(cfg, w, [tuple(int(v) for v in c) for c in g[name + "_cache"]])
+    x, y = g[name + "_x"], g[name + "_y"]
+    got = list(o.infer_stream(x, y, np.zeros((len(x), 1024), np.float32), top_k=1, stream_chunk=chunk, boost_first_chunk=bool(boost)))
+    assert len(got) == int(g[name + "_n"])
+    for i, (c, fin) in enumerate(got):
+        assert np.array_equal(c, g["%s_chunk%d" % (name, i)]) and int(fin) == int(g["%s_final%d" % (name, i)]), (name, i)
