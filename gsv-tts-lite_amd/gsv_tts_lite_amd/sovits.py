@@ -209,9 +209,21 @@ class SynthesizerTrn:
         if ge.shape[-1] != 1:
             ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
         ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
-        if self.native_enc_p and self._voc.has_enc_p and speed == 1 and not stream_mode and codes.shape[0] == 1 and codes.shape[1] == 1:
+        if self.native_enc_p and self._voc.has_enc_p and speed == 1 and codes.shape[0] == 1 and codes.shape[1] == 1:
             # enc_p on device (csrc/encp.h): quantizer lookup, x2 upsampling, the three encoders and MRTE
             m_p, logs_p, attn = self._voc.enc_p(codes[0, 0], text[0], ge_in, slice_indices)
+            if stream_mode:
+                # models.py:209-215 slices the encoder output at valid_start_idx and cross-fades its first
+                # overlap_len frames with the previous chunk's tail BEFORE the 1x1 `proj`; proj is affine, so
+                # the same cross-fade on its output (m_p | logs_p) is the same function.  y_overlap keeps the
+                # tail of the statistics instead of the tail of the features.
+                stats = torch.cat([m_p, logs_p], dim=1)[:, :, valid_start_idx:]
+                alpha = torch.linspace(0, 1, overlap_len, dtype=stats.dtype, device=stats.device).view(1, 1, -1)
+                if self.enc_p.y_overlap is not None:
+                    stats[:, :, :overlap_len] = self.enc_p.y_overlap * (1 - alpha) + stats[:, :, :overlap_len] * alpha
+                self.enc_p.y_overlap = stats[:, :, -overlap_len:].clone()
+                m_p, logs_p = torch.split(stats, self.inter_channels, dim=1)
+                m_p, logs_p = m_p.contiguous(), logs_p.contiguous()
             y_mask = torch.ones(1, 1, m_p.shape[-1], dtype=torch.float32, device=self.device)
             self.enc_p.mrte.cross_attention.attn = attn[None]
         else:

@@ -291,6 +291,92 @@ class TTS:
             finally:
                 self._empty_cache()
 
+    def _sola_algorithm(self, f1_overlap, f2, overlap_len, search_len: int = 320):
+        """TTS.py:1612-1627: align the new chunk to the previous chunk's tail by normalised cross-correlation
+        over `search_len` offsets, then cross-fade `overlap_len` samples."""
+        import torch.nn.functional as F
+        query = f1_overlap
+        key = f2[:, :, :overlap_len + search_len]
+        corr = F.conv1d(key, query)
+        energy = F.conv1d(key ** 2, torch.ones_like(query)) + 1e-8
+        offset = (corr / torch.sqrt(energy)).argmax(dim=-1)
+        f2_aligned = f2[:, :, int(offset.item()):]
+        alpha = torch.linspace(0, 1, overlap_len, device=f2.device, dtype=f2.dtype).view(1, 1, -1)
+        faded = f1_overlap * (1 - alpha) + f2_aligned[:, :, :overlap_len] * alpha
+        return torch.cat([faded, f2_aligned[:, :, overlap_len:]], dim=-1), offset
+
+    def infer_stream(self, spk_audio_path, prompt_audio_path, prompt_audio_text, text, return_subtitles=False,
+                     is_cut_text=True, cut_minlen=10, cut_mute=0.4,
+                     cut_mute_scale_map={"…": 2.0, ".": 1.5, "。": 1.5, "?": 1.5, "？": 1.5, "!": 1.5, "！": 1.5, ",": 1.0,
+                                         "，": 1.0, ":": 1.0, "：": 1.0, ";": 1.0, "；": 1.0, "~": 1.0, "、": 0.8, "・": 0.8},
+                     stream_mode="token", stream_chunk=25, overlap_len=5, boost_first_chunk=True, top_k=15, top_p=1.0,
+                     temperature=1.0, repetition_penalty=1.35, noise_scale=0.5, speed=1.0, gpt_model=None,
+                     sovits_model=None, debug=True):
+        """TTS.py:289-504: generator of AudioClip chunks.  Per text segment the GPT streams cumulative token
+        chunks (t2s.infer_stream); every chunk is decoded from the start of the segment with
+        decode(stream_mode=True) -- only frames past `valid_start_idx` reach the flow / Generator -- and joined
+        to the previous one by SOLA over `overlap_len` frames."""
+        if return_subtitles:
+            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
+        with self._infer_lock:
+            try:
+                if not self._check_pause(text):
+                    text += "."
+                if stream_mode == "sentence":
+                    stream_chunk = 10000
+                if not is_cut_text:
+                    cut_minlen = 10000
+                cut_mute = cut_mute / speed
+                gpt_model = self._pick(self.gpt_models, gpt_model, self.default_gpt_path)
+                sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+                if gpt_model not in self.gpt_models:
+                    self.load_gpt_model(gpt_model)
+                if sovits_model not in self.sovits_models:
+                    self.load_sovits_model(sovits_model)
+                t2s = self.gpt_models[gpt_model].t2s_model
+                vq = self.sovits_models[sovits_model].vq_model
+                dev = self.tts_config.device
+                ge = self._ge_for(spk_audio_path, sovits_model)
+                prompt, phones1, bert1 = self._prompt_for(prompt_audio_path, prompt_audio_text)
+                overlap_samples = overlap_len * vq.samples_per_frame
+                audio_len_s = 0.0
+                for i, text_cut in enumerate(cut_text(text, cut_minlen)):
+                    phones2, _, bert2, _ = self._phones_and_bert(text_cut)
+                    ids = torch.tensor(phones1 + phones2, dtype=torch.int64, device=dev).unsqueeze(0)
+                    bert = torch.cat([bert1, bert2]).unsqueeze(0)
+                    phones2_t = torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0)
+                    last_overlap_audio, valid_start_idx, chunk_idx = None, 0, 0
+                    for pred, is_final in t2s.infer_stream(ids, prompt, bert, top_k=top_k, top_p=top_p, temperature=temperature,
+                                                           repetition_penalty=repetition_penalty, stream_chunk=stream_chunk,
+                                                           boost_first_chunk=boost_first_chunk if i == 0 else False, debug=debug):
+                        with torch.inference_mode():
+                            audio, attn = vq.decode(pred, phones2_t, ge, noise_scale=noise_scale, speed=speed, stream_mode=True,
+                                                    valid_start_idx=valid_start_idx, overlap_len=overlap_len)
+                            if last_overlap_audio is not None:
+                                audio, _ = self._sola_algorithm(last_overlap_audio, audio, overlap_samples)
+                            last_overlap_audio = audio[:, :, -overlap_samples:].clone()
+                            if not is_final:
+                                audio = audio[:, :, :-overlap_samples]
+                                valid_start_idx = attn.shape[1] - overlap_len
+                            audio = audio[0, 0, :]
+                            if chunk_idx == 0:
+                                audio = audio[self._find_head_threshold_offsets(audio):]
+                            if is_final:
+                                if text_cut[-1] in cut_mute_scale_map:
+                                    scale = cut_mute_scale_map[text_cut[-1]]
+                                elif "…" in cut_mute_scale_map and text_cut[-3:] in ["...", "。。。"]:
+                                    scale = cut_mute_scale_map["…"]
+                                else:
+                                    scale = 1.0
+                                audio = torch.cat([audio, torch.zeros(int(cut_mute * scale * self.samplerate), dtype=audio.dtype, device=audio.device)])
+                            audio = audio.float().cpu().numpy()
+                        audio_len_s += len(audio) / self.samplerate
+                        yield AudioClip(self.audio_queue, audio, self.samplerate, audio_len_s, [], text)
+                        chunk_idx += 1
+                    vq.enc_p.y_overlap = None
+            finally:
+                self._empty_cache()
+
     @torch.inference_mode()
     def infer_batched(self, spk_audio_paths, prompt_audio_paths, prompt_audio_texts, texts, return_subtitles=False,
                       is_cut_text=True, cut_minlen=10, cut_mute=0.4,

@@ -83,3 +83,37 @@ def test_tts_infer_and_infer_batched(dev, tmp_path):
         tts.cache_prompt_audio("p2.wav", "", prompt=torch.zeros(1, 4, dtype=torch.int64), phones1=[1, 2])
     tts.unload_gpt_model(*tts.get_gpt_list())
     assert tts.get_gpt_list() == []
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_tts_infer_stream_chunks(dev, dtype):
+    """TTS.infer_stream (TTS.py:289-504): token-mode streaming with SOLA joins.  float32 runs enc_p's streaming
+    branch in the torch restatement, bfloat16 the device enc_p with the cross-fade applied to the projected
+    statistics (the same function: proj is affine).  Greedy + noise 0, so the streamed audio must cover the
+    same frames as the one-shot infer(): total length within a few SOLA search windows."""
+    tts, AudioClip = _make_tts(dev, dtype)
+    text = "Hello there, this is a streaming test"
+    whole = tts.infer("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0)
+    clips = list(tts.infer_stream("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0, stream_chunk=8,
+                                  overlap_len=2, is_cut_text=False, debug=False))
+    assert len(clips) >= 2 and all(isinstance(c, AudioClip) for c in clips)
+    total = 0
+    last = 0.0
+    for c in clips:
+        assert c.samplerate == 32000 and c.audio_data.dtype == np.float32 and np.isfinite(c.audio_data).all()
+        total += len(c.audio_data)
+        assert c.audio_len_s > last
+        last = c.audio_len_s
+    assert abs(last - total / 32000) < 1e-6
+    # infer() appends 0.2 s of silence, the stream 0.4 s * 1.0 ('t' is no punctuation -> '.' appended -> x1.5)
+    body_whole = len(whole.audio_data) - int(0.2 * 32000)
+    body_stream = total - int(0.4 * 1.5 * 32000)
+    assert abs(body_stream - body_whole) <= 320 * len(clips) + 640, (body_stream, body_whole, len(clips))
+    if dtype == "bfloat16":   # device enc_p streaming vs the torch streaming branch: same chunking, close audio
+        vq = next(iter(tts.sovits_models.values())).vq_model
+        assert vq._voc.has_enc_p
+        vq.native_enc_p = False
+        clips2 = list(tts.infer_stream("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0, stream_chunk=8,
+                                       overlap_len=2, is_cut_text=False, debug=False))
+        assert len(clips2) == len(clips)
+        assert abs(sum(len(c.audio_data) for c in clips2) - total) <= 320 * len(clips)
