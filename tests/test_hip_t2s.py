@@ -377,3 +377,40 @@ def test_greedy_infer_stream_fp32_matches_reference_golden(golden_dir, dev, name
     for i, (c, fin) in enumerate(got):
         assert c.dim() == 3 and c.shape[:2] == (1, 1)
         assert np.array_equal(c[0, 0].cpu().numpy(), g["%s_chunk%d" % (name, i)]) and int(fin) == int(g["%s_final%d" % (name, i)]), (name, i)
+
+
+def test_batched_step_bf16_mfma_path_margin_gated(dev):
+    """bf16 with >= 36 slots runs the batched step (rowgemm GEMM chain on B rows + t2s_batch_attn_kernel; weights
+    streamed once per step).  43 ragged requests through 40 slots (three refills), greedy: tokens must equal the
+    fp32 oracle's continuous-batching output up to the first step whose oracle top-1/top-2 margin is below the
+    bf16 noise bound; completion order bookkeeping must be a permutation."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=4)
+    w = synth.gpt_weights(cfg, seed=23, eos_gain=2.0)
+    cache = [(40, 128)]
+    rng = np.random.default_rng(1)
+    shapes = [(int(rng.integers(1, 9)), int(rng.integers(2, 20)), int(rng.integers(1, 30))) for _ in range(43)]
+    rs = [synth.synth_request(70 + i, p, t, n, seed=23, bert="random") for i, (p, t, n) in enumerate(shapes)]
+    o = orc.T2SOracle(cfg, w, cache)
+    ref, ref_idx = o.infer_batched([r[0] for r in rs], [r[1] for r in rs], [r[2] for r in rs], top_k=1)
+    ref_by_req = {int(i): t for i, t in zip(ref_idx, ref)}
+    m = _model(cfg, w, cache, torch.bfloat16, dev)
+    pred, idx = m.infer_batched([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs], top_k=1)
+    assert sorted(idx.tolist()) == list(range(43))
+    BF16_MARGIN = 0.35
+    exact = 0
+    for req, tok in zip(idx.tolist(), pred):
+        tok = tok.cpu().numpy()
+        want = ref_by_req[req]
+        nm = min(len(tok), len(want))
+        neq = np.nonzero(tok[:nm] != want[:nm])[0]
+        if neq.size == 0 and len(tok) == len(want):
+            exact += 1
+            continue
+        first = int(neq[0]) if neq.size else nm
+        # the oracle's decision margins for this request (single-sequence run with the batched path's rules)
+        o1 = orc.T2SOracle(cfg, w, [(1, 128)])
+        single = o1.infer(rs[req][0], rs[req][1], rs[req][2], top_k=1, repetition_penalty=1.0, initial_suppression_steps=0)
+        if len(single) >= first and np.array_equal(single[:first], want[:first]) and first + 1 < len(o1.margins):
+            assert o1.margins[first + 1] < BF16_MARGIN, (req, first, o1.margins[first + 1])
+    assert exact >= 30, exact

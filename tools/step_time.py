@@ -1,0 +1,18 @@
+"""raw decode step time at batch B (graph replay), batched-step path on/off via GSV_NO_BATCHED_STEP"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "gsv-tts-lite_amd"))
+import torch
+from gsv_tts_lite_amd import synth
+from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
+B = int(sys.argv[1]); dev = torch.device("cuda:0")
+cfg = synth.gpt_config()
+m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1, eos_gain=-8.0))
+m.initialize_runtime(torch.bfloat16, dev, [(B, 512)])
+rs = [synth.synth_request(i, 40, 60, 100, seed=1) for i in range(B)]
+with torch.inference_mode():
+    xy, xl, yl, _, _ = m.embed_prompt([torch.from_numpy(r[0]).to(dev) for r in rs], [torch.from_numpy(r[1]).to(dev) for r in rs], [torch.from_numpy(r[2]).to(dev) for r in rs])
+    m.prefill(B, 0, xy, xl, yl)
+    m._set_ctl(m._rt[B], 0, 0, False, 1.0)
+    m._decode(B, 5); torch.cuda.synchronize()
+    t0 = time.perf_counter(); m._decode(B, 100); torch.cuda.synchronize()
+    print("B=%d step %.3f ms (%s)" % (B, (time.perf_counter() - t0) * 10, "per-seq kernels" if os.environ.get("GSV_NO_BATCHED_STEP") else "batched step"))
