@@ -1,6 +1,6 @@
 """scratch: per-phase shader-clock breakdown of the last layer's decode kernels"""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gsv-tts-lite_amd"))
 import numpy as np, torch
 from gsv_tts_lite_amd import synth, _native as N

@@ -1,6 +1,6 @@
 """stress: how often does the persistent step disagree with itself / with the per-layer path"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gsv-tts-lite_amd"))
 import numpy as np, torch
 from gsv_tts_lite_amd import synth

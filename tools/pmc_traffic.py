@@ -5,7 +5,7 @@ Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZ
 FETCH_SIZE tallies the 128-B requests of a wide coalesced stream at 64 B, i.e. reports exactly 1/2 of the
 bytes fetched -> doubled here; WRITE_SIZE is taken as is (uncalibrated).  Infinity-Cache hits are
 counted, so for weight sets that fit the 256 MiB cache this is fabric traffic, not DRAM traffic.
-usage: tools_pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import csv, json, re, sys
 from collections import defaultdict
 
