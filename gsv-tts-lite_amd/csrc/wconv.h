@@ -33,6 +33,7 @@ struct WConvArgs {
     int ld, n_rows;
     float in_slope;               // leaky-ReLU on the input (1 = none)
     float out_slope;              // leaky-ReLU on the output (1 = none)
+    long long* dbg;               // null, or cycle stamps of block 0 / wave 0 per tile phase (tools/tg_bench)
 };
 
 // C: channels (cin == cout), MS: 32-channel output slices per block (waves along channels),
@@ -41,7 +42,7 @@ template <int C, int MS, int BN, int NT>
 __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const uint4* __restrict__ W,
                                            const float* __restrict__ bias, const bf16_t* R, bf16_t* Y, int dil, int blk,
                                            int nblk, int ld, int n_rows, float in_slope, float out_slope,
-                                           unsigned char* lds) {
+                                           unsigned char* lds, long long* dbg = nullptr) {
     constexpr int KSTEPS = C / 16;
     constexpr int MT = (C + 31) / 32;             // m-tiles in the packed weights
     constexpr int RG = 4 / MS;                    // row groups
@@ -119,8 +120,10 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     issue_x(blk);
     commit_x(blk, xbuf0);
     __syncthreads();
-    int cur = 0;
+    int cur = 0, nst = 0;
+    auto stamp = [&]() { if (dbg && blk == 0 && tid == 0 && nst < 60) dbg[nst] = (long long)__builtin_readcyclecounter(); ++nst; };
     for (int tile = blk; tile < ntiles; tile += nblk) {
+        stamp();
         const int tn = tile + nblk;
         const bool has_next = tn < ntiles;
         const int nb0 = tile * BN;
@@ -135,6 +138,7 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
         }
         if (has_next) issue_x(tn);
 
+        stamp();
         // ---- MFMA loop: LDS + registers only
         const unsigned char* xb = cur ? xbuf1 : xbuf0;
         const unsigned lb = (unsigned)(wrow + j) * XRS + hf * 16;
@@ -166,6 +170,7 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
             }
         }
 
+        stamp();
         // ---- epilogue, wave-private
         if (R) {
 #pragma unroll
@@ -217,7 +222,9 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
             if (n < n_rows) *reinterpret_cast<u32x4*>(Y + (size_t)n * ld + ms * 32 + pc * 8) = o;
         }
 
+        stamp();
         if (has_next) commit_x(tn, cur ? xbuf0 : xbuf1);
+        stamp();
         __syncthreads();   // next tile's rows visible; everyone is done with this tile's
         cur ^= 1;
     }
@@ -237,9 +244,9 @@ __global__ __launch_bounds__(256, 1) void wconv_kernel(WConvArgs a) {
     bf16_t* Y = br == 0 ? a.Y0 : (br == 1 ? a.Y1 : a.Y2);
     const int k = br == 0 ? a.k0 : (br == 1 ? a.k1 : a.k2);
     const int dil = br == 0 ? a.d0 : (br == 1 ? a.d1 : a.d2);
-    if (k == 11) wconv_body<C, MS, BN, 11>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds);
-    else if (k == 7) wconv_body<C, MS, BN, 7>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds);
-    else if (k == 3) wconv_body<C, MS, BN, 3>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds);
+    if (k == 11) wconv_body<C, MS, BN, 11>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 7) wconv_body<C, MS, BN, 7>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 3) wconv_body<C, MS, BN, 3>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
 }
 
 // LDS bytes of a wconv_kernel<C, MS, BN> launch (sized for 11 taps at dilation 5)

@@ -66,6 +66,7 @@ void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf
     nb[0] += total_blocks - used;
     w.nb0 = nb[0]; w.nb1 = nb[1]; w.nb2 = nb[2];
     dim3 grid(total_blocks);
+    long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8)); w.dbg = dbg;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, w);
     CK(hipDeviceSynchronize());
@@ -86,6 +87,7 @@ void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf
         }
         CK(hipMemset(Yd[b], 0, ny * 2));
     }
+    { long long hdb[64]; CK(hipMemcpy(hdb, dbg, sizeof(hdb), hipMemcpyDeviceToHost)); printf("  stamps (k=%d, block 0, wave 0):", ks[0]); for (int i = 1; i < 16 && hdb[i]; ++i) printf(" %lld", hdb[i] - hdb[i - 1]); printf("\n"); }
     double flops = 0;
     for (int b = 0; b < 3; ++b) flops += 2.0 * C * C * ks[b] * N;
     printf("%-20s ovh %5.1f grid %5d (%d/%d/%d) lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g\n", name, ovh, total_blocks, nb[0], nb[1], nb[2], lds, us,
@@ -177,12 +179,9 @@ int main(int argc, char** argv) {
     w.Y0 = Y[0]; w.Y1 = Y[1]; w.Y2 = Y[2];
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
-    for (int nblk : {256, 512, 768})
-      for (double ovh : {3.0, 8.0, 14.0, 25.0, 50.0, 100.0}) {
-        if (C == 128 && nblk == 256) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, nblk, ovh);
-        if (C == 64 && nblk < 768) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, nblk, ovh);
-        if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, nblk, ovh);
-        if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, nblk, ovh);
-    }
+    if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
+    if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, 256, 14.0);
+    if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, 512, 50.0);
+    if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, 768, 50.0);
     return 0;
 }
