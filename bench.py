@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--version", default="v2Pro", choices=["v2", "v2Pro", "v2ProPlus"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sampling / time-to-first-audio extras")
     ap.add_argument("--ttft-runs", type=int, default=30)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CI on a 1-GPU box)")
@@ -281,6 +282,8 @@ def main():
         # ---- extras (not part of `value`): default-parameter sampling, and time to first audio
         # (first 25-token chunk + 50-frame vocoder pass)
         try:
+            if a.no_extras:
+                raise RuntimeError("--no-extras")
             for _ in range(2):
                 torch.cuda.synchronize(dev); s0 = time.perf_counter()
                 tk = t2s.infer(x, y, bert, top_k=15, repetition_penalty=1.35)
