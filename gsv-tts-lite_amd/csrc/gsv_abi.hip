@@ -578,6 +578,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         // bias + residual + LayerNorm in the consumer of the raw (split) GEMM tiles
         const int rtiles = cdiv(M, 32);
         bf16_t* fb16 = (bf16_t*)fbuf;                    // FFN hidden as bf16: the GEMM's operand type anyway
+        bf16_t* xb16 = fb16 + (size_t)M * kF;            // bf16 copy of the LayerNorm output (second half of the fp32-sized fbuf)
         float* part = qkv;                               // W2 split partials reuse qkv + attn (dead by then): [4][M][512]
         auto gemm = [&](auto kern, const void* X, int ldx, const PackedConv& pc, const float* bias, int relu, void* Y, int ldy,
                         int nsplit, size_t split_stride) {
@@ -589,7 +590,8 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         };
         for (int l = 0; l < h->cfg.n_layer; ++l) {
             T2SLayer& L = h->layers[l];
-            gemm(rowgemm_kernel<float, float>, xy, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
+            if (l == 0) gemm(rowgemm_kernel<float, float>, xy, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
+            else gemm(rowgemm_kernel<bf16_t, float>, xb16, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
             PrefillAttnMfmaArgs pm;
             pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
             pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
@@ -597,11 +599,11 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
             gemm(rowgemm_kernel<float, float>, attn, kD, L.g_out, nullptr, 0, ybuf, kD, 1, 0);
             hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)ybuf, 1, (size_t)0, (const float*)L.bo,
-                               (const float*)xy, (const float*)L.ln1g, (const float*)L.ln1b, xy, M);
-            gemm(rowgemm_kernel<float, bf16_t>, xy, kD, L.g_w1, L.b1, 1, fb16, kF, 1, 0);
+                               (const float*)xy, (const float*)L.ln1g, (const float*)L.ln1b, xy, M, xb16);
+            gemm(rowgemm_kernel<bf16_t, bf16_t>, xb16, kD, L.g_w1, L.b1, 1, fb16, kF, 1, 0);
             gemm(rowgemm_kernel<bf16_t, float>, fb16, kF, L.g_w2, nullptr, 0, part, kD, 4, (size_t)M * kD);
             hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)part, 4, (size_t)M * kD, (const float*)L.b2,
-                               (const float*)xy, (const float*)L.ln2g, (const float*)L.ln2b, xy, M);
+                               (const float*)xy, (const float*)L.ln2g, (const float*)L.ln2b, xy, M, xb16);
         }
         HIPCHK(hipGetLastError());
     } else {

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 __global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
                                                           const float* __restrict__ bias, const float* res,
                                                           const float* __restrict__ g, const float* __restrict__ bta,
-                                                          float* y, int rows) {   // y may alias res (row-wise in place)
+                                                          float* y, int rows, bf16_t* yb = nullptr) {   // y may alias res (row-wise in place)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float v[8], t[8];
@@ -435,6 +435,10 @@ __global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restric
     for (int i = 0; i < 8; ++i) o[i] = v[i] * rs * g[lane * 8 + i] + bta[lane * 8 + i];
     *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8) = f32x4{o[0], o[1], o[2], o[3]};
     *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    if (yb) {   // the next GEMM's operand type: same values it would round on load, half the bytes
+        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        *reinterpret_cast<u32x4*>(yb + (size_t)row * kD + lane * 8) = pk;
+    }
 }
 
 // ---- batched decode step (bf16, large batches): one token per sequence ---------------------------------
