@@ -7,7 +7,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
-#include "../gsv-tts-lite_amd/csrc/wconv.h"
+#include "wpair_experiment.h"
 
 using namespace gsv;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -92,6 +92,62 @@ void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf
     for (int b = 0; b < 3; ++b) flops += 2.0 * C * C * ks[b] * N;
     printf("%-20s ovh %5.1f grid %5d (%d/%d/%d) lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g\n", name, ovh, total_blocks, nb[0], nb[1], nb[2], lds, us,
            flops / us * 1e-6, maxd);
+    fflush(stdout);
+}
+
+template <int C, int MS, int BNW, int BNP>
+void run_pair(const char* name, WConvArgs w1, int N, int reps, bf16_t** Xd, bf16_t** T1d, bf16_t** Yd, Conv* cv, size_t ny, int blocks_w, int blocks_p, double ovh) {
+    // reference: c1 (lrelu in, lrelu out) then c2 (+ residual) with the single-conv kernel; both convs use the same weights here
+    auto kw = wconv_kernel<C, MS, BNW>;
+    const size_t ldsw = wconv_lds_bytes<C, MS, BNW>();
+    CK(hipFuncSetAttribute((const void*)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+    const int ks[3] = {w1.k0, w1.k1, w1.k2};
+    double tot = 0; for (int b = 0; b < 3; ++b) tot += ks[b] + ovh;
+    auto deal = [&](int total, int (&nb)[3]) { int used = 0; for (int b = 0; b < 3; ++b) { nb[b] = std::max(1, (int)(total * (ks[b] + ovh) / tot)); used += nb[b]; } nb[0] += total - used; };
+    int nbw[3], nbp[3]; deal(blocks_w, nbw); deal(blocks_p, nbp);
+    WConvArgs a1 = w1; a1.R0 = a1.R1 = a1.R2 = nullptr; a1.Y0 = T1d[0]; a1.Y1 = T1d[1]; a1.Y2 = T1d[2]; a1.in_slope = 0.1f; a1.out_slope = 0.1f;
+    a1.nb0 = nbw[0]; a1.nb1 = nbw[1]; a1.nb2 = nbw[2]; a1.dbg = nullptr;
+    WConvArgs a2 = w1; a2.X0 = T1d[0]; a2.X1 = T1d[1]; a2.X2 = T1d[2]; a2.R0 = Xd[0]; a2.R1 = Xd[1]; a2.R2 = Xd[2];
+    a2.d0 = a2.d1 = a2.d2 = 1; a2.in_slope = 1.0f; a2.out_slope = 1.0f; a2.nb0 = nbw[0]; a2.nb1 = nbw[1]; a2.nb2 = nbw[2]; a2.dbg = nullptr;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) { hipLaunchKernelGGL(kw, dim3(blocks_w), dim3(256), ldsw, 0, a1); hipLaunchKernelGGL(kw, dim3(blocks_w), dim3(256), ldsw, 0, a2); }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) { hipLaunchKernelGGL(kw, dim3(blocks_w), dim3(256), ldsw, 0, a1); hipLaunchKernelGGL(kw, dim3(blocks_w), dim3(256), ldsw, 0, a2); }
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const float us2 = ms * 1e3f / reps;
+    std::vector<bf16_t> yref[3];
+    for (int b = 0; b < 3; ++b) { yref[b].resize(ny); CK(hipMemcpy(yref[b].data(), Yd[b], ny * 2, hipMemcpyDeviceToHost)); CK(hipMemset(Yd[b], 0, ny * 2)); }
+    // fused pair
+    auto kp = wpair_kernel<C, BNP>;
+    const size_t ldsp = wpair_lds_bytes<C, BNP>();
+    CK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+    WPairArgs p; memset(&p, 0, sizeof(p));
+    p.X0 = Xd[0]; p.X1 = Xd[1]; p.X2 = Xd[2];
+    p.Wa0 = p.Wb0 = (const uint4*)cv[0].w; p.Wa1 = p.Wb1 = (const uint4*)cv[1].w; p.Wa2 = p.Wb2 = (const uint4*)cv[2].w;
+    p.ba0 = p.bb0 = cv[0].bias; p.ba1 = p.bb1 = cv[1].bias; p.ba2 = p.bb2 = cv[2].bias;
+    p.Y0 = Yd[0]; p.Y1 = Yd[1]; p.Y2 = Yd[2]; p.k0 = w1.k0; p.k1 = w1.k1; p.k2 = w1.k2; p.d0 = w1.d0; p.d1 = w1.d1; p.d2 = w1.d2;
+    p.nb0 = nbp[0]; p.nb1 = nbp[1]; p.nb2 = nbp[2]; p.ld = w1.ld; p.n_rows = N; p.slope = 0.1f;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kp, dim3(blocks_p), dim3(256), ldsp, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kp, dim3(blocks_p), dim3(256), ldsp, 0, p);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const float usp = ms * 1e3f / reps;
+    double maxd = 0; size_t nbad = 0;
+    std::vector<bf16_t> y(ny);
+    for (int b = 0; b < 3; ++b) {
+        CK(hipMemcpy(y.data(), Yd[b], ny * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ny; ++i) {
+            uint32_t ua = (uint32_t)y[i] << 16, ub = (uint32_t)yref[b][i] << 16;
+            float fa, fb; memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+            if (fa != fb && nbad++ < 5) printf("  pair mismatch br %d n %zu m %zu got %g want %g\n", b, i / C, i % C, fa, fb);
+            maxd = std::max(maxd, (double)fabsf(fa - fb));
+        }
+    }
+    printf("%-18s two launches %7.1f us   fused pair %7.1f us (blocks %d, lds %zu)   maxdiff %.3g\n", name, us2, usp, blocks_p, ldsp, maxd);
     fflush(stdout);
 }
 
@@ -180,8 +236,11 @@ int main(int argc, char** argv) {
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
-    if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, 256, 14.0);
-    if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, 512, 50.0);
-    if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, 768, 50.0);
+    bf16_t* T1[3]; for (int b = 0; b < 3; ++b) CK(hipMalloc(&T1[b], ny * 2));
+    for (int nb : {256, 512}) {
+        if (C == 64) run_pair<64, 2, 128, 128>("pair 64 bn128", w, N, reps, X, T1, Y, cv, ny, 256, nb, 14.0);
+        if (C == 32) run_pair<32, 1, 256, 256>("pair 32 bn256", w, N, reps, X, T1, Y, cv, ny, 512, nb, 50.0);
+        if (C == 16) run_pair<16, 1, 256, 256>("pair 16 bn256", w, N, reps, X, T1, Y, cv, ny, 768, nb, 50.0);
+    }
     return 0;
 }
