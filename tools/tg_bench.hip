@@ -236,11 +236,13 @@ int main(int argc, char** argv) {
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
-    bf16_t* T1[3]; for (int b = 0; b < 3; ++b) CK(hipMalloc(&T1[b], ny * 2));
-    for (int nb : {256, 512}) {
-        if (C == 64) run_pair<64, 2, 128, 128>("pair 64 bn128", w, N, reps, X, T1, Y, cv, ny, 256, nb, 14.0);
-        if (C == 32) run_pair<32, 1, 256, 256>("pair 32 bn256", w, N, reps, X, T1, Y, cv, ny, 512, nb, 50.0);
-        if (C == 16) run_pair<16, 1, 256, 256>("pair 16 bn256", w, N, reps, X, T1, Y, cv, ny, 768, nb, 50.0);
+    for (int nb : {512, 768, 1024, 1536, 2048}) {
+        if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
+        if (C == 32) run_wconv<32, 1, 128>("wconv 32 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
+        if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
+        if (C == 16) run_wconv<16, 1, 128>("wconv 16 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
+        if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, nb, 14.0);
+        if (C == 64) run_wconv<64, 2, 64>("wconv 64 bn64", w, N, reps, yrp, Y, ny, nb, 14.0);
     }
     return 0;
 }
