@@ -802,6 +802,44 @@ __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
             const int v = tid + 256 * i;
             x[i] = v < a.V ? a.logits[(size_t)b * a.V + v] * invt : -INFINITY;
         }
+        // top-p (GPT/utils.py:29-40), on the un-tempered penalised logits: a token stays iff the probability mass of the
+        // tokens at least as likely as it is <= top_p (or it is the arg-max).  That set is {p >= tau}; tau is found by
+        // bisection over the float bit pattern (31 block sums) instead of the reference's sort + cumsum.
+        const float top_p = a.fctl[2];
+        if (top_p > 0.f && top_p < 1.0f) {
+            float lmax = -INFINITY; int li = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                if (x[i] > lmax) { lmax = x[i]; li = tid + 256 * i; }
+            t2s_block_argmax(lmax, li, sv, si);
+            const float lm = lmax * (1.0f / invt);           // x holds logits * invt
+            float pr[NPT], z = 0.f;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int v = tid + 256 * i;
+                pr[i] = (v < a.V && x[i] > -INFINITY) ? expf(x[i] * (1.0f / invt) - lm) : 0.f;
+                z += pr[i];
+            }
+            __shared__ float zred[8];
+            z = block_sum<4>(z, zred);
+            const float iz = 1.0f / z;
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) pr[i] *= iz;
+            unsigned lo = 0u, hi = 0x3f800001u;              // G(lo) > top_p >= G(hi)
+            for (int it = 0; it < 31 && hi - lo > 1u; ++it) {
+                const unsigned mid = lo + (hi - lo) / 2u;
+                const float xm = __uint_as_float(mid);
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) s += pr[i] >= xm ? pr[i] : 0.f;
+                s = block_sum<4>(s, zred);
+                if (s <= top_p) hi = mid; else lo = mid;
+            }
+            const float tau = __uint_as_float(hi);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                if (!(pr[i] >= tau) && tid + 256 * i != li) x[i] = -INFINITY;
+        }
         const int k = a.ctl[4];
         float pivot = -INFINITY, top = -INFINITY;
         if (k > 0 && k < a.V) {

@@ -239,19 +239,20 @@ class Text2SemanticDecoder:
     def _flush(self, batch):
         N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))
 
-    def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0):
+    def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0, top_p=1.0):
         """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling"""
         lo, hi = int(seed) & 0x7fffffff, (int(seed) >> 31) & 0x7fffffff
         rt["ctl"].copy_(torch.tensor([int(mode), int(suppress_steps), int(rep_enabled), 0, int(top_k or 0), lo, hi, 0],
                                      dtype=torch.int32))
-        rt["fctl"].copy_(torch.tensor([float(rep), float(temperature), 0.0, 0.0], dtype=torch.float32))
+        rt["fctl"].copy_(torch.tensor([float(rep), float(temperature), float(1.0 if top_p is None else top_p), 0.0],
+                                      dtype=torch.float32))
 
     def _sampling_mode(self, top_k, top_p, generator):
-        """(mode, seed): greedy stays the device argmax; top-k / temperature sampling runs on device unless
-        top_p < 1 (sort + cumsum: host path) or device sampling is switched off."""
+        """(mode, seed): greedy stays the device argmax; top-p / temperature / top-k sampling runs on device unless
+        device sampling is switched off (then: host-sampled tokens, one step per launch)."""
         if top_k == 1:
             return 0, 0
-        if not self.device_sampling or (top_p is not None and top_p < 1.0) or (top_k is not None and top_k > 256):
+        if not self.device_sampling or (top_k is not None and top_k > 256):
             return 1, 0
         if generator is not None:   # the caller's generator (CPU or device) seeds the device noise stream
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
@@ -277,7 +278,7 @@ class Text2SemanticDecoder:
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1   # the device loop serves greedy and device sampling alike
         rep_on = repetition_penalty != 1.0
-        self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed)
+        self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p)
         rt["seen"].zero_()
         if rep_on:
             rt["seen"][0, y[0].to(self.device)] = 1
@@ -353,7 +354,7 @@ class Text2SemanticDecoder:
                 raise RuntimeError("no decode iterations: prompt fills the largest bucket")
             mode, seed = self._sampling_mode(top_k, top_p, generator)
             rep_on = repetition_penalty != 1.0
-            self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed)
+            self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p)
             rt["seen"].zero_()
             if rep_on:
                 rt["seen"][0, y[0].to(self.device)] = 1
@@ -412,7 +413,7 @@ class Text2SemanticDecoder:
         actual = min(B, batch_size)
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1
-        self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed)
+        self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed, top_p)
         dev = self.device
         rt["kv_len"].zero_()
         rt["x_len"].zero_()

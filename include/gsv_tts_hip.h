@@ -88,8 +88,9 @@ typedef struct {
                                2 = device sampling: temperature fctl[1], top-k ctl[4] (<= 0: off; ties with the
                                k-th value are kept, GPT/utils.py:45-48), then argmax(softmax / Exp(1))
                                (utils.py:56-59) with a counter-based noise stream keyed by
-                               (seed, slot, kv position, step, token id); top_p is host-only */
-    float* fctl;            /* [4]   {repetition_penalty, temperature, -, -} */
+                               (seed, slot, kv position, step, token id); top-p fctl[2] in (0,1) is applied first, on the
+                               un-tempered logits, as the set {p >= tau} (ties with tau stay together) */
+    float* fctl;            /* [4]   {repetition_penalty, temperature, top_p, -} */
 } gsv_t2s_state;
 int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st);
 

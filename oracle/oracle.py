@@ -512,9 +512,30 @@ def device_uniform(seed, slot, pos, step, V):
     return ((h >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
 
 
-def device_sample(logits, top_k, temperature, seed, slot, pos, step):
-    """(token, margin): temperature, top-k with ties kept, Gumbel argmax; margin = top-1 minus top-2 score"""
-    x = np.asarray(logits, np.float32) / np.float32(max(temperature, 1e-5))
+def _device_top_p(logits, top_p):
+    """the device sampler's top-p: keep v iff sum_{p_u >= p_v} p_u <= top_p, or v is the arg-max (== the reference's
+    sort + cumsum rule, GPT/utils.py:29-40, with ties kept or dropped together)"""
+    x = np.asarray(logits, np.float32).copy()
+    if top_p is None or not (0.0 < top_p < 1.0):
+        return x
+    fin = np.isfinite(x)
+    p = np.where(fin, np.exp(x.astype(np.float64) - x[fin].max()), 0.0)
+    p /= p.sum()
+    order = np.argsort(-p, kind="stable")
+    cum = np.cumsum(p[order])
+    g = np.empty_like(p)
+    ps = p[order]
+    # inclusive mass with ties grouped: the cumulative value at the LAST position of each run of equal probabilities
+    last = np.r_[np.nonzero(np.diff(ps))[0], len(ps) - 1]
+    g[order] = np.repeat(cum[last], np.diff(np.r_[-1, last]))
+    keep = (g <= top_p + 1e-12) | (np.arange(len(x)) == int(np.argmax(x)))
+    x[~keep] = -np.inf
+    return x
+
+
+def device_sample(logits, top_k, temperature, seed, slot, pos, step, top_p=1.0):
+    """(token, margin): top-p, temperature, top-k with ties kept, Gumbel argmax; margin = top-1 minus top-2 score"""
+    x = _device_top_p(logits, top_p) / np.float32(max(temperature, 1e-5))
     V = x.shape[0]
     pivot = -np.inf
     if top_k and 0 < top_k < V:
@@ -527,9 +548,9 @@ def device_sample(logits, top_k, temperature, seed, slot, pos, step):
     return int(order[0]), float(sc[order[0]] - sc[order[1]]) if V > 1 else np.inf
 
 
-def device_sample_probs(logits, top_k, temperature):
-    """the distribution the device sampler draws from (== GPT/utils.py logits_to_probs with top_p = 1)"""
-    x = np.asarray(logits, np.float64) / max(temperature, 1e-5)
+def device_sample_probs(logits, top_k, temperature, top_p=1.0):
+    """the distribution the device sampler draws from (== GPT/utils.py logits_to_probs)"""
+    x = _device_top_p(logits, top_p).astype(np.float64) / max(temperature, 1e-5)
     if top_k and 0 < top_k < x.shape[0]:
         pivot = np.sort(x)[::-1][top_k - 1]
         x = np.where(x < pivot, -np.inf, x)

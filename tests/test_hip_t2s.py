@@ -414,3 +414,42 @@ def test_batched_step_bf16_mfma_path_margin_gated(dev):
         if len(single) >= first and np.array_equal(single[:first], want[:first]) and first + 1 < len(o1.margins):
             assert o1.margins[first + 1] < BF16_MARGIN, (req, first, o1.margins[first + 1])
     assert exact >= 30, exact
+
+
+@pytest.mark.parametrize("top_k,top_p,temp", [(15, 0.6, 1.0), (0, 0.85, 0.7)])
+def test_device_sampler_top_p(dev, top_k, top_p, temp):
+    """top-p on device (bisection for the {p >= tau} set instead of sort + cumsum): the kept set must be the
+    reference's (oracle.logits_to_probs is pinned to GPT/utils.py by sample.npz), draws must agree with the
+    restated noise stream, and the empirical distribution must pass chi-square."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=1)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=5), [(1, 64)], torch.float32, dev)
+    rt = m._rt[1]
+    V = 1025
+    logits = (np.random.default_rng(3).standard_normal(V) * 3.0).astype(np.float32)
+    logits[[280, 486, 1024]] = -np.inf
+    ref_p = orc.logits_to_probs(logits[None].copy(), None, temperature=temp, top_k=(top_k or None), top_p=top_p)[0]
+    mine = orc.device_sample_probs(logits, top_k, temp, top_p)
+    assert np.array_equal(ref_p > 0, mine > 0) and np.abs(ref_p - mine).max() < 1e-6
+    n, bad = 3000, 0
+    counts = np.zeros(V)
+    with torch.inference_mode():
+        rt["logits"][0].copy_(torch.from_numpy(logits))
+        rt["kv_len"].fill_(5); rt["x_len"].fill_(2); rt["step"].fill_(4)
+        for s in range(n):
+            seed = 7919 * s + 3
+            m._set_ctl(rt, 2, 0, False, 1.0, top_k, temp, seed, top_p)
+            m._flush(1)
+            tok = int(rt["pre_tokens"][0, 5].item())
+            counts[tok] += 1
+            want, margin = orc.device_sample(logits, top_k, temp, seed, 0, 5, 4, top_p)
+            if tok != want:
+                assert margin < 1e-4, (s, tok, want, margin)
+                bad += 1
+    assert bad <= 3
+    assert counts[ref_p == 0].sum() == 0, "drew a token outside the top-p / top-k set"
+    kept = ref_p > 0
+    exp = ref_p[kept] * n
+    big = exp >= 5                                       # chi-square needs expected counts that are not tiny
+    chi2 = (((counts[kept][big] - exp[big]) ** 2) / exp[big]).sum()
+    assert chi2 < 30.0 + 3.0 * big.sum(), (chi2, int(big.sum()))
