@@ -21,6 +21,7 @@
 #include "flowfuse.h"
 #include "encp.h"
 #include "voc_kernels.h"
+#include "gsv_error.h"
 
 using namespace gsv;
 
@@ -37,6 +38,20 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+
+}  // namespace
+
+int gsv::abi_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+namespace {
 
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \

@@ -22,6 +22,7 @@ EXPORTS = [
     "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_megastep_error",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
+    "gsv_align_workspace", "gsv_align_viterbi",
 ]
 
 
@@ -82,6 +83,7 @@ def lib():
         "gsv_voc_dec": [vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_has_enc_p": [vp],
         "gsv_voc_enc_p": [vp, vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, sz, vp],
+        "gsv_align_viterbi": [vp, i, i, i, vp, vp, sz, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -93,6 +95,8 @@ def lib():
     L.gsv_voc_workspace.restype = sz
     L.gsv_voc_enc_workspace.argtypes = [vp, i, i]
     L.gsv_voc_enc_workspace.restype = sz
+    L.gsv_align_workspace.argtypes = [i, i]
+    L.gsv_align_workspace.restype = sz
     _LIB = L
     return L
 

@@ -339,3 +339,26 @@ def mixed_lengths(n: int, seed: int = 1234):
     a = hashed_ints("mixed.text", n, 20, 121, seed)
     b = hashed_ints("mixed.prompt", n, 75, 151, seed)
     return [(int(p), int(q)) for p, q in zip(a, b)]
+
+
+def synth_attn(seed: int, heads: int, frames: int, phonemes: int, lead: int = 0, tail: int = 0,
+               noise: float = 0.2) -> np.ndarray:
+    """Synthetic MRTE cross-attention [heads, frames, phonemes] for the subtitle-alignment tests: a monotone
+    ridge from phoneme 0 to phonemes-1 with per-head jitter and uniform noise.  `lead` frames before the ridge
+    peak away from phoneme 0 (-> -1 in the alignment), `tail` frames peak at the last phoneme on every head
+    (-> the fixed row of TTS.py:1757-1761).  Only IEEE +, *, / on float32, so it is bit-reproducible."""
+    rng = np.random.default_rng(seed)
+    span = max(1, frames - lead - tail)
+    t = np.arange(frames)
+    centre = np.clip((t - lead) * (phonemes - 1) // max(1, span - 1), 0, phonemes - 1)
+    centre = np.where(t < lead, min(2, phonemes - 1), centre)
+    centre = np.where(t >= frames - tail, phonemes - 1, centre)
+    jit = rng.integers(-1, 2, size=(heads, frames))
+    jit[:, t < lead] = 0
+    jit[:, t >= frames - tail] = 0
+    c = np.clip(centre[None, :] + jit, 0, phonemes - 1)
+    if lead > 0:
+        c[:, lead] = 0                      # the ridge starts on phoneme 0 for every head
+    d = (np.arange(phonemes)[None, None, :] - c[:, :, None]).astype(np.float32)
+    u = rng.random((heads, frames, phonemes), dtype=np.float32)
+    return (np.float32(1) / (np.float32(1) + d * d) + np.float32(noise) * u).astype(np.float32)

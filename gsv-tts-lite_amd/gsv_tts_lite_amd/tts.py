@@ -15,8 +15,9 @@ installable here).  Their *outputs* enter through the same caches the reference 
     cache_spk_audio(path, ge=...)                      (reference fills it via get_ge, TTS.py:1346)
     cache_prompt_audio(path, text, prompt=..., phones1=..., bert1=...)       (TTS.py:1391)
     set_text_frontend(fn)   fn(text) -> (phones2, word2ph, bert2[P,1024], norm_text)
-With those in place infer()/infer_batched() behave as in the reference.  Subtitle alignment
-(`return_subtitles=True`, TTS.py:1744) is a later row.
+With those in place infer()/infer_batched()/infer_stream() behave as in the reference, including
+`return_subtitles=True`: the frame->phoneme alignment runs on the device (subtitles.viterbi_monotonic ->
+gsv_align_viterbi, replacing TTS.py:1744-1797) and the word-timing / text-span bookkeeping is subtitles.py.
 """
 from __future__ import annotations
 
@@ -29,6 +30,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import subtitles as sub
 from .loader import Gpt, Sovits, get_gpt_weights, get_sovits_weights
 
 log = logging.getLogger("gsv_tts_lite_amd")
@@ -251,13 +253,19 @@ class TTS:
     def _check_pause(text):
         return len(text) > 0 and text[-1] in PAUSE_MARKS
 
+    def _close_subtitles(self, subtitles, word2ph, tail_s):
+        """TTS.py:255-261 / 472-478 / 772-777: make the list end on a pause mark (a zero-length entry for the
+        last word when it is not one) and let that last entry cover the trailing silence."""
+        if not self._check_pause(subtitles[-1]["text"]):
+            subtitles.append({"text": word2ph["word"][-1], "start_s": subtitles[-1]["end_s"], "end_s": subtitles[-1]["end_s"]})
+        if tail_s is not None:
+            subtitles[-1]["end_s"] += tail_s
+
     # ------------------------------------------------------------------ inference
     @torch.inference_mode()
     def infer(self, spk_audio_path, prompt_audio_path, prompt_audio_text, text, return_subtitles=False, top_k=15,
               top_p=1.0, temperature=1.0, repetition_penalty=1.35, noise_scale=0.5, speed=1.0, gpt_model=None,
               sovits_model=None):
-        if return_subtitles:
-            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
         with self._infer_lock:
             try:
                 if not self._check_pause(text):
@@ -273,21 +281,30 @@ class TTS:
                 dev = self.tts_config.device
                 ge = self._ge_for(spk_audio_path, sovits_model)
                 prompt, phones1, bert1 = self._prompt_for(prompt_audio_path, prompt_audio_text)
-                phones2, _, bert2, _ = self._phones_and_bert(text)
+                phones2, word2ph, bert2, norm_text = self._phones_and_bert(text)
                 ids = torch.tensor(phones1 + phones2, dtype=torch.int64, device=dev).unsqueeze(0)
                 bert = torch.cat([bert1, bert2]).unsqueeze(0)
                 pred = t2s.infer(ids, prompt, bert, top_k=top_k, top_p=top_p, temperature=temperature,
                                  repetition_penalty=repetition_penalty)
-                audio, _ = vq.decode(pred, torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0), ge,
-                                     noise_scale=noise_scale, speed=speed)
+                audio, attn = vq.decode(pred, torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0), ge,
+                                        noise_scale=noise_scale, speed=speed)
                 audio = audio[0, 0, :]
-                audio = audio[self._find_head_threshold_offsets(audio):]
+                subtitles = []
+                if return_subtitles:   # TTS.py:250-263 (the reference aligns even when nobody asked; only done on request here)
+                    subtitles = sub.get_subtitles(word2ph, sub.viterbi_monotonic(attn), speed, sovits_hz=self.sovits_hz)
+                    self._close_subtitles(subtitles, word2ph, 0.2)
+                    subtitles = sub.sub2text_index(subtitles, norm_text, text)
+                head_offset = self._find_head_threshold_offsets(audio)
+                audio = audio[head_offset:]
+                if subtitles:
+                    sub.increment_subtitle_times(subtitles, -head_offset / self.samplerate)
+                    subtitles[0]["start_s"] = max(0, subtitles[0]["start_s"])
                 audio = audio.float().cpu().numpy()
                 peak = np.abs(audio).max() if audio.size else 0.0
                 if peak > 1:
                     audio = audio / peak
                 audio = np.concatenate([audio, np.zeros(int(0.2 * self.samplerate), dtype=audio.dtype)])
-                return AudioClip(self.audio_queue, audio, self.samplerate, len(audio) / self.samplerate, [], text)
+                return AudioClip(self.audio_queue, audio, self.samplerate, len(audio) / self.samplerate, subtitles, text)
             finally:
                 self._empty_cache()
 
@@ -316,8 +333,6 @@ class TTS:
         chunks (t2s.infer_stream); every chunk is decoded from the start of the segment with
         decode(stream_mode=True) -- only frames past `valid_start_idx` reach the flow / Generator -- and joined
         to the previous one by SOLA over `overlap_len` frames."""
-        if return_subtitles:
-            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
         with self._infer_lock:
             try:
                 if not self._check_pause(text):
@@ -339,13 +354,13 @@ class TTS:
                 ge = self._ge_for(spk_audio_path, sovits_model)
                 prompt, phones1, bert1 = self._prompt_for(prompt_audio_path, prompt_audio_text)
                 overlap_samples = overlap_len * vq.samples_per_frame
-                audio_len_s = 0.0
+                audio_len_s, cur_text_l, last_end_s = 0.0, 0, 0
                 for i, text_cut in enumerate(cut_text(text, cut_minlen)):
-                    phones2, _, bert2, _ = self._phones_and_bert(text_cut)
+                    phones2, word2ph, bert2, norm_text = self._phones_and_bert(text_cut)
                     ids = torch.tensor(phones1 + phones2, dtype=torch.int64, device=dev).unsqueeze(0)
                     bert = torch.cat([bert1, bert2]).unsqueeze(0)
                     phones2_t = torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0)
-                    last_overlap_audio, valid_start_idx, chunk_idx = None, 0, 0
+                    last_overlap_audio, valid_start_idx, chunk_idx, last_subtitles_end = None, 0, 0, 0
                     for pred, is_final in t2s.infer_stream(ids, prompt, bert, top_k=top_k, top_p=top_p, temperature=temperature,
                                                            repetition_penalty=repetition_penalty, stream_chunk=stream_chunk,
                                                            boost_first_chunk=boost_first_chunk if i == 0 else False, debug=debug):
@@ -357,10 +372,20 @@ class TTS:
                             last_overlap_audio = audio[:, :, -overlap_samples:].clone()
                             if not is_final:
                                 audio = audio[:, :, :-overlap_samples]
-                                valid_start_idx = attn.shape[1] - overlap_len
+                                attn = attn[:, :-overlap_len, :]
+                                valid_start_idx = attn.shape[1]
                             audio = audio[0, 0, :]
+                            subtitles = []
+                            if return_subtitles:   # TTS.py:444-451: a chunk whose path is mostly single frames is not trusted yet
+                                assign = sub.viterbi_monotonic(attn)
+                                if is_final or sub.is_normal_assign(assign):
+                                    subtitles = sub.get_subtitles(word2ph, assign, speed, last_end_s=last_end_s, sovits_hz=self.sovits_hz)
                             if chunk_idx == 0:
-                                audio = audio[self._find_head_threshold_offsets(audio):]
+                                head_offset = self._find_head_threshold_offsets(audio)
+                                audio = audio[head_offset:]
+                            if subtitles:
+                                sub.increment_subtitle_times(subtitles, -head_offset / self.samplerate)
+                                subtitles[0]["start_s"] = max(last_end_s, subtitles[0]["start_s"])
                             if is_final:
                                 if text_cut[-1] in cut_mute_scale_map:
                                     scale = cut_mute_scale_map[text_cut[-1]]
@@ -369,11 +394,23 @@ class TTS:
                                 else:
                                     scale = 1.0
                                 audio = torch.cat([audio, torch.zeros(int(cut_mute * scale * self.samplerate), dtype=audio.dtype, device=audio.device)])
+                                if subtitles:
+                                    self._close_subtitles(subtitles, word2ph, cut_mute * scale)
+                                    last_end_s = subtitles[-1]["end_s"]
+                            new_subtitles = []
+                            if subtitles:   # TTS.py:481-486: chunks are cumulative, hand out what is new; the last word stays open
+                                subtitles = sub.sub2text_index(subtitles, norm_text, text_cut)
+                                sub.increment_subtitle_indices(subtitles, cur_text_l)
+                                new_subtitles = subtitles[last_subtitles_end:]
+                                last_subtitles_end = len(subtitles) - 1
+                                if not is_final and new_subtitles:
+                                    new_subtitles[-1]["end_s"] = None
                             audio = audio.float().cpu().numpy()
                         audio_len_s += len(audio) / self.samplerate
-                        yield AudioClip(self.audio_queue, audio, self.samplerate, audio_len_s, [], text)
+                        yield AudioClip(self.audio_queue, audio, self.samplerate, audio_len_s, new_subtitles, text)
                         chunk_idx += 1
                     vq.enc_p.y_overlap = None
+                    cur_text_l += len(text_cut)
             finally:
                 self._empty_cache()
 
@@ -385,8 +422,6 @@ class TTS:
                                           "、": 0.8, "・": 0.8},
                       top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35, noise_scale=0.5, speed=1.0,
                       bert_batch_size=20, sovits_batch_size=10, gpt_model=None, sovits_model=None):
-        if return_subtitles:
-            raise NotImplementedError("subtitle alignment is a later scope row (SURVEY.md 8(f) rank 4)")
         with self._infer_lock:
             try:
                 if isinstance(texts, str):
@@ -417,6 +452,8 @@ class TTS:
                         seg2orig.append(i)
                 feats = [self._phones_and_bert(s) for s in segs]
                 ids, prompts, berts, ges, phones2_all = [], [], [], [], []
+                word2ph_all = [f[1] for f in feats]
+                norm_all = [f[3] for f in feats]
                 for k, (ph2, _, b2, _) in enumerate(feats):
                     o = seg2orig[k]
                     prompt, ph1, b1 = self._prompt_for(prompt_audio_paths[o], prompt_audio_texts[o])
@@ -439,7 +476,7 @@ class TTS:
                 orig_idx = orig_idx.cpu()[order]
                 lengths = lengths[order]
 
-                audios = []
+                audios, subs_out = [], []
                 for s in range(0, m, sovits_batch_size):
                     e = min(s + sovits_batch_size, m)
                     sem = pred[s:e]
@@ -451,12 +488,30 @@ class TTS:
                     ends = torch.cumsum(plens, 0)
                     pairs = torch.stack([ends - plens, ends], dim=1)
                     slice_indices = torch.repeat_interleave(pairs, (ln * 2).to(dev), dim=0)
-                    audio, _ = vq.decode(torch.cat(sem).unsqueeze(0).unsqueeze(0), ph_cat, ge_cat, noise_scale=noise_scale,
-                                         speed=speed, cuda_graph=False, slice_indices=slice_indices)
+                    audio, attn = vq.decode(torch.cat(sem).unsqueeze(0).unsqueeze(0), ph_cat, ge_cat, noise_scale=noise_scale,
+                                            speed=speed, cuda_graph=False, slice_indices=slice_indices)
                     audio = audio[0, 0, :]
+                    if return_subtitles:   # TTS.py:768-777: one alignment over the time-concatenated batch
+                        w2p_cat = {"word": [w for o in oi for w in word2ph_all[o]["word"]],
+                                   "ph": [c for o in oi for c in word2ph_all[o]["ph"]]}
+                        subtitles = sub.get_subtitles(w2p_cat, sub.viterbi_monotonic(attn), speed, sovits_hz=self.sovits_hz)
+                        self._close_subtitles(subtitles, w2p_cat, None)
                     peak = audio.abs().max()
                     if peak > 1.0:
                         audio = audio / peak
+                    if return_subtitles:   # TTS.py:783-804: the word timings, not the token counts, cut the batch apart
+                        last_i = 0
+                        for o in oi:
+                            best_i = sub.find_subtitles(subtitles, word2ph_all[o], last_i)
+                            part = subtitles[last_i:best_i]
+                            last_i = best_i
+                            a = audio[int(part[0]["start_s"] * self.samplerate):int(part[-1]["end_s"] * self.samplerate)]
+                            h, t = self._find_head_threshold_offsets(a), self._find_tail_threshold_offsets(a)
+                            audios.append(a[h:-t].float().cpu().numpy())
+                            part[0]["start_s"] += h / self.samplerate
+                            part[-1]["end_s"] -= t / self.samplerate
+                            subs_out.append(sub.sub2text_index(part, norm_all[o], segs[o]))
+                        continue
                     pos = 0.0
                     for l in ln.tolist():
                         nxt = pos + l * 2 * vq.samples_per_frame / speed
@@ -466,9 +521,14 @@ class TTS:
                         audios.append(a[h:-t].float().cpu().numpy())
 
                 ordered = [None] * len(audios)
+                ordered_subs = [None] * len(audios)
                 for cur, o in enumerate(orig_idx.tolist()):
                     ordered[o] = audios[cur]
+                    if return_subtitles:
+                        ordered_subs[o] = subs_out[cur]
                 per_text = [[] for _ in range(n)]
+                per_text_subs = [[] for _ in range(n)]
+                last_orig, cur_text_l = None, 0
                 for k, a in enumerate(ordered):
                     per_text[seg2orig[k]].append(a)
                     tail = segs[k][-1]
@@ -479,10 +539,18 @@ class TTS:
                     else:
                         sc = 1.0
                     per_text[seg2orig[k]].append(np.zeros(int(cut_mute * sc * self.samplerate), dtype=a.dtype))
+                    if return_subtitles:   # TTS.py:843-852: spans are per segment; shift them into the whole text
+                        if seg2orig[k] != last_orig:
+                            cur_text_l, last_orig = 0, seg2orig[k]
+                        ordered_subs[k][-1]["end_s"] += cut_mute * sc
+                        sub.increment_subtitle_indices(ordered_subs[k], cur_text_l)
+                        per_text_subs[seg2orig[k]].append(ordered_subs[k])
+                        cur_text_l += len(segs[k])
                 clips = []
-                for parts, t in zip(per_text, texts):
+                for parts, sparts, t in zip(per_text, per_text_subs, texts):
                     a = np.concatenate(parts) if parts else np.zeros(0, np.float32)
-                    clips.append(AudioClip(self.audio_queue, a, self.samplerate, len(a) / self.samplerate, [], t))
+                    subtitles = sub.cat_subtitles(*sparts) if return_subtitles else []
+                    clips.append(AudioClip(self.audio_queue, a, self.samplerate, len(a) / self.samplerate, subtitles, t))
                 return tuple(clips)
             finally:
                 self._empty_cache()

@@ -193,6 +193,16 @@ int gsv_voc_enc_p(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* 
                   const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* Subtitle alignment: monotonic Viterbi path of vocoder frames over phonemes -- replaces
+ * TTS._viterbi_monotonic (gsv_tts/TTS.py:1744-1797), which TTS.infer / infer_stream / infer_batched call on
+ * the `attn` returned by vq_model.decode (TTS.py:250, 445, 769).
+ *   attn fp32 [H][T][N] (device; H <= 8 heads, T frames, 2 <= N <= 4096 phonemes)
+ *   -> assign int32 [T] (device): phoneme per frame, -1 before the first frame whose head-averaged attention
+ *   peaks at phoneme 0.  workspace (device) from gsv_align_workspace(T, N); nothing is allocated. */
+size_t gsv_align_workspace(int T, int N);
+int gsv_align_viterbi(const float* attn, int H, int T, int N, int32_t* assign, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

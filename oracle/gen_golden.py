@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "gsv-tts-lite_amd"))
 
-from ref_harness import import_reference  # noqa: E402
+from ref_harness import import_reference, reference_functions  # noqa: E402
 from gsv_tts_lite_amd import synth  # noqa: E402
 
 import tqdm  # noqa: E402
@@ -274,12 +274,94 @@ def gen_decode(Syn):
     np.savez_compressed(os.path.join(GOLD, "decode.npz"), seed=1234, **META, **out)
 
 
+ALIGN_CASES = [  # (seed, heads, frames, phonemes, lead, tail)
+    (100, 4, 60, 17, 0, 0), (101, 4, 60, 17, 5, 6), (102, 4, 200, 40, 3, 20), (103, 4, 500, 120, 0, 10),
+    (104, 2, 64, 2, 0, 4), (105, 4, 33, 3, 2, 2), (106, 4, 300, 300, 4, 9), (107, 4, 40, 70, 0, 0),
+    (108, 4, 1, 5, 0, 0), (109, 4, 700, 90, 10, 30), (110, 4, 150, 1100, 2, 5), (111, 8, 90, 2500, 0, 3),
+]
+
+
+def _word2ph(n_ph, seed):
+    """words of 1-4 phonemes covering exactly n_ph phonemes (the last word is a pause mark when it is 1 long)"""
+    rng = np.random.default_rng(seed)
+    words, phs, left, k = [], [], n_ph, 0
+    while left > 0:
+        c = int(min(left, rng.integers(1, 5)))
+        words.append("w%d" % k)
+        phs.append(c)
+        left -= c
+        k += 1
+    if phs[-1] == 1:
+        words[-1] = "."
+    return {"word": words, "ph": phs}
+
+
+def gen_subtitles():
+    """Subtitle alignment + host bookkeeping: TTS._viterbi_monotonic / _is_normal_assign / _get_subtitles /
+    _find_subtitles / _cat_subtitles and TextProcessor.sub2text_index, run from the reference's own source.
+    TTS.py cannot be imported here (av / torchaudio are absent), so the function definitions are compiled from
+    the reference file at generation time (ref_harness.reference_functions); only their outputs are stored.
+    The attention inputs are regenerated from a seed (synth.synth_attn); the fixture keeps a checksum."""
+    import bisect, copy, json, re
+    tf = reference_functions("gsv_tts/TTS.py", ["_viterbi_monotonic", "_is_normal_assign", "_get_subtitles", "_find_subtitles",
+                                               "_cat_subtitles"], {"torch": torch})
+
+    class Self:            # the attributes those methods read
+        sovits_hz = 50
+    out, host = {}, {"get_subtitles": [], "is_normal_assign": [], "find_subtitles": [], "cat_subtitles": [], "sub2text_index": []}
+    for (seed, H, T, P, lead, tail) in ALIGN_CASES:
+        a = synth.synth_attn(seed, H, T, P, lead, tail)
+        assign = tf["_viterbi_monotonic"](Self(), tt(a))
+        out["assign_%d" % seed] = assign.numpy()
+        out["check_%d" % seed] = np.float64(a.astype(np.float64).sum())
+        host["is_normal_assign"].append({"seed": seed, "want": bool(tf["_is_normal_assign"](Self(), assign))})
+        if T > 1 and P <= 300:
+            for speed, last_end in ((1.0, 0), (1.3, 1.7)):
+                for extra in (0, 3):   # word list longer than the aligned phonemes -> the early-break branch
+                    w2p = _word2ph(P + extra, seed)
+                    subs = tf["_get_subtitles"](Self(), w2p, assign, speed, last_end_s=last_end)
+                    host["get_subtitles"].append({"seed": seed, "word2ph": w2p, "speed": speed, "last_end_s": last_end, "want": subs})
+    out["cases"] = np.array(ALIGN_CASES, np.int64)
+    for assign in ([-1, -1, -1], [0, 1, 2, 3], [0, 0, 1, 2, 2, 3], [-1, 0, 0, 1, 1], [5], [2, 2, 3, 3, 4, 5, 6, 6]):
+        host["is_normal_assign"].append({"assign": assign, "want": bool(tf["_is_normal_assign"](Self(), torch.tensor(assign)))})
+    mk = lambda words, t0=0.0: [{"text": w, "start_s": t0 + 0.25 * i, "end_s": t0 + 0.25 * (i + 1)} for i, w in enumerate(words)]
+    subs = mk(["a", "b", ".", "c", "d", "e", "!", "a", "b", "."])
+    for w2p, last_i in (({"word": ["a", "b", "."]}, 0), ({"word": ["c", "d", "e", "!"]}, 3), ({"word": ["a", "b", "."]}, 3),
+                        ({"word": ["x", "y"]}, 2), ({"word": ["a"] * 12}, 0), ({"word": ["b", "."]}, 9)):
+        host["find_subtitles"].append({"subtitles": subs, "word2ph": w2p, "last_i": last_i,
+                                       "want": int(tf["_find_subtitles"](Self(), subs, w2p, last_i))})
+    lists = [mk(["a", "b"], 0.5), mk(["c"], 3.0), mk(["d", "e", "f"], 0.125)]
+    host["cat_subtitles"].append({"lists": copy.deepcopy(lists), "want": tf["_cat_subtitles"](Self(), *copy.deepcopy(lists))})
+    pf = reference_functions("gsv_tts/TextProcessor.py", ["split_text", "LIS_mapping", "linear_interpolate", "sub2text_index"],
+                             {"re": re, "bisect": bisect})
+    texts = [
+        ("hello world, this is a test.", "Hello world, this is a test.", ["hello", "world", ",", "this", "is", "a", "test", "."]),
+        ("it costs five dollars today.", "It costs $5 today.", ["it", "costs", "five", "dollars", "today", "."]),
+        ("\u4eca\u5929\u5929\u6c14\u5f88\u597d.", "\u4eca\u5929\u5929\u6c14\u5f88\u597d\uff01", ["\u4eca\u5929", "\u5929\u6c14", "\u5f88", "\u597d", "."]),
+        ("a a a b a.", "a b a a a.", ["a", "a", "a", "b", "a", "."]),
+        ("one two three.", "1 2 3", ["one", "two", "three", "."]),
+        ("x y z.", "x y z.", ["x", "q", "z", "."]),
+    ]
+    for norm, orig, words in texts:
+        subs = mk(words)
+        host["sub2text_index"].append({"norm_text": norm, "orig_text": orig, "subtitles": copy.deepcopy(subs),
+                                       "want": pf["sub2text_index"](copy.deepcopy(subs), norm, orig)})
+    for cand in ([[0], [1], [2]], [[2, 5], [0, 3], [1, 4], []], [[], []], [[3, 1], [2], [3, 4], [0, 5]], [[1, 2, 3]] * 4):
+        host.setdefault("lis_mapping", []).append({"candidates": cand, "want": pf["LIS_mapping"]([list(c) for c in cand])})
+    for idx in ([-1, -1, 4, -1, -1, 9, -1], [-1] * 3, [0, -1, -1, -1, 7], [-1, -1, -1, 2], [5, -1, -1]):
+        host.setdefault("linear_interpolate", []).append({"indices": idx, "want": pf["linear_interpolate"](list(idx))})
+    np.savez_compressed(os.path.join(GOLD, "align.npz"), **META, **out)
+    with open(os.path.join(GOLD, "subtitles.json"), "w") as f:
+        json.dump(host, f, ensure_ascii=True, indent=1)
+    print("subtitles:", len(ALIGN_CASES), "alignments,", {k: len(v) for k, v in host.items()})
+
+
 if __name__ == "__main__":
     tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
@@ -287,3 +369,4 @@ if __name__ == "__main__":
     if "sample" in which: gen_sample(sample)
     if "vocoder" in which: gen_vocoder(Syn)
     if "decode" in which: gen_decode(Syn)
+    if "subtitles" in which: gen_subtitles()

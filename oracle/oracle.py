@@ -556,3 +556,49 @@ def device_sample_probs(logits, top_k, temperature, top_p=1.0):
         x = np.where(x < pivot, -np.inf, x)
     e = np.exp(x - x[np.isfinite(x)].max())
     return e / e.sum()
+
+
+# ---------------------------------------------------------------------------------------------
+# subtitle alignment (TTS._viterbi_monotonic, gsv_tts/TTS.py:1744-1797)
+# ---------------------------------------------------------------------------------------------
+def viterbi_normal(attn):
+    """head-averaged attention used by the alignment, TTS.py:1748-1767: heads whose arg-max is the last phoneme
+    do not vote; frames without votes get the fixed near-uniform row.  That row's renormalising sum is taken
+    in fp64 (closed form): torch's fp32 row sum depends on the host's vector width, so the reference has no
+    device-independent value for that one scalar."""
+    a = _f32(attn)
+    H, T, N = a.shape
+    votes = a.argmax(-1) != N - 1                                    # [H, T]
+    count = votes.sum(0)
+    s = np.zeros((T, N), np.float32)
+    for h in range(H):
+        s = s + a[h] * votes[h][:, None].astype(np.float32)
+    f1, f09, f11 = np.float32(1.0 / N), np.float32(0.9 / N), np.float32(1.1 / N)
+    row = np.full(N, f1, np.float32)
+    row[N - 1] = f09
+    row[1] = f11
+    dsum = (np.float64(N - 2) * np.float64(f1) + np.float64(f09) + np.float64(f11)) if N > 2 else np.float64(f1) + np.float64(f11)
+    row = row / np.float32(dsum)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = s / count.astype(np.float32)[:, None]
+    return np.where(count[:, None] > 0, mean, row[None, :]).astype(np.float32)
+
+
+def viterbi_monotonic(attn):
+    """attn [H, T, N] -> int64 [T]; TTS.py:1744-1797 (dp over frames, stay-or-advance-by-one, ties stay)."""
+    normal = viterbi_normal(attn)
+    T, N = normal.shape
+    peak0 = normal.argmax(-1) == 0
+    first_zero = int(np.nonzero(peak0)[0][0]) if peak0.any() else 0
+    dp = normal[0].copy()
+    adv = np.zeros((T, N), bool)
+    for t in range(1, T):
+        shifted = np.concatenate([np.float32([-np.inf]), dp[:-1]])
+        adv[t] = shifted > dp
+        dp = normal[t] + np.where(adv[t], shifted, dp)
+    path = np.zeros(T, np.int64)
+    path[-1] = int(dp.argmax())
+    for t in range(T - 2, -1, -1):
+        path[t] = path[t + 1] - int(adv[t + 1, path[t + 1]])
+    path[:first_zero] = -1
+    return path

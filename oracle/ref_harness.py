@@ -33,3 +33,25 @@ def import_reference():
     from gsv_tts.GPT_SoVITS.GPT.utils import sample  # noqa
     from gsv_tts.GPT_SoVITS.SoVITS.models import SynthesizerTrn  # noqa
     return Text2SemanticDecoder, sample, SynthesizerTrn
+
+
+def reference_functions(relpath, names, namespace=None):
+    """Compile the named function definitions (module-level or methods) of a reference file WITHOUT importing
+    the module -- for files whose imports need packages this container lacks (gsv_tts/TTS.py needs `av` and
+    `torchaudio`).  The source is read from the reference tree at call time and executed in `namespace`;
+    nothing is written anywhere.  Returns {name: function}."""
+    import ast
+    path = os.path.join(REF_ROOT, relpath)
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    want, found = set(names), []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            found.append(node)
+    mod = ast.Module(body=found, type_ignores=[])
+    ns = dict(namespace or {})
+    exec(compile(mod, path, "exec"), ns)
+    missing = want - set(ns)
+    if missing:
+        raise RuntimeError("not found in %s: %s" % (relpath, sorted(missing)))
+    return {n: ns[n] for n in names}

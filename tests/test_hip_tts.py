@@ -117,3 +117,112 @@ def test_tts_infer_stream_chunks(dev, dtype):
                                        overlap_len=2, is_cut_text=False, debug=False))
         assert len(clips2) == len(clips)
         assert abs(sum(len(c.audio_data) for c in clips2) - total) <= 320 * len(clips)
+
+
+def _word_frontend(text):
+    """words = latin runs or single marks; one phoneme per character; norm_text == text"""
+    import re
+    words = re.findall(r"[A-Za-z]+|[^\sA-Za-z]", text)
+    ids = [1 + (ord(c) * 7) % 690 for w in words for c in w]
+    return ids, {"word": words, "ph": [len(w) for w in words]}, None, text
+
+
+def _check_subtitles(subs, text, audio_len_s):
+    assert subs, "no subtitles"
+    prev = 0.0
+    for s in subs:
+        assert set(s) >= {"text", "start_s", "end_s", "orig_idx_start", "orig_idx_end"}
+        assert s["start_s"] >= prev - 1e-9
+        if s["end_s"] is not None:
+            assert s["end_s"] >= s["start_s"] - 1e-9
+            prev = s["end_s"]
+        assert 0 <= s["orig_idx_start"] < s["orig_idx_end"] <= len(text) + 1
+    assert prev <= audio_len_s + 1.0
+
+
+def test_tts_subtitles(dev, monkeypatch):
+    """return_subtitles=True through the facade (TTS.py:250-271, 444-488, 768-852): the device alignment of the
+    real enc_p attention equals the oracle's path, the audio does not change, the word timings are ordered and
+    the spans index the caller's text."""
+    from gsv_tts_lite_amd import subtitles as sub
+    from oracle import oracle as orc
+    tts, AudioClip = _make_tts(dev, "bfloat16")
+    tts.set_text_frontend(_word_frontend)
+    seen = []
+    real = sub.viterbi_monotonic
+
+    def spy(attn):
+        out = real(attn)
+        seen.append((attn.float().cpu().numpy(), out.cpu().numpy()))
+        return out
+    monkeypatch.setattr(sub, "viterbi_monotonic", spy)
+    text = "Hello there, this is a subtitle test."
+    plain = tts.infer("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0)
+    clip = tts.infer("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0, return_subtitles=True)
+    assert plain.subtitles == [] and len(seen) == 1
+    np.testing.assert_allclose(clip.audio_data, plain.audio_data, atol=1e-5)
+    a, got = seen[0]
+    assert a.shape[0] == 4 and np.array_equal(got, orc.viterbi_monotonic(a))
+    _check_subtitles(clip.subtitles, text, clip.audio_len_s)
+    for s in clip.subtitles[:-1]:
+        assert text[s["orig_idx_start"]:s["orig_idx_end"]] == s["text"]
+    # streaming: cumulative chunks hand out only new words; an unfinished last word has no end yet
+    seen.clear()
+    clips = list(tts.infer_stream("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0, stream_chunk=8,
+                                  overlap_len=2, is_cut_text=False, debug=False, return_subtitles=True))
+    assert len(seen) == len(clips)
+    for a, got in seen:
+        assert np.array_equal(got, orc.viterbi_monotonic(a))
+    assert clips[-1].subtitles and clips[-1].subtitles[-1]["end_s"] is not None
+    for c in clips[:-1]:
+        if c.subtitles:
+            assert c.subtitles[-1]["end_s"] is None
+    streamed = [s for c in clips for s in c.subtitles]
+    _check_subtitles(streamed, text, clips[-1].audio_len_s)
+
+
+def test_tts_batched_subtitles(dev, monkeypatch):
+    """infer_batched(return_subtitles=True), TTS.py:768-852: one alignment per time-concatenated vocoder batch, the
+    word timings cut the batch apart, spans are shifted into each original text.  The GPT is replaced by fixed
+    token lists and the attention by a per-segment ridge so that every word is reached (random weights give no
+    usable attention); decode() itself (flow + Generator on the concatenated batch) is the real one."""
+    tts, AudioClip = _make_tts(dev, "bfloat16")
+    tts.set_text_frontend(_word_frontend)
+    t2s = next(iter(tts.gpt_models.values())).t2s_model
+    vq = next(iter(tts.sovits_models.values())).vq_model
+    rng = np.random.default_rng(5)
+
+    def fake_gpt(ids, prompts, berts, **kw):
+        n = len(ids)
+        order = list(range(n))[::-1]                      # completion order != request order
+        return [torch.from_numpy(rng.integers(0, 1024, 30 + 4 * i)).to(dev) for i in order], torch.tensor(order)
+    monkeypatch.setattr(t2s, "infer_batched", fake_gpt)
+    real_decode = vq.decode
+
+    def ridge_decode(codes, text, ge, **kw):
+        audio, attn = real_decode(codes, text, ge, **kw)
+        pairs = kw["slice_indices"].cpu().numpy()
+        syn = np.zeros(tuple(attn.shape), np.float32)
+        t0 = 0
+        while t0 < pairs.shape[0]:
+            t1 = t0
+            while t1 < pairs.shape[0] and (pairs[t1] == pairs[t0]).all():
+                t1 += 1
+            p0, p1 = pairs[t0]
+            syn[:, t0:t1, p0:p1] = synth.synth_attn(int(p0), 4, t1 - t0, int(p1 - p0), noise=0.05)
+            t0 = t1
+        return audio, torch.from_numpy(syn).to(attn.device)
+    monkeypatch.setattr(vq, "decode", ridge_decode)
+    texts = ["First one is here. Second follows!", "Another text", "Third, with a comma."]
+    clips = tts.infer_batched("spk.wav", "prompt.wav", "prompt text.", texts, top_k=1, noise_scale=0.0, cut_minlen=8,
+                              sovits_batch_size=3, return_subtitles=True)
+    assert len(clips) == 3
+    for c, t in zip(clips, texts):
+        full = t if t[-1] in ".!?," else t + "."
+        _check_subtitles(c.subtitles, full, c.audio_len_s)
+        words = [s["text"] for s in c.subtitles]
+        assert "".join(words).replace(".", "").startswith(full.replace(" ", "").replace(".", "")[:6])
+        assert abs(c.subtitles[-1]["end_s"] - c.audio_len_s) < 0.75
+        for s in c.subtitles:   # spans of later segments are shifted by len(segment) as in TTS.py:852, which does
+            if len(s["text"]) > 1:   # not count the blank cut_text() dropped between segments
+                assert s["text"] in full[max(0, s["orig_idx_start"] - 2):s["orig_idx_end"] + 2]
