@@ -23,6 +23,8 @@ EXPORTS = [
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
     "gsv_align_workspace", "gsv_align_viterbi",
+    "gsv_ref_create", "gsv_ref_destroy", "gsv_ref_load_tensor", "gsv_ref_finalize", "gsv_ref_workspace",
+    "gsv_ref_spectrogram", "gsv_ref_get_ge", "gsv_ref_extract_latent",
 ]
 
 
@@ -43,6 +45,11 @@ class VocConfig(ctypes.Structure):
                 ("upsample_rates", ctypes.c_int * 8), ("upsample_kernel_sizes", ctypes.c_int * 8),
                 ("n_resblock_kernels", ctypes.c_int), ("resblock_kernel_sizes", ctypes.c_int * 4),
                 ("resblock_dilations", ctypes.c_int * 4), ("n_flows", ctypes.c_int), ("dtype", ctypes.c_int)]
+
+
+class RefConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("n_fft", "hop", "spec_bins", "hidden", "n_head", "kernel", "gin", "sv_dim", "ssl_dim", "bins")]
 
 
 _LIB = None
@@ -84,6 +91,13 @@ def lib():
         "gsv_voc_has_enc_p": [vp],
         "gsv_voc_enc_p": [vp, vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, sz, vp],
         "gsv_align_viterbi": [vp, i, i, i, vp, vp, sz, vp],
+        "gsv_ref_create": [ctypes.POINTER(RefConfig), ctypes.POINTER(vp)],
+        "gsv_ref_destroy": [vp],
+        "gsv_ref_load_tensor": [vp, ctypes.c_char_p, vp, i64, vp],
+        "gsv_ref_finalize": [vp, vp],
+        "gsv_ref_spectrogram": [vp, vp, i, vp, vp, sz, vp],
+        "gsv_ref_get_ge": [vp, vp, i, vp, vp, vp, sz, vp],
+        "gsv_ref_extract_latent": [vp, vp, i, vp, vp, vp, sz, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -95,6 +109,8 @@ def lib():
     L.gsv_voc_workspace.restype = sz
     L.gsv_voc_enc_workspace.argtypes = [vp, i, i]
     L.gsv_voc_enc_workspace.restype = sz
+    L.gsv_ref_workspace.argtypes = [vp, i, i, i]
+    L.gsv_ref_workspace.restype = sz
     L.gsv_align_workspace.argtypes = [i, i]
     L.gsv_align_workspace.restype = sz
     _LIB = L

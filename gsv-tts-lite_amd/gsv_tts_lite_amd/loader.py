@@ -143,7 +143,9 @@ def get_sovits_weights(sovits_path, tts_config) -> Sovits:
     if sovits_path.startswith("synthetic://"):
         _, q = _synthetic(sovits_path)
         hps = synth.sovits_hps(q.get("version", "v2Pro"))
-        weights = {k: torch.from_numpy(v) for k, v in synth.sovits_weights(hps, seed=int(q.get("seed", 1234))).items()}
+        seed = int(q.get("seed", 1234))
+        weights = {k: torch.from_numpy(v) for k, v in synth.sovits_weights(hps, seed=seed).items()}
+        weights.update({k: torch.from_numpy(v) for k, v in synth.ref_audio_weights(hps, seed=seed).items()})
         return _build_sovits(hps, weights, tts_config)
     if os.path.isdir(sovits_path):
         from safetensors.torch import load_file

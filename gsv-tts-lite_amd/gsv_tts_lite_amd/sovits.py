@@ -167,6 +167,7 @@ class SynthesizerTrn:
         self._weights = None
         self._voc = None
         self.enc_p = None
+        self._ref = None
         self.native_enc_p = True   # bf16: run enc_p on device when its tensors are loaded (fp32 keeps the torch path)
 
     def load_state_dict(self, sd, strict=False):
@@ -193,6 +194,31 @@ class SynthesizerTrn:
             self._codebook_decode = codebook_decode
         except KeyError:
             self.enc_p = None  # hot-path-only weight sets (no enc_p tensors): flow_dec still works
+
+    def _ref_audio(self):
+        if self._ref is None:
+            from .refaudio import RefAudioNative, has_ref_tensors
+            if self._voc is None:
+                raise RuntimeError("call initialize_runtime first")
+            if not has_ref_tensors(self._weights):
+                raise RuntimeError("get_ge / extract_latent need the ref_enc.* / ssl_proj.* tensors in the state dict")
+            self._ref = RefAudioNative(self._weights, self.gin_channels, self.is_v2pro, self.device)
+        return self._ref
+
+    @torch.inference_mode()
+    def spectrogram(self, audio):
+        """the Spectrogram transform of TTS._get_spec (TTS.py:1591-1604) for this model's filter / hop length"""
+        return self._ref_audio().spectrogram(audio)
+
+    @torch.inference_mode()
+    def get_ge(self, refer, sv_emb=None):
+        """models.py:371-378, on the device (csrc/refaudio.h)"""
+        return self._ref_audio().get_ge(refer, sv_emb if self.is_v2pro else None)
+
+    @torch.inference_mode()
+    def extract_latent(self, x):
+        """models.py:431-434, on the device"""
+        return self._ref_audio().extract_latent(x)
 
     def flow_dec(self, z_p, y_mask, ge):
         """models.py:380-383"""

@@ -362,3 +362,76 @@ def synth_attn(seed: int, heads: int, frames: int, phonemes: int, lead: int = 0,
     d = (np.arange(phonemes)[None, None, :] - c[:, :, None]).astype(np.float32)
     u = rng.random((heads, frames, phonemes), dtype=np.float32)
     return (np.float32(1) / (np.float32(1) + d * d) + np.float32(noise) * u).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# Reference-audio path: ref_enc / sv_emb / prelu / ssl_proj tensors + inputs
+# --------------------------------------------------------------------------------------
+
+def ref_audio_spec(hps: dict) -> "OrderedDict[str, tuple]":
+    """Names/shapes as the reference's SynthesizerTrn.state_dict() has them (SoVITS/models.py:305-318)."""
+    gin = hps["model"]["gin_channels"]
+    s = OrderedDict()
+    s["ref_enc.spectral.0.fc.weight"] = (128, 704)
+    s["ref_enc.spectral.0.fc.bias"] = (128,)
+    s["ref_enc.spectral.3.fc.weight"] = (128, 128)
+    s["ref_enc.spectral.3.fc.bias"] = (128,)
+    for i in (0, 1):
+        s["ref_enc.temporal.%d.conv1.conv.weight" % i] = (256, 128, 5)
+        s["ref_enc.temporal.%d.conv1.conv.bias" % i] = (256,)
+    for n in ("w_qs", "w_ks", "w_vs", "fc"):
+        s["ref_enc.slf_attn.%s.weight" % n] = (128, 128)
+        s["ref_enc.slf_attn.%s.bias" % n] = (128,)
+    s["ref_enc.fc.fc.weight"] = (gin, 128)
+    s["ref_enc.fc.fc.bias"] = (gin,)
+    s["ssl_proj.weight"] = (768, 768, 2)
+    s["ssl_proj.bias"] = (768,)
+    s["quantizer.vq.layers.0._codebook.embed"] = (1024, 768)
+    if hps["model"]["version"] in ("v2Pro", "v2ProPlus"):
+        s["sv_emb.weight"] = (gin, 20480)
+        s["sv_emb.bias"] = (gin,)
+        s["prelu.weight"] = (gin,)
+    return s
+
+
+def ref_audio_weights(hps: dict, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """Seeded tensors for ref_audio_spec; the codebook is the same tensor sovits_weights() generates.  The first
+    linear is scaled for |STFT| inputs of O(30), the attention projections for logits with a spread of a few units."""
+    out = OrderedDict()
+    for name, shape in ref_audio_spec(hps).items():
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        if name.endswith("_codebook.embed"):
+            v = _std(name, shape, 1.0, seed)
+        elif name == "ref_enc.spectral.0.fc.weight":
+            v = _std(name, shape, 0.05 / math.sqrt(fan_in), seed)
+        elif name in ("ref_enc.slf_attn.w_qs.weight", "ref_enc.slf_attn.w_ks.weight"):
+            v = _std(name, shape, 2.5 / math.sqrt(fan_in), seed)
+        elif name == "prelu.weight":
+            v = _std(name, shape, 0.05, seed, mean=0.25)
+        elif name.endswith("weight"):
+            v = _std(name, shape, 1.0 / math.sqrt(fan_in), seed)
+        else:
+            v = _std(name, shape, 0.05, seed)
+        out[name] = v
+    return out
+
+
+def synth_audio(i: int, n_samples: int, seed: int = 1234) -> np.ndarray:
+    """Mono waveform in [-1, 1]: a few drifting partials + noise (only IEEE ops of float64 -> float32)."""
+    t = np.arange(n_samples, dtype=np.float64) / 32000.0
+    f = 110.0 + 30.0 * (hashed_uniform("aud%d.f" % i, (6,), seed).astype(np.float64) + 1.0)
+    x = np.zeros(n_samples, np.float64)
+    for k in range(6):
+        x += (0.5 / (k + 1)) * np.sin(2 * np.pi * f[k] * (k + 1) * t * (1.0 + 0.05 * t))
+    x += 0.05 * hashed_uniform("aud%d.n" % i, (n_samples,), seed).astype(np.float64)
+    return (0.3 * x).astype(np.float32)
+
+
+def synth_sv_emb(i: int, seed: int = 1234) -> np.ndarray:
+    """ERes2Net speaker-verification embedding stand-in, [1, 20480]."""
+    return (hashed_uniform("spk%d.sv" % i, (1, 20480), seed) * np.float32(_SQRT3)).astype(np.float32)
+
+
+def synth_ssl(i: int, n_frames: int, seed: int = 1234) -> np.ndarray:
+    """CN-HuBERT last_hidden_state stand-in, channels-first [1, 768, n_frames]."""
+    return (hashed_uniform("ssl%d" % i, (1, 768, n_frames), seed) * np.float32(_SQRT3)).astype(np.float32)

@@ -8,12 +8,14 @@ Drop-in surface kept from the reference:
     load_gpt_model / load_sovits_model / unload_* / get_*_list                 TTS.py:1264-1345
     AudioClip(audio_data, samplerate, audio_len_s, subtitles, orig_text)       Player.py:68-99
 
-What sits in front of the hot path in the reference -- G2P text frontends, CN-HuBERT prompt
-tokens, ERes2Net/ref_enc speaker embedding -- is OUT OF SCOPE of this build (SURVEY.md section 2
-rows 7-9: CPU string processing and once-per-speaker models whose third-party packages are not
-installable here).  Their *outputs* enter through the same caches the reference keeps:
-    cache_spk_audio(path, ge=...)                      (reference fills it via get_ge, TTS.py:1346)
-    cache_prompt_audio(path, text, prompt=..., phones1=..., bert1=...)       (TTS.py:1391)
+What sits in front of the hot path in the reference -- G2P text frontends, audio file decoding / resampling,
+the CN-HuBERT and ERes2Net models -- is OUT OF SCOPE of this build (CPU string
+processing and third-party models whose packages are not installable here).  Their *outputs* enter through the
+same caches the reference keeps:
+    cache_spk_audio(path, ge=...)  or  cache_spk_audio(path, audio=<waveform>, sv_emb=<ERes2Net embedding>)
+                                   (spectrogram + get_ge on the device; the reference: TTS.py:1346, 1576)
+    cache_prompt_audio(path, text, prompt=... | ssl_content=<CN-HuBERT features>, phones1=..., bert1=...)
+                                   (extract_latent on the device; TTS.py:1391, 1556)
     set_text_frontend(fn)   fn(text) -> (phones2, word2ph, bert2[P,1024], norm_text)
 With those in place infer()/infer_batched()/infer_stream() behave as in the reference, including
 `return_subtitles=True`: the frame->phoneme alignment runs on the device (subtitles.viterbi_monotonic ->
@@ -176,20 +178,40 @@ class TTS:
         """fn(text) -> (phones2 list[int], word2ph dict, bert2 [P,1024] tensor, norm_text)"""
         self._text_frontend = fn
 
-    def cache_spk_audio(self, spk_audio_paths, sovits_model=None, ge=None):
-        if ge is None:
-            raise NotImplementedError("computing ge from audio (ref_enc + ERes2Net) is outside this build's scope; "
-                                      "pass ge=[1, gin, 1] (SURVEY.md section 2 rows 8-9)")
+    def cache_spk_audio(self, spk_audio_paths, sovits_model=None, ge=None, audio=None, sv_emb=None):
+        """TTS.py:1346-1389.  Either the finished embedding `ge` [1, gin, 1], or the reference waveform `audio`
+        (mono fp32 at the model rate, what TTS._load_audio + _resample give) plus, for v2Pro / v2ProPlus, the ERes2Net
+        embedding `sv_emb` [1, 20480]: then the spectrogram (TTS._get_spec) and get_ge run on the device."""
         sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+        if ge is None:
+            if audio is None:
+                raise NotImplementedError("decoding / resampling audio files and the ERes2Net model are outside this build's "
+                                          "scope; pass ge=[1, gin, 1], or audio=<waveform> (+ sv_emb=[1, 20480])")
+            if sovits_model not in self.sovits_models:
+                self.load_sovits_model(sovits_model)
+            vq = self.sovits_models[sovits_model].vq_model
+            audio = audio.to(self.tts_config.device).float().reshape(1, -1)
+            peak = audio.abs().max()
+            if peak > 1:                       # TTS.py:1586-1588
+                audio = audio / min(2, float(peak))
+            ge = vq.get_ge(vq.spectrogram(audio), sv_emb)
         entry = self.spk_audio_cache.setdefault(spk_audio_paths, {"ge": {}})
         entry["ge"][sovits_model] = ge.to(self.tts_config.device)
 
-    def cache_prompt_audio(self, prompt_audio_paths, prompt_audio_texts, prompt=None, phones1=None, bert1=None):
+    def cache_prompt_audio(self, prompt_audio_paths, prompt_audio_texts, prompt=None, phones1=None, bert1=None,
+                           ssl_content=None, sovits_model=None):
+        """TTS.py:1391-1440.  `prompt` int64 [1, Ly], or `ssl_content` [1, 768, Th] (CN-HuBERT last_hidden_state,
+        transposed as in TTS._get_prompt): then extract_latent runs on the device."""
         if not prompt_audio_texts:
             raise ValueError("prompt_audio_text must not be empty")
+        if prompt is None and ssl_content is not None:
+            sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+            if sovits_model not in self.sovits_models:
+                self.load_sovits_model(sovits_model)
+            prompt = self.sovits_models[sovits_model].vq_model.extract_latent(ssl_content)[0, 0].unsqueeze(0)
         if prompt is None or phones1 is None:
-            raise NotImplementedError("CN-HuBERT prompt tokenisation / G2P are outside this build's scope; pass "
-                                      "prompt=int64[1,Ly], phones1=list[int] (and bert1=[Lx1,1024])")
+            raise NotImplementedError("CN-HuBERT and G2P are outside this build's scope; pass prompt=int64[1,Ly] or "
+                                      "ssl_content=[1,768,Th], and phones1=list[int] (and bert1=[Lx1,1024])")
         if bert1 is None:
             bert1 = torch.zeros(len(phones1), 1024)
         self.prompt_audio_cache[prompt_audio_paths] = {

@@ -203,6 +203,47 @@ size_t gsv_align_workspace(int T, int N);
 int gsv_align_viterbi(const float* attn, int H, int T, int N, int32_t* assign, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* Reference-audio path, once per new speaker / prompt; fp32 in both numerics modes.
+ * Replaces, on the device:
+ *   gsv_ref_spectrogram     the torchaudio Spectrogram inside TTS._get_spec (gsv_tts/TTS.py:1591-1604: n_fft /
+ *                           win = filter_length, hop_length, periodic hann, center + reflect padding, power 1)
+ *   gsv_ref_get_ge          SynthesizerTrn.get_ge (SoVITS/models.py:371-378): ref_enc = MelStyleEncoder
+ *                           (module/modules.py:367-444) on refer[:, :704], + sv_emb(sv) and PReLU for v2Pro / v2ProPlus
+ *   gsv_ref_extract_latent  SynthesizerTrn.extract_latent (models.py:431-434): ssl_proj (k 2, stride 2) and the
+ *                           nearest-codebook search of EuclideanCodebook.quantize (module/core_vq.py:124-128)
+ * Tensors ("ref_enc.*", "sv_emb.*", "prelu.weight", "ssl_proj.*", "quantizer.vq.layers.0._codebook.embed") are
+ * given under their checkpoint names, device fp32, before finalize.  Audio decoding / resampling and the CN-HuBERT
+ * and ERes2Net models that produce `ssl` and `sv_emb` are outside this library. */
+typedef struct gsv_ref gsv_ref;
+typedef struct gsv_ref_config {
+    int n_fft;      /* hps.data.filter_length == win_length (2048) */
+    int hop;        /* hps.data.hop_length (640) */
+    int spec_bins;  /* spectrogram bins ref_enc reads (704, models.py:305,373) */
+    int hidden;     /* MelStyleEncoder style_hidden (128) */
+    int n_head;     /* 2 */
+    int kernel;     /* Conv1dGLU kernel (5) */
+    int gin;        /* gin_channels: 512 (v2) / 1024 (v2Pro, v2ProPlus) */
+    int sv_dim;     /* 20480 for v2Pro / v2ProPlus, 0 for v2 (no sv_emb / prelu) */
+    int ssl_dim;    /* 768 */
+    int bins;       /* codebook size (1024) */
+} gsv_ref_config;
+int gsv_ref_create(const gsv_ref_config* cfg, gsv_ref** out);
+int gsv_ref_destroy(gsv_ref* h);
+int gsv_ref_load_tensor(gsv_ref* h, const char* name, const float* data, int64_t numel, void* stream);
+int gsv_ref_finalize(gsv_ref* h, void* stream);
+/* bytes that cover a spectrogram of n_samples, a get_ge of n_frames and an extract_latent of n_ssl (0 = not used) */
+size_t gsv_ref_workspace(gsv_ref* h, int n_samples, int n_frames, int n_ssl);
+/* audio fp32 [n_samples] (mono, at the model rate) -> spec fp32 [n_fft/2+1][1 + n_samples/hop], channels-first */
+int gsv_ref_spectrogram(gsv_ref* h, const float* audio, int n_samples, float* spec, void* workspace, size_t workspace_bytes,
+                        void* stream);
+/* spec fp32 [>= spec_bins][n_frames] channels-first (row stride n_frames), sv_emb fp32 [sv_dim] or NULL -> ge fp32 [gin] */
+int gsv_ref_get_ge(gsv_ref* h, const float* spec, int n_frames, const float* sv_emb, float* ge, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* ssl fp32 [ssl_dim][n_ssl] channels-first (CN-HuBERT last_hidden_state transposed, TTS.py:1567) -> codes int64
+ * [n_ssl/2]; margin fp32 [n_ssl/2] or NULL = distance gap between the best and the second-best code */
+int gsv_ref_extract_latent(gsv_ref* h, const float* ssl, int n_ssl, int64_t* codes, float* margin, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,12 +356,43 @@ def gen_subtitles():
     print("subtitles:", len(ALIGN_CASES), "alignments,", {k: len(v) for k, v in host.items()})
 
 
+REF_CASES = [("v2Pro", 0, 32000 * 3 + 123, 151), ("v2", 1, 40000, 64), ("v2ProPlus", 2, 2048, 3)]
+
+
+def gen_refaudio(Syn):
+    """Reference-audio path: SynthesizerTrn.get_ge / extract_latent of the imported reference, and the Spectrogram
+    of TTS._get_spec.  torchaudio (a third-party dependency, absent here and unpinned by the reference) is not
+    importable; its Spectrogram(power=1) is |torch.stft(...)| with the arguments TTS.py:1591-1604 passes, which is
+    what runs here.  Inputs and weights are regenerated from seeds; the spectrogram is stored subsampled."""
+    out = {}
+    for ver, i, n_samples, n_ssl in REF_CASES:
+        hps = synth.sovits_hps(ver)
+        m = Syn(1025, 32, n_speakers=300, **hps["model"]).eval()
+        sd = {k: tt(v) for k, v in synth.ref_audio_weights(hps, 1234).items()}
+        sd["quantizer.vq.layers.0._codebook.inited"] = torch.ones(1)   # a trained checkpoint: no k-means re-init
+        assert not m.load_state_dict(sd, strict=False).unexpected_keys
+        a = synth.synth_audio(i, n_samples)
+        spec = torch.stft(tt(a), 2048, 640, 2048, window=torch.hann_window(2048), center=True, pad_mode="reflect",
+                          normalized=False, onesided=True, return_complex=True).abs()
+        sv = synth.synth_sv_emb(i) if ver != "v2" else None
+        ssl = synth.synth_ssl(i, n_ssl)
+        with torch.inference_mode():
+            ge = m.get_ge(spec[None], tt(sv) if sv is not None else None)
+            codes = m.extract_latent(tt(ssl))
+        out[ver + "_spec_sub"] = spec.numpy()[::8, ::4].copy()
+        out[ver + "_spec_sum"] = np.float64(spec.numpy().astype(np.float64).sum())
+        out[ver + "_ge"] = ge.numpy()
+        out[ver + "_codes"] = codes.numpy()
+        print("refaudio", ver, tuple(spec.shape), "ge std %.3f" % ge.std().item(), "codes", tuple(codes.shape))
+    np.savez_compressed(os.path.join(GOLD, "refaudio.npz"), seed=1234, **META, **out)
+
+
 if __name__ == "__main__":
     tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles", "refaudio"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
@@ -370,3 +401,4 @@ if __name__ == "__main__":
     if "vocoder" in which: gen_vocoder(Syn)
     if "decode" in which: gen_decode(Syn)
     if "subtitles" in which: gen_subtitles()
+    if "refaudio" in which: gen_refaudio(Syn)

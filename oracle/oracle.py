@@ -602,3 +602,72 @@ def viterbi_monotonic(attn):
         path[t] = path[t + 1] - int(adv[t + 1, path[t + 1]])
     path[:first_zero] = -1
     return path
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-audio path
+# ---------------------------------------------------------------------------------------------
+def spectrogram(audio, n_fft=2048, hop=640):
+    """torchaudio.transforms.Spectrogram(n_fft, win_length=n_fft, hop_length=hop, center=True, pad_mode="reflect",
+    power=1.0) as TTS._get_spec builds it (gsv_tts/TTS.py:1591-1604).  torchaudio is a third-party dependency that
+    is absent from /root/reference and from this image (the reference pins no version); its published algorithm is
+    |torch.stft(x, n_fft, hop, n_fft, window=hann_window(n_fft) [periodic], center=True, pad_mode="reflect",
+    normalized=False, onesided=True)|, restated here with an fp64 FFT.  -> float32 [n_fft/2+1][1 + n//hop]"""
+    x = np.asarray(audio, np.float64).reshape(-1)
+    xp = np.pad(x, n_fft // 2, mode="reflect")
+    T = 1 + x.shape[0] // hop
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    frames = np.stack([xp[t * hop:t * hop + n_fft] for t in range(T)]) * w
+    return np.abs(np.fft.rfft(frames, axis=1)).T.astype(np.float32)
+
+
+class RefAudioOracle:
+    """SynthesizerTrn.get_ge (SoVITS/models.py:371-378; MelStyleEncoder, module/modules.py:367-444) and
+    extract_latent (models.py:431-434; EuclideanCodebook.quantize, module/core_vq.py:124-128) in numpy fp32."""
+
+    def __init__(self, weights):
+        self.w = {k: _f32(v) for k, v in weights.items()}
+
+    def _lin(self, x, name):
+        return x @ self.w[name + ".weight"].T + self.w[name + ".bias"]
+
+    @staticmethod
+    def _mish(x):
+        sp = np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20)))).astype(np.float32)
+        return x * np.tanh(sp)
+
+    def get_ge(self, spec, sv_emb=None):
+        """spec [bins >= 704][T] channels-first -> ge [gin]"""
+        x = _f32(spec)[:704].T                                          # [T, 704]
+        x = self._mish(self._lin(x, "ref_enc.spectral.0.fc"))
+        x = self._mish(self._lin(x, "ref_enc.spectral.3.fc"))
+        T = x.shape[0]
+        for i in (0, 1):                                                # Conv1dGLU, modules.py:238-254
+            W = self.w["ref_enc.temporal.%d.conv1.conv.weight" % i]     # [256, 128, 5]
+            xp = np.pad(x, ((2, 2), (0, 0)))
+            c = sum(xp[k:k + T] @ W[:, :, k].T for k in range(5)) + self.w["ref_enc.temporal.%d.conv1.conv.bias" % i]
+            x = x + c[:, :128] * (1.0 / (1.0 + np.exp(-c[:, 128:])))
+        q, k, v = (self._lin(x, "ref_enc.slf_attn." + n) for n in ("w_qs", "w_ks", "w_vs"))
+        heads = []
+        for h in range(2):                                              # modules.py:291-363
+            s = q[:, h * 64:(h + 1) * 64] @ k[:, h * 64:(h + 1) * 64].T / np.float32(np.sqrt(128.0))
+            s = np.exp(s - s.max(-1, keepdims=True))
+            heads.append((s / s.sum(-1, keepdims=True)) @ v[:, h * 64:(h + 1) * 64])
+        x = self._lin(np.concatenate(heads, 1), "ref_enc.slf_attn.fc") + x
+        f = self._lin(x, "ref_enc.fc.fc")
+        ge = (f / np.float32(T)).sum(0)                                 # temporal_avg_pool, modules.py:409-419
+        if sv_emb is not None:                                          # models.py:374-377
+            ge = ge + self._lin(_f32(sv_emb).reshape(1, -1), "sv_emb")[0]
+            ge = np.where(ge >= 0, ge, self.w["prelu.weight"] * ge)
+        return ge.astype(np.float32)
+
+    def extract_latent(self, ssl):
+        """ssl [768][Th] channels-first -> (codes int64 [Th//2], margin float32 [Th//2])"""
+        x = _f32(ssl).T                                                 # [Th, 768]
+        To = x.shape[0] // 2
+        W = self.w["ssl_proj.weight"]                                   # [768, 768, 2]
+        y = x[0:2 * To:2] @ W[:, :, 0].T + x[1:2 * To:2] @ W[:, :, 1].T + self.w["ssl_proj.bias"]
+        e = self.w["quantizer.vq.layers.0._codebook.embed"]
+        dist = -(((y * y).sum(1, keepdims=True) - 2 * (y @ e.T)) + (e * e).sum(1)[None, :])
+        top = np.sort(dist, axis=1)
+        return dist.argmax(1).astype(np.int64), (top[:, -1] - top[:, -2]).astype(np.float32)
