@@ -342,7 +342,8 @@ def main():
                     if k["kernel"] in tr:
                         k["traffic"] = tr[k["kernel"]]
                 out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"])
-                out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
+                if a.version == "v2Pro" and a.dtype == "bf16":   # the PMC passes were taken on this configuration
+                    out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
             except Exception:
                 pass
         if world == 1 and not a.no_cpu_baseline:
