@@ -198,6 +198,7 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
 
 // The weights-in-registers path for the Generator's resblock convs (wconv.h).  Returns 1 when the
 // launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
+inline bool wconv_channels(int C) { return C == 16 || C == 24 || C == 32 || C == 48 || C == 64 || C == 96 || C == 128; }
 template <typename AT>
 int run_wconv(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
     (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
@@ -206,19 +207,20 @@ int run_wconv(const Branch* brs, int ld, int n_rows, float in_slope, float out_s
 template <>
 int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
     const int C = brs[0].pc->cout;
-    if (C != 16 && C != 32 && C != 64 && C != 128) return -1;
+    if (!wconv_channels(C)) return -1;
+    const int Ck = C == 24 ? 32 : C;   // 24 channels live in rows of 32 (zero pad channels, zero weight rows): the 32 kernel
     int order[3] = {0, 1, 2};
     for (int i = 0; i < 3; ++i) {
         const PackedConv& q = *brs[i].pc;
-        if (q.cin != C || q.cout != C || q.u != 0 || (q.k != 3 && q.k != 7 && q.k != 11) || q.dil < 1 || q.dil > 5 ||
-            q.pad != (q.k - 1) / 2 * q.dil || ld < C)
+        if (q.cin != Ck || q.cout != C || q.u != 0 || (q.k != 3 && q.k != 7 && q.k != 11) || q.dil < 1 || q.dil > 5 ||
+            q.pad != (q.k - 1) / 2 * q.dil || ld < Ck)
             return -1;
     }
     std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
     // blocks are dealt in proportion to taps + a per-tile overhead (staging, epilogue) in tap units; both the
     // overhead and the block count per shape are measured (tools/tg_bench.hip)
-    const int nblk = C == 128 ? 256 : (C == 64 ? 256 : (C == 32 ? 512 : 768));
-    const double ovh = C == 128 ? 8.0 : (C == 64 ? 14.0 : 50.0);
+    const int nblk = C >= 64 ? 256 : (C >= 32 ? 512 : (C == 24 ? 512 : 768));
+    const double ovh = C >= 96 ? 8.0 : (C == 64 ? 14.0 : (C == 48 ? 30.0 : 50.0));
     double tot = 0;
     for (int i = 0; i < 3; ++i) tot += brs[i].pc->k + ovh;
     int nb[3], used = 0;
@@ -235,7 +237,7 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
     a.k0 = b0.pc->k; a.k1 = b1.pc->k; a.k2 = b2.pc->k;
     a.d0 = b0.pc->dil; a.d1 = b1.pc->dil; a.d2 = b2.pc->dil;
     a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
-    a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
+    a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope; a.cout = C;
     if ((b0.res == nullptr) != (b1.res == nullptr) || (b0.res == nullptr) != (b2.res == nullptr)) return -1;
     auto launch = [&](auto kern, size_t lds) -> int {
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -244,8 +246,10 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
         return GSV_OK;
     };
     if (C == 128) return launch(wconv_kernel<128, 4, 64>, wconv_lds_bytes<128, 4, 64>());
+    if (C == 96) return launch(wconv_kernel<96, 4, 64>, wconv_lds_bytes<96, 4, 64>());     // 3 slices + a staging-only wave
     if (C == 64) return launch(wconv_kernel<64, 2, 128>, wconv_lds_bytes<64, 2, 128>());
-    if (C == 32) return launch(wconv_kernel<32, 1, 256>, wconv_lds_bytes<32, 1, 256>());
+    if (C == 48) return launch(wconv_kernel<48, 2, 64>, wconv_lds_bytes<48, 2, 64>());
+    if (Ck == 32) return launch(wconv_kernel<32, 1, 256>, wconv_lds_bytes<32, 1, 256>());
     return launch(wconv_kernel<16, 1, 256>, wconv_lds_bytes<16, 1, 256>());
 }
 
@@ -1092,9 +1096,13 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
         VocStage& sg = v->stages[i];
         const int ldi = ld_of(sg.cin), ldo = ld_of(sg.cout);
         const int Tn = Tc * sg.u;
-        if (ldo != sg.cout) {  // pad channels feed zero-weight k-steps but must not hold NaN/Inf bit patterns
+        // pad channels feed zero-weight k-steps but must not hold NaN/Inf bit patterns.  The wconv path writes whole
+        // rows (its pad outputs are exact zeros: zero weight rows, zero bias, zero residual), so there only the
+        // transposed conv's output buffer needs clearing; the tapgemm path writes `cout` channels per row.
+        const bool wc = sizeof(AT) == 2 && wconv_channels(sg.cout);
+        if (ldo != sg.cout) {
             for (int q = 0; q < 11; ++q)
-                if (q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
+                if (wc ? q == 0 : q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
         }
         Epi eu; eu.in_slope = 0.1f;
         if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
@@ -1113,6 +1121,7 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
             // the only form its consumer reads, so the second conv stages its input without arithmetic
             int rw = run_wconv<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
             if (rw > 0) return rw;
+            if (rw != 0 && wc && ldo != sg.cout) return fail(GSV_ERR_STATE, "wconv declined a padded stage whose buffers were not cleared");
             if (rw == 0) {
                 rw = run_wconv<AT>(b2, ldo, Tn, 1.0f, 1.0f, st);
                 if (rw > 0) return rw;

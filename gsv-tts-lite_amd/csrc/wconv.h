@@ -33,6 +33,7 @@ struct WConvArgs {
     int ld, n_rows;
     float in_slope;               // leaky-ReLU on the input (1 = none)
     float out_slope;              // leaky-ReLU on the output (1 = none)
+    int cout;                     // real output channels when rows are padded to C (bias has only `cout` entries); 0 = C
     long long* dbg;               // null, or cycle stamps of block 0 / wave 0 per tile phase (tools/tg_bench)
 };
 
@@ -41,7 +42,7 @@ struct WConvArgs {
 template <int C, int MS, int BN, int NT>
 __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const uint4* __restrict__ W,
                                            const float* __restrict__ bias, const bf16_t* R, bf16_t* Y, int dil, int blk,
-                                           int nblk, int ld, int n_rows, float in_slope, float out_slope,
+                                           int nblk, int ld, int n_rows, float in_slope, float out_slope, int cout,
                                            unsigned char* lds, long long* dbg = nullptr) {
     constexpr int KSTEPS = C / 16;
     constexpr int MT = (C + 31) / 32;             // m-tiles in the packed weights
@@ -53,8 +54,9 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     constexpr int VPR = C / 8;                    // 16-byte vectors per row
     constexpr int RPP = 256 / VPR;                // rows per staging pass
     constexpr int NVX = (XROWS + RPP - 1) / RPP;  // staging vectors per thread
-    constexpr int CW = C < 32 ? C : 32;           // channels of a wave's slice that exist
-    constexpr int PCS = CW / 8;                   // 16-byte pieces per row of the slice
+    constexpr int CW = C < 32 ? C : 32;           // channels of a full slice
+    constexpr int PCS = CW / 8;                   // 16-byte pieces per row of the slice (the last slice of C = 48 has
+                                                  // fewer that exist: `pv` below; C = 96 runs as 4 slices, the 4th idle)
     constexpr int RORS = 32 * 2 + 16;             // residual/output patch: bytes per row
     constexpr int NVR = WN * 32 * PCS / 64;       // patch vectors per lane
     constexpr int ROBYTES = WN * 32 * RORS;
@@ -62,6 +64,7 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
     const int ms = wid % MS, rg = wid / MS;
+    const bool live = ms < MT;                    // a wave whose slice does not exist only helps staging
     const int wrow = rg * WN * 32;
     unsigned char* xbuf0 = lds;
     unsigned char* xbuf1 = lds + XBYTES;
@@ -74,14 +77,15 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
 
     // the wave's weights: every (tap, k-step) fragment of its 32-channel slice
     u32x4 w[NT][KSTEPS];
+    const int msw = live ? ms : 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
-            w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + ms) * KSTEPS + ks) * 64 + lane]);
+            w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + msw) * KSTEPS + ks) * 64 + lane]);
     // bias sits in LDS (registers are for weights): [MS*32] floats behind the patches
     float* bl = reinterpret_cast<float*>(lds + 2 * XBYTES + 4 * ROBYTES);
-    if (tid < MS * 32) bl[tid] = (bias && tid < C) ? bias[tid] : 0.f;
+    if (tid < MS * 32) bl[tid] = (bias && tid < cout) ? bias[tid] : 0.f;
 
     // staging map: thread -> (first row, 16-byte column)
     const int cv = tid % VPR, r0 = tid / VPR;
@@ -116,6 +120,7 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
         row = idx / PCS;
         pc = idx % PCS;
     };
+    auto piece_ok = [&](int pc) { return ms * 32 + pc * 8 < C; };
 
     issue_x(blk);
     commit_x(blk, xbuf0);
@@ -127,18 +132,19 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
         const int tn = tile + nblk;
         const bool has_next = tn < ntiles;
         const int nb0 = tile * BN;
-        if (R) {
+        if (R && live) {
 #pragma unroll
             for (int p = 0; p < NVR; ++p) {
                 int row, pc;
                 patch_rc(p, row, pc);
                 const int n = min(nb0 + wrow + row, n_rows - 1);
-                rraw[p] = *reinterpret_cast<const u32x4*>(R + (size_t)n * ld + ms * 32 + pc * 8);
+                rraw[p] = *reinterpret_cast<const u32x4*>(R + (size_t)n * ld + ms * 32 + (piece_ok(pc) ? pc : 0) * 8);
             }
         }
         if (has_next) issue_x(tn);
 
         stamp();
+        if (live) {
         // ---- MFMA loop: LDS + registers only
         const unsigned char* xb = cur ? xbuf1 : xbuf0;
         const unsigned lb = (unsigned)(wrow + j) * XRS + hf * 16;
@@ -219,8 +225,9 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
             patch_rc(p, row, pc);
             const u32x4 o = *reinterpret_cast<const u32x4*>(ro + row * RORS + pc * 16);
             const int n = nb0 + wrow + row;
-            if (n < n_rows) *reinterpret_cast<u32x4*>(Y + (size_t)n * ld + ms * 32 + pc * 8) = o;
+            if (n < n_rows && piece_ok(pc)) *reinterpret_cast<u32x4*>(Y + (size_t)n * ld + ms * 32 + pc * 8) = o;
         }
+        }   // live
 
         stamp();
         if (has_next) commit_x(tn, cur ? xbuf0 : xbuf1);
@@ -244,9 +251,10 @@ __global__ __launch_bounds__(256, 1) void wconv_kernel(WConvArgs a) {
     bf16_t* Y = br == 0 ? a.Y0 : (br == 1 ? a.Y1 : a.Y2);
     const int k = br == 0 ? a.k0 : (br == 1 ? a.k1 : a.k2);
     const int dil = br == 0 ? a.d0 : (br == 1 ? a.d1 : a.d2);
-    if (k == 11) wconv_body<C, MS, BN, 11>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
-    else if (k == 7) wconv_body<C, MS, BN, 7>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
-    else if (k == 3) wconv_body<C, MS, BN, 3>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, lds, br == 0 ? a.dbg : nullptr);
+    const int cout = a.cout > 0 ? a.cout : C;
+    if (k == 11) wconv_body<C, MS, BN, 11>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 7) wconv_body<C, MS, BN, 7>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 3) wconv_body<C, MS, BN, 3>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
 }
 
 // LDS bytes of a wconv_kernel<C, MS, BN> launch (sized for 11 taps at dilation 5)

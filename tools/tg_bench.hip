@@ -236,6 +236,8 @@ int main(int argc, char** argv) {
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
+    if (C == 96) for (int nb : {256, 512, 768}) run_wconv<96, 4, 64>("wconv 96 bn64", w, N, reps, yrp, Y, ny, nb, 8.0);
+    if (C == 48) for (int nb : {512, 768, 1024}) for (double ov : {14.0, 30.0}) run_wconv<48, 2, 64>("wconv 48 bn64", w, N, reps, yrp, Y, ny, nb, ov);
     for (int nb : {512, 768, 1024, 1536, 2048}) {
         if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
         if (C == 32) run_wconv<32, 1, 128>("wconv 32 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
