@@ -198,7 +198,9 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
 
 // The weights-in-registers path for the Generator's resblock convs (wconv.h).  Returns 1 when the
 // launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
-inline bool wconv_channels(int C) { return C == 16 || C == 24 || C == 32 || C == 48 || C == 64 || C == 96 || C == 128; }
+inline bool wconv_channels(int C) {
+    return C == 16 || C == 24 || C == 32 || C == 48 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256;
+}
 template <typename AT>
 int run_wconv(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
     (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
@@ -219,13 +221,15 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
     std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
     // blocks are dealt in proportion to taps + a per-tile overhead (staging, epilogue) in tap units; both the
     // overhead and the block count per shape are measured (tools/tg_bench.hip)
-    const int nblk = C >= 64 ? 256 : (C >= 32 ? 512 : (C == 24 ? 512 : 768));
+    const int msp = C == 256 ? 4 : (C == 192 ? 3 : 1);   // blocks that share a row-tile walk (output slices split between them)
+    int nblk = C >= 64 ? 256 : (C >= 32 ? 512 : (C == 24 ? 512 : 768));
     const double ovh = C >= 96 ? 8.0 : (C == 64 ? 14.0 : (C == 48 ? 30.0 : 50.0));
     double tot = 0;
     for (int i = 0; i < 3; ++i) tot += brs[i].pc->k + ovh;
     int nb[3], used = 0;
-    for (int i = 0; i < 3; ++i) { nb[i] = std::max(1, (int)(nblk * (brs[order[i]].pc->k + ovh) / tot)); used += nb[i]; }
-    nb[0] += nblk - used;
+    for (int i = 0; i < 3; ++i) { nb[i] = std::max(msp, (int)(nblk * (brs[order[i]].pc->k + ovh) / tot) / msp * msp); used += nb[i]; }
+    nb[0] += (nblk - used) / msp * msp;
+    nblk = nb[0] + nb[1] + nb[2];
     WConvArgs a;
     memset(&a, 0, sizeof(a));
     const Branch &b0 = brs[order[0]], &b1 = brs[order[1]], &b2 = brs[order[2]];
@@ -245,6 +249,8 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
         HIPCHK(hipGetLastError());
         return GSV_OK;
     };
+    if (C == 256) return launch(wconv_kernel<256, 2, 64, 2, 4>, wconv_lds_bytes<256, 2, 64, 2, 4>());   // K split in the block, slices over 4 blocks
+    if (C == 192) return launch(wconv_kernel<192, 2, 64, 2, 3>, wconv_lds_bytes<192, 2, 64, 2, 3>());
     if (C == 128) return launch(wconv_kernel<128, 4, 64>, wconv_lds_bytes<128, 4, 64>());
     if (C == 96) return launch(wconv_kernel<96, 4, 64>, wconv_lds_bytes<96, 4, 64>());     // 3 slices + a staging-only wave
     if (C == 64) return launch(wconv_kernel<64, 2, 128>, wconv_lds_bytes<64, 2, 128>());

@@ -16,6 +16,9 @@
 //     16-byte lanes in 64-byte runs instead of the D fragment's scattered 8-byte pieces.
 // Up to 3 convolutions of one shape class (the three resblock branches, k = 3 / 7 / 11) run in one
 // launch; blocks are dealt to branches in proportion to their cost.
+// Wider convs (C = 192, 256: a 32-channel slice of 11 taps is 132 / 176 fragments, more than a wave's
+// registers) split the contraction between two waves (KSP = 2: each holds half of the slice's k-steps, the
+// partial tiles meet in LDS) and the output slices between MSP blocks that walk the same row tiles.
 #pragma once
 #include "tapgemm.h"
 
@@ -39,14 +42,15 @@ struct WConvArgs {
 
 // C: channels (cin == cout), MS: 32-channel output slices per block (waves along channels),
 // BN: rows per tile.  Waves: MS slices x (4/MS) row groups, each wave 32 channels x (WN*32) rows.
-template <int C, int MS, int BN, int NT>
+template <int C, int MS, int BN, int NT, int KSP = 1, int MSP = 1>
 __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const uint4* __restrict__ W,
                                            const float* __restrict__ bias, const bf16_t* R, bf16_t* Y, int dil, int blk,
                                            int nblk, int ld, int n_rows, float in_slope, float out_slope, int cout,
                                            unsigned char* lds, long long* dbg = nullptr) {
     constexpr int KSTEPS = C / 16;
     constexpr int MT = (C + 31) / 32;             // m-tiles in the packed weights
-    constexpr int RG = 4 / MS;                    // row groups
+    constexpr int RG = 4 / (MS * KSP);            // row groups
+    constexpr int KSW = KSTEPS / KSP;             // k-steps of a slice held by one wave
     constexpr int WN = BN / 32 / RG;              // 32-row tiles per wave
     constexpr int XRS = C * 2 + 16;               // LDS bytes per staged row (16-byte skew: conflict-free 32-row reads)
     constexpr int XROWS = BN + (NT - 1) * 5;      // rows staged at the largest dilation
@@ -63,8 +67,11 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
-    const int ms = wid % MS, rg = wid / MS;
-    const bool live = ms < MT;                    // a wave whose slice does not exist only helps staging
+    const int ms = wid % MS, kh = (wid / MS) % KSP, rg = wid / (MS * KSP);
+    const int mg = MSP > 1 ? blk % MSP : 0;       // this block's group of MS output slices
+    const int gs = mg * MS + ms;                  // the wave's slice of the conv
+    if (MSP > 1) { blk /= MSP; nblk /= MSP; }     // the MSP blocks of a walker visit the same tiles
+    const bool live = gs < MT;                    // a wave whose slice does not exist only helps staging
     const int wrow = rg * WN * 32;
     unsigned char* xbuf0 = lds;
     unsigned char* xbuf1 = lds + XBYTES;
@@ -76,16 +83,18 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     if (blk >= ntiles) return;
 
     // the wave's weights: every (tap, k-step) fragment of its 32-channel slice
-    u32x4 w[NT][KSTEPS];
-    const int msw = live ? ms : 0;
+    u32x4 w[NT][KSW];
+    const int msw = live ? gs : 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks)
-            w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + msw) * KSTEPS + ks) * 64 + lane]);
+        for (int ks = 0; ks < KSW; ++ks)
+            w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + msw) * KSTEPS + kh * KSW + ks) * 64 + lane]);
     // bias sits in LDS (registers are for weights): [MS*32] floats behind the patches
     float* bl = reinterpret_cast<float*>(lds + 2 * XBYTES + 4 * ROBYTES);
-    if (tid < MS * 32) bl[tid] = (bias && tid < cout) ? bias[tid] : 0.f;
+    if (tid < MS * 32) bl[tid] = (bias && mg * MS * 32 + tid < cout) ? bias[mg * MS * 32 + tid] : 0.f;
+    // KSP = 2: the second half's partial tiles, [MS*RG waves][WN][16][64] floats behind the bias
+    float* kred = reinterpret_cast<float*>(lds + 2 * XBYTES + 4 * ROBYTES + MS * 32 * sizeof(float)) + (size_t)(rg * MS + ms) * WN * 16 * 64;
 
     // staging map: thread -> (first row, 16-byte column)
     const int cv = tid % VPR, r0 = tid / VPR;
@@ -120,7 +129,8 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
         row = idx / PCS;
         pc = idx % PCS;
     };
-    auto piece_ok = [&](int pc) { return ms * 32 + pc * 8 < C; };
+    auto piece_ok = [&](int pc) { return gs * 32 + pc * 8 < C; };
+    const bool epi = live && kh == 0;             // the wave that owns the tile's epilogue
 
     issue_x(blk);
     commit_x(blk, xbuf0);
@@ -132,34 +142,34 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
         const int tn = tile + nblk;
         const bool has_next = tn < ntiles;
         const int nb0 = tile * BN;
-        if (R && live) {
+        if (R && epi) {
 #pragma unroll
             for (int p = 0; p < NVR; ++p) {
                 int row, pc;
                 patch_rc(p, row, pc);
                 const int n = min(nb0 + wrow + row, n_rows - 1);
-                rraw[p] = *reinterpret_cast<const u32x4*>(R + (size_t)n * ld + ms * 32 + (piece_ok(pc) ? pc : 0) * 8);
+                rraw[p] = *reinterpret_cast<const u32x4*>(R + (size_t)n * ld + gs * 32 + (piece_ok(pc) ? pc : 0) * 8);
             }
         }
         if (has_next) issue_x(tn);
 
         stamp();
+        f32x16 acc[WN];
         if (live) {
         // ---- MFMA loop: LDS + registers only
         const unsigned char* xb = cur ? xbuf1 : xbuf0;
-        const unsigned lb = (unsigned)(wrow + j) * XRS + hf * 16;
-        f32x16 acc[WN];
+        const unsigned lb = (unsigned)(wrow + j) * XRS + hf * 16 + kh * KSW * 32;
 #pragma unroll
         for (int k = 0; k < WN; ++k)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
         {
             // flat (tap, k-step) walk; B fragments are read DEPTH iterations ahead of their MFMAs
-            constexpr int NIT = NT * KSTEPS;
+            constexpr int NIT = NT * KSW;
             constexpr int DEPTH = 3;
             u32x4 bf[DEPTH + 1][WN];
             auto ldb = [&](int it, u32x4 (&dst)[WN]) {
-                const unsigned tb = lb + (unsigned)((it / KSTEPS) * dil) * XRS + (it % KSTEPS) * 32;
+                const unsigned tb = lb + (unsigned)((it / KSW) * dil) * XRS + (it % KSW) * 32;
 #pragma unroll
                 for (int k = 0; k < WN; ++k) dst[k] = *reinterpret_cast<const u32x4*>(xb + tb + k * 32 * XRS);
             };
@@ -170,13 +180,31 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
             for (int it = 0; it < NIT; ++it) {
                 if (it + DEPTH < NIT) ldb(it + DEPTH, bf[(it + DEPTH) % (DEPTH + 1)]);
 #pragma unroll
-                for (int k = 0; k < WN; ++k) Mma<bf16_t>::run(acc[k], w[it / KSTEPS][it % KSTEPS], bf[it % (DEPTH + 1)][k]);
+                for (int k = 0; k < WN; ++k) Mma<bf16_t>::run(acc[k], w[it / KSW][it % KSW], bf[it % (DEPTH + 1)][k]);
                 __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, WN, 0);
             }
         }
 
+        }   // live: MFMA
+        if constexpr (KSP > 1) {   // the second half hands its partial tiles over
+            if (live && kh == 1) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) kred[(k * 16 + q) * 64 + lane] = acc[k][q];
+            }
+            __syncthreads();
+            if (epi) {
+#pragma unroll
+                for (int k = 0; k < WN; ++k)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[k][q] += kred[(k * 16 + q) * 64 + lane];
+            }
+        }
+
         stamp();
+        if (epi) {
         // ---- epilogue, wave-private
         if (R) {
 #pragma unroll
@@ -225,9 +253,9 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
             patch_rc(p, row, pc);
             const u32x4 o = *reinterpret_cast<const u32x4*>(ro + row * RORS + pc * 16);
             const int n = nb0 + wrow + row;
-            if (n < n_rows && piece_ok(pc)) *reinterpret_cast<u32x4*>(Y + (size_t)n * ld + ms * 32 + pc * 8) = o;
+            if (n < n_rows && piece_ok(pc)) *reinterpret_cast<u32x4*>(Y + (size_t)n * ld + gs * 32 + pc * 8) = o;
         }
-        }   // live
+        }   // epi
 
         stamp();
         if (has_next) commit_x(tn, cur ? xbuf0 : xbuf1);
@@ -237,7 +265,7 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     }
 }
 
-template <int C, int MS, int BN>
+template <int C, int MS, int BN, int KSP = 1, int MSP = 1>
 __global__ __launch_bounds__(256, 1) void wconv_kernel(WConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = blockIdx.x;
@@ -252,15 +280,17 @@ __global__ __launch_bounds__(256, 1) void wconv_kernel(WConvArgs a) {
     const int k = br == 0 ? a.k0 : (br == 1 ? a.k1 : a.k2);
     const int dil = br == 0 ? a.d0 : (br == 1 ? a.d1 : a.d2);
     const int cout = a.cout > 0 ? a.cout : C;
-    if (k == 11) wconv_body<C, MS, BN, 11>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
-    else if (k == 7) wconv_body<C, MS, BN, 7>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
-    else if (k == 3) wconv_body<C, MS, BN, 3>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
+    if (k == 11) wconv_body<C, MS, BN, 11, KSP, MSP>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 7) wconv_body<C, MS, BN, 7, KSP, MSP>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
+    else if (k == 3) wconv_body<C, MS, BN, 3, KSP, MSP>(X, W, bias, R, Y, dil, blk, nblk, a.ld, a.n_rows, a.in_slope, a.out_slope, cout, lds, br == 0 ? a.dbg : nullptr);
 }
 
 // LDS bytes of a wconv_kernel<C, MS, BN> launch (sized for 11 taps at dilation 5)
-template <int C, int MS, int BN>
+template <int C, int MS, int BN, int KSP = 1, int MSP = 1>
 constexpr size_t wconv_lds_bytes() {
-    return (size_t)2 * (BN + 50) * (C * 2 + 16) + (size_t)MS * BN * (32 * 2 + 16) + MS * 32 * sizeof(float);
+    // staged rows (two buffers) + 4 wave patches of WN*32 rows + bias + (KSP = 2) the partial tiles
+    return (size_t)2 * (BN + 50) * (C * 2 + 16) + (size_t)4 * (BN / (4 / (MS * KSP))) * (32 * 2 + 16) + MS * 32 * sizeof(float) +
+           (KSP > 1 ? (size_t)(4 / KSP) * (BN / (4 / (MS * KSP)) / 32) * 16 * 64 * sizeof(float) : 0);
 }
 
 }  // namespace gsv

@@ -53,17 +53,18 @@ float run(const char* name, TapGemmArgs a, int C, int N, int span, int reps, bf1
     return us;
 }
 
-template <int C, int MS, int BN>
+template <int C, int MS, int BN, int KSP = 1, int MSP = 1>
 void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf16_t** Yd, size_t ny, int total_blocks, double ovh) {
-    auto kern = wconv_kernel<C, MS, BN>;
-    const size_t lds = wconv_lds_bytes<C, MS, BN>();
+    auto kern = wconv_kernel<C, MS, BN, KSP, MSP>;
+    const size_t lds = wconv_lds_bytes<C, MS, BN, KSP, MSP>();
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // deal blocks to branches in proportion to cost (taps + fixed overhead)
     const int ks[3] = {w.k0, w.k1, w.k2};
     double tot = 0; for (int b = 0; b < 3; ++b) tot += ks[b] + ovh;
     int nb[3]; int used = 0;
-    for (int b = 0; b < 3; ++b) { nb[b] = std::max(1, (int)(total_blocks * (ks[b] + ovh) / tot)); used += nb[b]; }
-    nb[0] += total_blocks - used;
+    for (int b = 0; b < 3; ++b) { nb[b] = std::max(MSP, (int)(total_blocks * (ks[b] + ovh) / tot) / MSP * MSP); used += nb[b]; }
+    nb[0] += (total_blocks - used) / MSP * MSP;
+    total_blocks = nb[0] + nb[1] + nb[2];
     w.nb0 = nb[0]; w.nb1 = nb[1]; w.nb2 = nb[2];
     dim3 grid(total_blocks);
     long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8)); w.dbg = dbg;
@@ -236,6 +237,8 @@ int main(int argc, char** argv) {
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
+    if (C == 256) for (int nb : {256, 512}) for (double ov : {8.0, 4.0}) run_wconv<256, 2, 64, 2, 4>("wconv 256 ks2 ms4", w, N, reps, yrp, Y, ny, nb, ov);
+    if (C == 192) for (int nb : {256, 512}) for (double ov : {8.0, 4.0}) run_wconv<192, 2, 64, 2, 3>("wconv 192 ks2 ms3", w, N, reps, yrp, Y, ny, nb, ov);
     if (C == 96) for (int nb : {256, 512, 768}) run_wconv<96, 4, 64>("wconv 96 bn64", w, N, reps, yrp, Y, ny, nb, 8.0);
     if (C == 48) for (int nb : {512, 768, 1024}) for (double ov : {14.0, 30.0}) run_wconv<48, 2, 64>("wconv 48 bn64", w, N, reps, yrp, Y, ny, nb, ov);
     for (int nb : {512, 768, 1024, 1536, 2048}) {
