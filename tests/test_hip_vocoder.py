@@ -130,11 +130,14 @@ def test_flow_bf16_fused_matches_reference_golden(golden_dir, dev, ver, T, tag):
     assert err.max() < 6e-2 and err.mean() < 6e-3, (err.max(), err.mean())
 
 
-def test_generator_bf16_wconv_odd_lengths_vs_oracle(dev):
+@pytest.mark.parametrize("ver", ["v2Pro", "v2ProPlus"])
+def test_generator_bf16_wconv_odd_lengths_vs_oracle(dev, ver):
     """bf16 Generator (wconv / tapgemm / conv_post kernels) at lengths that leave ragged last tiles in every
-    stage (T = 1, 7, 131 -> 10 .. 83840 rows), broadcast and per-frame ge, against the fp32 oracle."""
+    stage (T = 1, 7, 131 -> 10 .. 83840 rows), broadcast and per-frame ge, against the fp32 oracle.  v2Pro walks
+    the 256 (K split in the block, slices over 4 blocks) / 128 / 64 / 32 / 16-channel wconv shapes, v2ProPlus the
+    192 (3 blocks) / 96 (3 slices + a staging wave) / 48 (half-empty second slice) / 24-in-32 ones."""
     from oracle import oracle as orc
-    v, hps, w = _voc("v2Pro", 13, torch.bfloat16, dev)
+    v, hps, w = _voc(ver, 13, torch.bfloat16, dev)
     vo = orc.VocoderOracle(hps, w)
     for T, per_frame in [(1, False), (7, True), (131, False)]:
         z = synth.hashed_uniform("bfodd.z%d" % T, (1, 192, T), 13) * np.float32(1.2)
