@@ -17,6 +17,9 @@ ap.add_argument("--requests", type=int, default=256)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--max-kv", type=int, default=512)
 ap.add_argument("--eos-gain", type=float, default=4.0)
+ap.add_argument("--vocoder", default="", help="v2 | v2Pro | v2ProPlus: also run flow + Generator over every utterance, "
+                "time-concatenated in batches of --sovits-batch like TTS.infer_batched (TTS.py:728-764)")
+ap.add_argument("--sovits-batch", type=int, default=10)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -36,6 +39,31 @@ pred, orig = m.infer_batched(xs, ys, bs, top_k=1)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ntok = int(sum(len(p) for p in pred))
-print(json.dumps({"config": "continuous batching bs=%d, %d mixed-length requests, %s" % (a.batch, a.requests, a.dtype),
-                  "tokens": ntok, "seconds": dt, "tokens_per_s": ntok / dt, "requests_per_s": a.requests / dt,
-                  "mean_tokens_per_request": ntok / a.requests}))
+out = {"config": "continuous batching bs=%d, %d mixed-length requests, %s" % (a.batch, a.requests, a.dtype),
+       "tokens": ntok, "seconds": dt, "tokens_per_s": ntok / dt, "requests_per_s": a.requests / dt,
+       "mean_tokens_per_request": ntok / a.requests}
+if a.vocoder:
+    # flow + Generator on z ~ N(0,1) of the generated lengths (enc_p's output statistics are not what is timed here),
+    # per-frame speaker embedding of the time-concatenated batch, as infer_batched feeds it
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps(a.vocoder)
+    sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
+    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, dtype, dev)
+    gin = hps["model"]["gin_channels"]
+    ge1 = torch.from_numpy(synth.synth_ge(0, gin)).to(dev)
+    frames = [2 * len(p) for p in pred]
+    order = sorted(range(len(frames)), key=lambda i: frames[i])
+    batches = [order[i:i + a.sovits_batch] for i in range(0, len(order), a.sovits_batch)]
+    def run():
+        tot = 0
+        for b in batches:
+            T = sum(frames[i] for i in b)
+            z = torch.randn(1, 192, T, device=dev)
+            voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge1.expand(-1, -1, T).contiguous())
+            tot += T
+        return tot
+    run(); torch.cuda.synchronize()
+    t1 = time.perf_counter(); tot = run(); torch.cuda.synchronize(); dv = time.perf_counter() - t1
+    out.update({"vocoder": a.vocoder, "vocoder_seconds": dv, "audio_s": tot / 50.0, "vocoder_audio_s_per_s": tot / 50.0 / dv,
+                "end_to_end_tokens_per_s": ntok / (dt + dv), "end_to_end_audio_s_per_s": tot / 50.0 / (dt + dv)})
+print(json.dumps(out))
