@@ -457,7 +457,9 @@ struct BatchAttnArgs {
     float* out;              // [B][512]
 };
 
-// One thread per key (<= 4 keys per thread at T <= 1024), whole 64-byte rows per load.  Two other shapes were
+// One thread per key (<= 4 keys per thread at T <= 1024), whole 64-byte rows per load.  Fusing the head's share of
+// the out-proj into this kernel (per-head [512][32] panel, 16 partial rows summed by the LayerNorm kernel, one launch
+// less per layer) was measured and rejected: step 0.98 -> 1.00 ms at 64 slots, 1.60 -> 1.84 ms at 256.  Two other shapes were
 // measured and rejected: 8 lanes per key with a 32-key pass loop (one exposed memory latency per pass: step
 // 0.93 -> 1.04 ms at B = 32) and the same with all passes preloaded (256 registers of K/V: 1.37 ms).
 template <typename WT>
