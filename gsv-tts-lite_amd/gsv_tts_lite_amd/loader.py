@@ -161,3 +161,37 @@ def get_sovits_weights(sovits_path, tts_config) -> Sovits:
             raise ValueError("The SoVITS checkpoint is not a v2 / v2Pro / v2ProPlus model")
     hps["model"]["version"] = version
     return _build_sovits(hps, blob["weight"], tts_config)
+
+
+def convert_to_safetensors(checkpoint_path, output_dir=None) -> str:
+    """TTS.to_safetensors (gsv_tts/TTS.py:1482-1523): a `.pth` SoVITS checkpoint becomes {hps.json, model.safetensors},
+    a `.ckpt` GPT checkpoint {config.json, model.safetensors} -- the directory form both loaders read.  The tensors
+    are what the reference's module holds after loading: GPT keys remapped (Loader.py:130-154), the Generator's
+    weight norm folded (`dec.remove_weight_norm()`, Loader.py:95), the flow's weight_g / weight_v kept."""
+    from safetensors.torch import save_file
+    checkpoint_path = str(checkpoint_path)
+    root, ext = os.path.splitext(checkpoint_path)
+    if output_dir is None:
+        output_dir = root
+    os.makedirs(output_dir, exist_ok=True)
+    as_tensor = lambda v: (torch.from_numpy(v) if not torch.is_tensor(v) else v).detach().cpu().contiguous()
+    if ext == ".pth":
+        blob, version = read_sovits_file(checkpoint_path)
+        hps = json.loads(json.dumps(blob["config"], default=lambda o: dict(o)))
+        hps["model"]["semantic_frame_rate"] = "25hz"
+        if version is not None:
+            hps["model"]["version"] = version
+        weights = {k: as_tensor(v) for k, v in fold_dec_weight_norm(blob["weight"]).items() if torch.is_tensor(v) or hasattr(v, "shape")}
+        save_file(weights, os.path.join(output_dir, "model.safetensors"))
+        with open(os.path.join(output_dir, "hps.json"), "w") as f:
+            json.dump(hps, f, indent=4, ensure_ascii=False)
+    elif ext == ".ckpt":
+        blob = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        config = blob["config"]
+        weights = {k: as_tensor(v) for k, v in remap_gpt_keys(blob["weight"], config["model"]["n_layer"]).items()}
+        save_file(weights, os.path.join(output_dir, "model.safetensors"))
+        with open(os.path.join(output_dir, "config.json"), "w") as f:
+            json.dump(config, f, indent=4, ensure_ascii=False)
+    else:
+        raise ValueError("to_safetensors converts .pth (SoVITS) and .ckpt (GPT) checkpoints, got %r" % ext)
+    return output_dir

@@ -33,7 +33,7 @@ import numpy as np
 import torch
 
 from . import subtitles as sub
-from .loader import Gpt, Sovits, get_gpt_weights, get_sovits_weights
+from .loader import Gpt, Sovits, convert_to_safetensors, get_gpt_weights, get_sovits_weights
 
 log = logging.getLogger("gsv_tts_lite_amd")
 
@@ -160,6 +160,14 @@ class TTS:
                     log.warning("SoVITS model %s not found.", p)
                 for a in self.spk_audio_cache.values():
                     a["ge"].pop(p, None)
+        finally:
+            self._empty_cache()
+
+    def to_safetensors(self, checkpoint_path: str, output_dir: str = None):
+        """TTS.py:1482-1523: convert a .pth / .ckpt checkpoint to the safetensors directory form."""
+        try:
+            out = convert_to_safetensors(checkpoint_path, output_dir)
+            log.info("Successfully converted and saved to: %s", out)
         finally:
             self._empty_cache()
 

@@ -89,8 +89,42 @@ def test_tts_loads_ckpt_pth_and_safetensors_dirs_like_synthetic(tmp_path):
         tts.cache_prompt_audio("prompt.wav", "prompt text.", prompt=torch.from_numpy(y)[None], phones1=x.tolist())
         return tts.infer("spk.wav", "prompt.wav", "prompt text.", "Loading formats.", top_k=1, noise_scale=0.0).audio_data
 
+    # TTS.to_safetensors (TTS.py:1482-1523): the converted directories load like the originals
+    conv = TTS(gpt_cache=[(1, 128)], sovits_cache=[50], device=dev, dtype="float32")
+    conv.to_safetensors(str(tmp_path / "s1.ckpt"))
+    conv.to_safetensors(str(p), str(tmp_path / "s2_conv"))
+    assert (tmp_path / "s1" / "config.json").exists() and (tmp_path / "s2_conv" / "hps.json").exists()
+    with pytest.raises(ValueError):
+        conv.to_safetensors(str(tmp_path / "model.bin"))
+
     ref = run("synthetic://gpt?seed=9&n_layer=3&eos_gain=1.0", "synthetic://sovits?version=v2Pro&seed=9")
-    for gpt, sov in ((str(tmp_path / "s1.ckpt"), str(p)), (str(gdir), str(sdir))):
+    for gpt, sov in ((str(tmp_path / "s1.ckpt"), str(p)), (str(gdir), str(sdir)), (str(tmp_path / "s1"), str(tmp_path / "s2_conv"))):
         out = run(gpt, sov)
         assert out.shape == ref.shape
         np.testing.assert_allclose(out, ref, atol=1e-5)
+
+
+def test_convert_to_safetensors_on_cpu(tmp_path):
+    """the converter itself needs no device: keys remapped / weight norm folded, config files as the reference writes them"""
+    from safetensors.torch import load_file
+    cfg = synth.gpt_config(n_layer=2)
+    gw = synth.gpt_weights(cfg, seed=4)
+    torch.save(_upstream_gpt_blob(cfg, gw), str(tmp_path / "g.ckpt"))
+    out = loader.convert_to_safetensors(str(tmp_path / "g.ckpt"))
+    assert out == str(tmp_path / "g") and json.load(open(tmp_path / "g" / "config.json")) == cfg
+    back = load_file(str(tmp_path / "g" / "model.safetensors"))
+    assert set(back) == set(gw) and all(np.array_equal(back[k].numpy(), gw[k]) for k in gw)
+    hps = synth.sovits_hps("v2")
+    sw = {k: torch.from_numpy(v) for k, v in synth.sovits_weights(hps, seed=4, hot_path_only=True).items()}
+    v = sw.pop("dec.conv_pre.weight")
+    sw["dec.conv_pre.weight_v"] = v
+    sw["dec.conv_pre.weight_g"] = v.pow(2).sum(dim=(1, 2), keepdim=True).sqrt() * 0.5
+    p = tmp_path / "s.pth"
+    torch.save({"config": hps, "weight": sw}, str(p))
+    p.write_bytes(b"01" + p.read_bytes()[2:])          # "01": the v2 marker that replaces b"PK" (Loader.py:17-21)
+    loader.convert_to_safetensors(str(p), str(tmp_path / "sdir"))
+    h2 = json.load(open(tmp_path / "sdir" / "hps.json"))
+    assert h2["model"]["version"] == "v2" and h2["model"]["semantic_frame_rate"] == "25hz"
+    st = load_file(str(tmp_path / "sdir" / "model.safetensors"))
+    assert "dec.conv_pre.weight" in st and "dec.conv_pre.weight_g" not in st and "flow.flows.0.enc.in_layers.0.weight_g" in st
+    np.testing.assert_allclose(st["dec.conv_pre.weight"].numpy(), (v * 0.5).numpy(), rtol=1e-6)
