@@ -5,6 +5,8 @@ Drop-in surface kept from the reference:
         use_jieba_fast, always_load_cnhubert, always_load_sv)                 TTS.py:39-52
     infer(...) -> AudioClip                                                    TTS.py:150-286
     infer_batched(...) -> tuple[AudioClip]                                     TTS.py:507-868
+    infer_stream(...) -> generator of AudioClip, infer_vc(...), *_async wrappers  TTS.py:289-504, 871-1262
+    to_safetensors, cache_* / del_* / get_*_list                                TTS.py:1346-1523
     load_gpt_model / load_sovits_model / unload_* / get_*_list                 TTS.py:1264-1345
     AudioClip(audio_data, samplerate, audio_len_s, subtitles, orig_text)       Player.py:68-99
 
@@ -226,6 +228,24 @@ class TTS:
             "prompt": prompt.to(self.tts_config.device), "phones1": list(phones1),
             "bert1": bert1.to(self.tts_config.device), "text": prompt_audio_texts}
 
+    def del_spk_audio(self, *spk_audio_list):
+        """TTS.py:1436-1448"""
+        for p in spk_audio_list:
+            if self.spk_audio_cache.pop(p, None) is None:
+                log.warning("Speaker audio %s not found in cache.", p)
+
+    def del_prompt_audio(self, *prompt_audio_list):
+        """TTS.py:1450-1462"""
+        for p in prompt_audio_list:
+            if self.prompt_audio_cache.pop(p, None) is None:
+                log.warning("Prompt audio %s not found in cache.", p)
+
+    def get_spk_audio_list(self):
+        return list(self.spk_audio_cache.keys())
+
+    def get_prompt_audio_list(self):
+        return list(self.prompt_audio_cache.keys())
+
     def _pick(self, table, name, default):
         if name is None:
             name = next(iter(table)) if table else default
@@ -337,6 +357,75 @@ class TTS:
                 return AudioClip(self.audio_queue, audio, self.samplerate, len(audio) / self.samplerate, subtitles, text)
             finally:
                 self._empty_cache()
+
+    @torch.inference_mode()
+    def infer_vc(self, spk_audio_path, prompt_audio_path, prompt_audio_text, noise_scale=0.5, speed=1.0, sovits_model=None):
+        """TTS.py:871-964, voice conversion: the prompt's own semantic tokens and phonemes go straight to the SoVITS
+        decoder with the target speaker's `ge`; word timings always come back (the reference aligns unconditionally here)."""
+        with self._infer_lock:
+            try:
+                if not self._check_pause(prompt_audio_text):
+                    prompt_audio_text += "."
+                sovits_model = self._pick(self.sovits_models, sovits_model, self.default_sovits_path)
+                if sovits_model not in self.sovits_models:
+                    self.load_sovits_model(sovits_model)
+                vq = self.sovits_models[sovits_model].vq_model
+                dev = self.tts_config.device
+                ge = self._ge_for(spk_audio_path, sovits_model)
+                if prompt_audio_path not in self.prompt_audio_cache:
+                    self.cache_prompt_audio(prompt_audio_path, prompt_audio_text)
+                prompt = self.prompt_audio_cache[prompt_audio_path]["prompt"]
+                phones, word2ph, _, norm_text = self._phones_and_bert(prompt_audio_text)
+                audio, attn = vq.decode(prompt.unsqueeze(0), torch.tensor(phones, dtype=torch.int64, device=dev).unsqueeze(0), ge,
+                                        noise_scale=noise_scale, speed=speed)
+                audio = audio[0, 0, :].float().cpu().numpy()
+                subtitles = sub.get_subtitles(word2ph, sub.viterbi_monotonic(attn), speed, sovits_hz=self.sovits_hz)
+                self._close_subtitles(subtitles, word2ph, 0.2)
+                subtitles = sub.sub2text_index(subtitles, norm_text, prompt_audio_text)
+                peak = np.abs(audio).max() if audio.size else 0.0
+                if peak > 1:
+                    audio = audio / peak
+                audio = np.concatenate([audio, np.zeros(int(0.2 * self.samplerate), dtype=audio.dtype)])
+                return AudioClip(self.audio_queue, audio, self.samplerate, len(audio) / self.samplerate, subtitles, prompt_audio_text)
+            finally:
+                self._empty_cache()
+
+    # ------------------------------------------------------------------ asyncio front (TTS.py:966-1262)
+    # The reference's wrappers take the engine lock around the synchronous call inside an executor thread; here the
+    # synchronous methods hold that (non-reentrant) lock themselves, so the wrappers only move the call off the loop.
+    async def infer_async(self, *args, executor=None, **kwargs):
+        import asyncio
+        import functools
+        return await asyncio.get_running_loop().run_in_executor(executor, functools.partial(self.infer, *args, **kwargs))
+
+    async def infer_batched_async(self, *args, executor=None, **kwargs):
+        import asyncio
+        import functools
+        return await asyncio.get_running_loop().run_in_executor(executor, functools.partial(self.infer_batched, *args, **kwargs))
+
+    async def infer_stream_async(self, *args, executor=None, **kwargs):
+        """async generator of AudioClip chunks: infer_stream runs in an executor thread and hands chunks over a queue"""
+        import asyncio
+        loop = asyncio.get_running_loop()
+        queue = asyncio.Queue()
+        failure = []
+
+        def pump():
+            try:
+                for chunk in self.infer_stream(*args, **kwargs):
+                    loop.call_soon_threadsafe(queue.put_nowait, chunk)
+            except BaseException as exc:        # surfaced on the consumer side instead of dying in the worker
+                failure.append(exc)
+            finally:
+                loop.call_soon_threadsafe(queue.put_nowait, None)
+        loop.run_in_executor(executor, pump)
+        while True:
+            chunk = await queue.get()
+            if chunk is None:
+                break
+            yield chunk
+        if failure:
+            raise failure[0]
 
     def _sola_algorithm(self, f1_overlap, f2, overlap_len, search_len: int = 320):
         """TTS.py:1612-1627: align the new chunk to the previous chunk's tail by normalised cross-correlation

@@ -226,3 +226,30 @@ def test_tts_batched_subtitles(dev, monkeypatch):
         for s in c.subtitles:   # spans of later segments are shifted by len(segment) as in TTS.py:852, which does
             if len(s["text"]) > 1:   # not count the blank cut_text() dropped between segments
                 assert s["text"] in full[max(0, s["orig_idx_start"] - 2):s["orig_idx_end"] + 2]
+
+
+def test_tts_vc_async_and_cache_management(dev):
+    """infer_vc (TTS.py:871-964), the asyncio wrappers (TTS.py:966-1262) and the cache bookkeeping (TTS.py:1436-1480)"""
+    import asyncio
+    tts, AudioClip = _make_tts(dev, "bfloat16")
+    tts.set_text_frontend(_word_frontend)
+    vc = tts.infer_vc("spk.wav", "prompt.wav", "prompt text.", noise_scale=0.0)
+    assert isinstance(vc, AudioClip) and vc.orig_text == "prompt text." and np.isfinite(vc.audio_data).all()
+    assert len(vc.audio_data) == 30 * 2 * 640 + 6400            # the cached prompt's 30 tokens -> 60 frames, + 0.2 s
+    _check_subtitles(vc.subtitles, "prompt text.", vc.audio_len_s)
+    text = "Hello there, async test."
+    want = tts.infer("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0)
+
+    async def go():
+        one = await tts.infer_async("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0)
+        many = await tts.infer_batched_async("spk.wav", "prompt.wav", "prompt text.", [text, "Second one."], top_k=1, noise_scale=0.0)
+        chunks = [c async for c in tts.infer_stream_async("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0,
+                                                          stream_chunk=8, overlap_len=2, debug=False)]
+        return one, many, chunks
+    one, many, chunks = asyncio.run(go())
+    np.testing.assert_allclose(one.audio_data, want.audio_data, atol=1e-5)
+    assert len(many) == 2 and len(chunks) >= 2 and all(isinstance(c, AudioClip) for c in chunks)
+    assert tts.get_spk_audio_list() == ["spk.wav"] and tts.get_prompt_audio_list() == ["prompt.wav"]
+    tts.del_spk_audio("spk.wav", "missing.wav")
+    tts.del_prompt_audio("prompt.wav")
+    assert tts.get_spk_audio_list() == [] and tts.get_prompt_audio_list() == []
