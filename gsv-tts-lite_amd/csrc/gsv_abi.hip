@@ -475,11 +475,11 @@ int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_
 
 template <typename WT>
 int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirect, int slot0, int nrows, int vlimit,
-               int bump, hipStream_t st) {
+               int bump, hipStream_t st, const int32_t* slots = nullptr) {
     const T2SLayer& L = h->layers.back();
     LogitsArgs<WT> a;
     a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
-    a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0;
+    a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0; a.slots = slots;
     a.step = s.step; a.ctl = s.ctl; a.fctl = s.fctl; a.seen = s.seen; a.logits = s.logits; a.hidden = s.hidden;
     a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;
     if (mode == 0) hipLaunchKernelGGL((t2s_logits_kernel<WT, 0>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
@@ -577,7 +577,7 @@ int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, bool mega, hipStream_t st) {
 
 template <typename WT>
 int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
-                     const int64_t* y_lens, void* ws, size_t ws_bytes, hipStream_t st) {
+                     const int64_t* y_lens, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* slots = nullptr) {
     const gsv_t2s_state& s = bd.st;
     const int M = nrows * l_max, T = s.max_kv;
     const size_t need = gsv_t2s_prefill_workspace(h, nrows, l_max);
@@ -620,7 +620,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             PrefillAttnMfmaArgs pm;
             pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
             pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
-            pm.T = T; pm.slot0 = slot0; pm.l_max = l_max; pm.out = attn;
+            pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
             gemm(rowgemm_kernel<float, float>, attn, kD, L.g_out, nullptr, 0, ybuf, kD, 1, 0);
             hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)ybuf, 1, (size_t)0, (const float*)L.bo,
@@ -639,12 +639,12 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             PrefillAttnArgs<WT> pa;
             pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
             pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-            pa.T = T; pa.slot0 = slot0; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
+            pa.T = T; pa.slot0 = slot0; pa.slots = slots; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
             if constexpr (sizeof(WT) == 2) {   // bf16 cache: flash attention on the matrix cores
                 PrefillAttnMfmaArgs pm;
                 pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
                 pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
-                pm.T = T; pm.slot0 = slot0; pm.l_max = l_max; pm.out = attn;
+                pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
                 hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
             } else {
                 hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
@@ -665,11 +665,11 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     }
     PrefillFinishArgs fa;
     fa.hidden = xy; fa.x_lens = x_lens; fa.y_lens = y_lens; fa.hlast = hlast; fa.kv_len = s.kv_len; fa.x_len = s.x_len;
-    fa.step = s.step; fa.eos_at = s.eos_at; fa.slot0 = slot0; fa.l_max = l_max;
+    fa.step = s.step; fa.eos_at = s.eos_at; fa.slot0 = slot0; fa.slots = slots; fa.l_max = l_max;
     hipLaunchKernelGGL(t2s_prefill_finish_kernel, dim3(nrows), dim3(128), 0, st, fa);
     HIPCHK(hipGetLastError());
     // first sample: logits[:, :-1] (t2s_model.py:417,613) -> EOS column dropped
-    return t2s_logits<WT>(h, s, 0, hlast, slot0, nrows, h->cfg.vocab - 1, 0, st);
+    return t2s_logits<WT>(h, s, 0, hlast, slot0, nrows, h->cfg.vocab - 1, 0, st, slots);
 }
 
 }  // namespace
@@ -844,6 +844,18 @@ int gsv_t2s_prefill(gsv_t2s* h, int batch, int slot0, int nrows, int l_max, floa
     return h->cfg.dtype == GSV_BF16
                ? t2s_prefill_impl<bf16_t>(h, *b, slot0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream))
                : t2s_prefill_impl<float>(h, *b, slot0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream));
+}
+
+int gsv_t2s_prefill_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                          const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    if (!slots || nrows < 1 || nrows > batch) return fail(GSV_ERR_ARG, "prefill_slots: need 1..batch rows and their slot list");
+    if (l_max < 1 || l_max > b->st.max_kv) return fail(GSV_ERR_ARG, "prompt of %d positions does not fit the KV cache (%d)", l_max, b->st.max_kv);
+    return h->cfg.dtype == GSV_BF16
+               ? t2s_prefill_impl<bf16_t>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots)
+               : t2s_prefill_impl<float>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots);
 }
 
 int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream) {

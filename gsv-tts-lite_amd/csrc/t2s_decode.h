@@ -626,6 +626,7 @@ struct LogitsArgs {
     int V, eos;
     int vlimit;          // logits with v >= vlimit are -inf (first sample drops the EOS column)
     int slot0;           // first state slot of row 0
+    const int32_t* slots;// or: state slot of every row (refills of scattered slots); null = slot0 + row
     const int32_t* step;
     const int32_t* ctl;  // {use_override, suppress_steps, rep_enabled, -}
     const float* fctl;   // {rep_penalty}
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     float* lg = red + 2 * kNW;  // up to 128 rows per slice
     float* stage = lg + 128;
     const int p = blockIdx.x, r_ = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int b = a.slot0 + r_;  // state slot; row r_ of zpart/x1/hdirect
+    const int b = a.slots ? a.slots[r_] : a.slot0 + r_;  // state slot; row r_ of zpart/x1/hdirect
     constexpr int CPR = Geo<WT>::CPR;
     const int rpb = (a.V + kNP - 1) / kNP;      // rows per slice (<= 128)
     const int rww = (rpb + kNW - 1) / kNW;      // rows per wave (<= 8)

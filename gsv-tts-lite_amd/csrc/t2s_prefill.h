@@ -82,6 +82,7 @@ struct PrefillAttnArgs {
     WT* kc;              // this layer: [B][16][T][32]
     WT* vc;
     int T, slot0, l_max, qsplit;
+    const int32_t* slots;  // state slot of every row, or null = slot0 + row
     float* out;          // [nrows][l_max][512]
 };
 
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_kernel(PrefillAttnArgs<W
     float* Sc = Vs + (size_t)a.l_max * 32;  // [4][l_max]
     float* Qs = Sc + 4 * (size_t)a.l_max;   // [4][32]
     const float* base = a.qkv + (size_t)r * a.l_max * 1536;
-    WT* Kp = a.kc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
-    WT* Vp = a.vc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
+    WT* Kp = a.kc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
+    WT* Vp = a.vc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
     for (int e = tid; e < L * 32; e += 256) {
         const int t = e >> 5, d = e & 31;
         const WT kq = from_f32<WT>(base[(size_t)t * 1536 + 512 + h * 32 + d]);
@@ -162,6 +163,7 @@ struct PrefillAttnMfmaArgs {
     bf16_t* kc;          // this layer: [B][16][T][32]
     bf16_t* vc;
     int T, slot0, l_max;
+    const int32_t* slots;  // state slot of every row, or null = slot0 + row
     float* out;          // [nrows][l_max][512]
 };
 
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnM
     unsigned char* Qs = Ks + (size_t)nkt * 32 * KRS;         // [128][KRS]
     unsigned char* Vt = Qs + 128 * KRS;                      // [32 d][vrs]
     const float* base = a.qkv + (size_t)r * a.l_max * 1536;
-    bf16_t* Kp = a.kc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
-    bf16_t* Vp = a.vc + (((size_t)(a.slot0 + r) * kH + h) * a.T) * kDh;
+    bf16_t* Kp = a.kc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
+    bf16_t* Vp = a.vc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
     // ---- stage K (rows), V (transposed, permuted), Q (rows): one float4 of 4 d per item
     for (int e = tid; e < nkt * 32 * 8; e += 256) {
         const int t = e >> 3, d4 = (e & 7) * 4;
@@ -542,6 +544,7 @@ struct PrefillFinishArgs {
     int32_t* step;
     int32_t* eos_at;
     int slot0, l_max;
+    const int32_t* slots;  // state slot of every row, or null = slot0 + row
 };
 
 __global__ __launch_bounds__(128) void t2s_prefill_finish_kernel(PrefillFinishArgs a) {
@@ -551,10 +554,11 @@ __global__ __launch_bounds__(128) void t2s_prefill_finish_kernel(PrefillFinishAr
     *reinterpret_cast<f32x4*>(a.hlast + (size_t)r * kD + c) =
         *reinterpret_cast<const f32x4*>(a.hidden + ((size_t)r * a.l_max + last) * kD + c);
     if (threadIdx.x == 0) {
-        a.kv_len[a.slot0 + r] = L;
-        a.x_len[a.slot0 + r] = lx;
-        a.step[a.slot0 + r] = 0;
-        a.eos_at[a.slot0 + r] = -1;
+        const int slot = a.slots ? a.slots[r] : a.slot0 + r;
+        a.kv_len[slot] = L;
+        a.x_len[slot] = lx;
+        a.step[slot] = 0;
+        a.eos_at[slot] = -1;
     }
 }
 

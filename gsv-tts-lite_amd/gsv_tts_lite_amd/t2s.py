@@ -223,6 +223,15 @@ class Text2SemanticDecoder:
         N.check(L.gsv_t2s_prefill(self._h, batch, slot0, n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
                                   ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
 
+    def prefill_slots(self, batch, slots, xy, xl, yl):
+        """the same for rows that go to scattered slots: one packed prefill refills every slot that finished in a window"""
+        n, lmax, _ = xy.shape
+        L = N.lib()
+        sl = torch.tensor(list(slots), dtype=torch.int32, device=self.device)
+        ws = self._workspace(L.gsv_t2s_prefill_workspace(self._h, n, lmax))
+        N.check(L.gsv_t2s_prefill_slots(self._h, batch, sl.data_ptr(), n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
+
     def decode_hidden(self, batch, x):
         """T2STransformer.decode_next_token for an explicit x [B, D] (t2s_model.py:129-143)."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
@@ -468,8 +477,7 @@ class Text2SemanticDecoder:
             self._flush(batch_size)
             kv = rt["kv_len"].clone()
             samples = rt["pre_tokens"][rows, kv.clamp(max=rt["T"])]
-            kv_h = kv.tolist()
-            smp = samples.tolist()
+            kv_h, smp = torch.stack([kv, samples.to(kv.dtype)]).tolist()   # one device->host copy per window
             cap = caps[min(bucket_i, len(caps) - 1)]
             reached = [k + check_interval >= cap for k in kv_h]
             eos = [t == self.EOS for t in smp]
@@ -483,11 +491,14 @@ class Text2SemanticDecoder:
             fin = [(not ignore[b]) and (eos[b] or reached[b]) for b in range(batch_size)]
             if not any(fin):
                 continue
-            for i in [b for b in range(batch_size) if fin[b]]:
-                seg = rt["pre_tokens"][i, kv_h[i] - steps[i] + 1: kv_h[i]]
-                e = (seg == self.EOS).nonzero(as_tuple=True)[0]
-                if e.numel() > 0:
-                    seg = seg[: int(e[0].item())]
+            refill = []   # (slot, request) pairs of this window: the reference prefills them one by one in this order
+            fin_idx = [b for b in range(batch_size) if fin[b]]
+            fin_rows = rt["pre_tokens"][fin_idx].cpu().numpy()      # one copy for every sequence that finished
+            for j, i in enumerate(fin_idx):
+                a0, b0 = kv_h[i] - steps[i] + 1, kv_h[i]
+                hit = np.nonzero(fin_rows[j, a0:b0] == self.EOS)[0]   # cut at the first EOS (t2s_model.py:675-678)
+                n_keep = int(hit[0]) if hit.size else max(0, b0 - a0)
+                seg = rt["pre_tokens"][i, a0: a0 + n_keep]
                 pred.append(seg.clone())
                 orig.append(slot_orig[i])
                 steps[i] = 0
@@ -505,13 +516,20 @@ class Text2SemanticDecoder:
                         stop = True
                         break
                 else:
-                    xy1, xl1, yl1, xh, yh = self.embed_prompt([x[cur]], [y[cur]], [bert_feature[cur]])
-                    if xy1.shape[1] > caps[-1]:
+                    n_new = int(x[cur].shape[0]) + int(y[cur].shape[0])
+                    if n_new > caps[-1]:
                         raise ValueError("prompt longer than the largest KV bucket")
-                    self.prefill(batch_size, i, xy1, xl1, yl1)
-                    if not greedy:  # the refilled slot needs its own first sample (t2s_model.py:713-714)
-                        rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]
-                    kv_h[i] = int(xh[0] + yh[0])
+                    refill.append((i, cur))
+                    kv_h[i] = n_new            # what the slot holds once refilled: the next slots' bucket choice sees it
                     slot_orig[i] = cur
                     cur += 1
+            if refill and not stop:
+                # rows are independent through the prefill, so the window's refills run as ONE packed prefill into their
+                # scattered slots (gsv_t2s_prefill_slots) instead of one 170-launch chain per sequence
+                req = [c for _, c in refill]
+                xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in req], [y[c] for c in req], [bert_feature[c] for c in req])
+                self.prefill_slots(batch_size, [i for i, _ in refill], xy1, xl1, yl1)
+                if not greedy:  # every refilled slot needs its own first sample, drawn in slot order (t2s_model.py:713-714)
+                    for i, _ in refill:
+                        rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]
         return pred, torch.tensor(orig, device=dev)

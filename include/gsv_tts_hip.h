@@ -114,6 +114,11 @@ int gsv_t2s_embed_prompt(gsv_t2s* h, int nrows, int lx_max, int ly_max, int l_ma
 size_t gsv_t2s_prefill_workspace(gsv_t2s* h, int nrows, int l_max);
 int gsv_t2s_prefill(gsv_t2s* h, int batch, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
                     const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for rows that go to scattered slots (the continuous-batching refill of every sequence that finished in a
+ * check window, t2s_model.py:696-722, as ONE packed prefill): slots int32 [nrows] on the device, distinct, each
+ * < batch; row r fills slot slots[r]. */
+int gsv_t2s_prefill_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                          const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream);
 
 /* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
  * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
