@@ -453,3 +453,31 @@ def test_device_sampler_top_p(dev, top_k, top_p, temp):
     big = exp >= 5                                       # chi-square needs expected counts that are not tiny
     chi2 = (((counts[kept][big] - exp[big]) ** 2) / exp[big]).sum()
     assert chi2 < 30.0 + 3.0 * big.sum(), (chi2, int(big.sum()))
+
+
+def test_batched_sampling_with_refills_is_reproducible(dev):
+    """infer_batched with the production sampling parameters (top_k 15, top_p 0.9, temperature 0.8; no repetition
+    penalty in the batched path, t2s_model.py:555-734) over more requests than slots -- the per-sequence kernels at
+    4 slots, the batched MFMA step at 40 -- completes every request once, keeps tokens in range and repeats exactly
+    for the same generator seed (the device sampler's stream is a counter-based function of seed / slot / position)."""
+    from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
+    cfg = synth.gpt_config(n_layer=6)
+    m = Text2SemanticDecoder(cfg)
+    m.load_state_dict(synth.gpt_weights(cfg, seed=3, eos_gain=3.0))
+    m.initialize_runtime(torch.bfloat16, dev, [(4, 256), (40, 256)])
+    reqs = [synth.synth_request(i, 10, 12 + i % 5, 20 + i % 7, seed=3) for i in range(50)]
+    xs = [torch.from_numpy(r[0]).to(dev) for r in reqs]
+    ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
+    bs = [torch.from_numpy(r[2]).to(dev) for r in reqs]
+    for n in (11, 50):
+        outs = []
+        for _ in range(2):
+            g = torch.Generator(device=dev)
+            g.manual_seed(7)
+            pred, orig = m.infer_batched(xs[:n], ys[:n], bs[:n], top_k=15, top_p=0.9, temperature=0.8, generator=g)
+            outs.append(([p.cpu().numpy() for p in pred], orig.cpu().numpy()))
+        assert sorted(outs[0][1].tolist()) == list(range(n))
+        assert np.array_equal(outs[0][1], outs[1][1])
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert np.array_equal(a, b) and ((a >= 0) & (a < 1024)).all()
+        assert max(len(p) for p in outs[0][0]) > 5
