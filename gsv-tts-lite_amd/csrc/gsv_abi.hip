@@ -18,6 +18,7 @@
 #include "t2s_prefill.h"
 #include "tapgemm.h"
 #include "wconv.h"
+#include "wups.h"
 #include "flowfuse.h"
 #include "encp.h"
 #include "voc_kernels.h"
@@ -257,6 +258,48 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
     if (C == 48) return launch(wconv_kernel<48, 2, 64>, wconv_lds_bytes<48, 2, 64>());
     if (Ck == 32) return launch(wconv_kernel<32, 1, 256>, wconv_lds_bytes<32, 1, 256>());
     return launch(wconv_kernel<16, 1, 256>, wconv_lds_bytes<16, 1, 256>());
+}
+
+
+// Upsampling layer (transposed conv) on the weights-in-registers kernel (wups.h); -1 = shape not covered (caller
+// falls back to tapgemm), 0 = launched, > 0 = GSV_ERR_*.
+template <typename AT>
+int run_wups(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
+    (void)pc; (void)X; (void)ldx; (void)n_in; (void)Y; (void)ldy; (void)in_slope; (void)st;
+    return -1;
+}
+template <>
+int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
+    if (pc.u < 1 || getenv("GSV_NO_WUPS")) return -1;
+    WUpsArgs a;
+    a.X = (const bf16_t*)X; a.W = (const uint4*)pc.w; a.bias = pc.bias; a.Y = (bf16_t*)Y;
+    a.ldx = ldx; a.ldy = ldy; a.n_in = n_in; a.u = pc.u; a.tpad = pc.pad; a.mtiles = pc.mtiles; a.cout = pc.cout;
+    a.cvalid = std::min(ldy, (pc.cout + 15) / 16 * 16); a.in_slope = in_slope;
+    auto launch = [&](auto kern, size_t lds, int ms, int bn, int pg, int max_blocks) -> int {
+        if (pc.u % pg != 0) return -1;
+        const int groups = (pc.u / pg) * cdiv(pc.mtiles, ms);
+        a.nwalk = std::max(1, std::min(cdiv(n_in, bn), max_blocks / groups));
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(a.nwalk * groups), dim3(256), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    };
+#define GSV_WUPS(CIN, MS, BN, NT, PG, MAXB)                                                     \
+    if (pc.cin == CIN && pc.ntaps == NT && ldx >= CIN)                                           \
+        return launch(wups_kernel<CIN, MS, BN, NT, PG>, wups_lds_bytes<CIN, MS, BN, NT, PG>(), MS, BN, PG, MAXB);
+    GSV_WUPS(512, 4, 32, 2, 1, 512)
+    GSV_WUPS(256, 4, 64, 2, 2, 256)
+    GSV_WUPS(128, 2, 128, 4, 2, 256)
+    GSV_WUPS(64, 1, 256, 1, 2, 512)
+    GSV_WUPS(32, 1, 256, 1, 2, 768)
+    // 768 -> 384 channels (v2ProPlus stage 0) stays on tapgemm: 96 fragments per wave spill, and its 500 rows per 10 s of
+    // audio give a block one tile to amortise a 393 KB weight load over (measured 47 vs 40 us)
+    GSV_WUPS(384, 2, 64, 2, 1, 264)
+    GSV_WUPS(192, 4, 64, 4, 1, 256)
+    GSV_WUPS(96, 2, 128, 1, 2, 512)
+    GSV_WUPS(48, 1, 256, 1, 2, 768)
+#undef GSV_WUPS
+    return -1;
 }
 
 }  // namespace
@@ -1123,7 +1166,10 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
                 if (wc ? q == 0 : q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
         }
         Epi eu; eu.in_slope = 0.1f;
-        if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
+        int ru = run_wups<AT>(sg.up, x, ldi, Tc, xu, ldo, 0.1f, st);
+        if (ru > 0) return ru;
+        if (ru < 0)
+            if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
         if (ldo != sg.cout) HIPCHK(hipMemsetAsync(x, 0, sizeof(AT) * (size_t)Tn * ldo, st));
         // the three resblocks (k = 3, 7, 11) advance in lock step: one launch per conv position
         const AT* cur[3] = {xu, xu, xu};
