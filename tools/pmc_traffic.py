@@ -36,7 +36,7 @@ flat = {k: v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in
 # whole flow + Generator pass: every launch of the vocoder-only kernel classes, divided by the number of passes
 # (one conv_post / one cl->cf per pass)
 def _is_voc(full):
-    return ("wconv_kernel" in full or "flowfuse_kernel" in full or "avg3_kernel" in full or "conv_post_kernel" in full
+    return ("wconv_kernel" in full or "wups_kernel" in full or "flowfuse_kernel" in full or "avg3_kernel" in full or "conv_post_kernel" in full
             or "cf_to_cl_kernel" in full or ("tapgemm_kernel<unsigned short, unsigned short" in full)
             or "rowgemm_kernel<unsigned short, float, 16>" in full)   # cond GEMV (gin 1024); <.., 8> is also the prefill's W2
 passes = sum(len(v) for k, v in fetch.items() if "conv_post_kernel" in k)
