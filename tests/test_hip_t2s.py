@@ -481,3 +481,41 @@ def test_batched_sampling_with_refills_is_reproducible(dev):
         for a, b in zip(outs[0][0], outs[1][0]):
             assert np.array_equal(a, b) and ((a >= 0) & (a < 1024)).all()
         assert max(len(p) for p in outs[0][0]) > 5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prefill_into_scattered_slots_equals_one_by_one(dev, dtype):
+    """gsv_t2s_prefill_slots (the packed refill of a check window): rows of different lengths sent to slots [5, 0, 3]
+    in one call leave exactly the state that three single-row prefills leave -- K/V cache rows, kv_len / x_len, the
+    first logits and the recorded prompt tokens, bit for bit (rows are independent through every prefill kernel)."""
+    cfg = synth.gpt_config(n_layer=4)
+    w = synth.gpt_weights(cfg, seed=21)
+    shapes = [(6, 11, 14), (3, 4, 30), (9, 20, 7)]
+    rs = [synth.synth_request(70 + i, p, t, n, seed=21, bert="random") for i, (p, t, n) in enumerate(shapes)]
+    slots = [5, 0, 3]
+    xs, ys, bs = ([_T(r[k], dev) for r in rs] for k in range(3))
+    states = []
+    for packed in (False, True):
+        with torch.inference_mode():
+            m = _model(cfg, w, [(6, 96)], dtype, dev)
+            rt = m._rt[6]
+            for t in (rt["kv_len"], rt["x_len"], rt["logits"], rt["pre_tokens"]):
+                t.zero_()
+            m.k_cache_root.zero_()
+            m.v_cache_root.zero_()
+            if packed:
+                xy, xl, yl, _, _ = m.embed_prompt(xs, ys, bs)
+                m.prefill_slots(6, slots, xy, xl, yl)
+            else:
+                for s_, x, y, b in zip(slots, xs, ys, bs):
+                    xy, xl, yl, _, _ = m.embed_prompt([x], [y], [b])
+                    m.prefill(6, s_, xy, xl, yl)
+            m._flush(6)
+            torch.cuda.synchronize()
+            st = {k: rt[k].clone() for k in ("kv_len", "x_len", "logits", "pre_tokens")}
+            st.update({"k": m.k_cache_root.clone(), "v": m.v_cache_root.clone()})
+            states.append(st)
+    a, b = states
+    assert a["kv_len"].tolist() == b["kv_len"].tolist() and a["kv_len"][5] == 6 + 11 + 14 and a["kv_len"][1] == 0
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
