@@ -319,6 +319,24 @@ def main():
                 tb.append((time.perf_counter() - s0) * 1e3)
             out["ttft_bs32_first_batch_ms_p50"] = float(np.median(tb[2:]))
             del t32
+            # the vocoder as TTS.infer_batched feeds it (TTS.py:728-764): 10 utterances time-concatenated, per-frame ge
+            T10 = 10 * FRAMES
+            z10 = z_p.repeat(1, 1, 10).contiguous()
+            m10 = torch.ones(1, 1, T10, device=dev)
+            ge10 = ge.expand(-1, -1, T10).contiguous()
+            for _ in range(2):
+                voc.flow_dec(z10, m10, ge10)
+            torch.cuda.synchronize(dev); s0 = time.perf_counter()
+            for _ in range(3):
+                voc.flow_dec(z10, m10, ge10)
+            torch.cuda.synchronize(dev)
+            t10 = (time.perf_counter() - s0) / 3
+            vb10, vf10 = vocoder_algorithmic(a.version, sbytes)
+            out["roofline_vocoder_batch10"] = {
+                "bound": "hbm", "achieved": vb10 * T10 / t10 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": vb10 * T10 / t10 / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_10s_audio": t10 * 1e3 / 10,
+                "mfma_tflops": vf10 * T10 / t10 / 1e12,
+                "note": "flow+Generator on 10 time-concatenated utterances (100 s of audio) in one pass, per-frame ge"}
         except Exception as exc:   # extras must never cost the bench line
             log("extras skipped: %r" % (exc,))
 
