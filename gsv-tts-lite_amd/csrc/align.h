@@ -26,7 +26,7 @@ namespace gsv {
 
 constexpr int kAlignMaxHeads = 8;
 
-__global__ __launch_bounds__(256) void align_normal_kernel(const float* __restrict__ attn, int H, int T, int N,
+static __global__ __launch_bounds__(256) void align_normal_kernel(const float* __restrict__ attn, int H, int T, int N,
                                                             float* __restrict__ normal, int* __restrict__ rowflag) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -10,7 +10,7 @@ namespace gsv {
 
 // rows of a table -> channels-last bf16 rows; `rep` consecutive output rows per index (x2 nearest upsampling
 // of the codebook vectors, models.py:388-392)
-__global__ void encp_gather_kernel(const int64_t* __restrict__ idx, int n_idx, int n_rows_table, const float* __restrict__ table,
+static __global__ void encp_gather_kernel(const int64_t* __restrict__ idx, int n_idx, int n_rows_table, const float* __restrict__ table,
                                    int C, int rep, bf16_t* __restrict__ out) {
     const int r = blockIdx.x;                                // output row
     int id = (int)idx[r / rep];
@@ -23,7 +23,7 @@ __global__ void encp_gather_kernel(const int64_t* __restrict__ idx, int n_idx, i
 
 // modules.LayerNorm over the channel axis (attentions.py / modules.py:14-27): y[t] = LN(x[t]) * gamma + beta, one
 // wave per row, C <= 512, two-pass like F.layer_norm
-__global__ __launch_bounds__(256) void encp_ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+static __global__ __launch_bounds__(256) void encp_ln_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ y, int rows, int C) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void encp_ln_kernel(const bf16_t* __restrict__
 
 // y[t] = LN(sum_s P[s][t] + bias + res[t]) * gamma + beta : consumer of rowgemm's raw (split) fp32 tiles in the encoder
 // layers (x = LN(x + attn_out), x = LN(x + ffn_out), attentions.py:88-101); y may alias res row-wise
-__global__ __launch_bounds__(256) void encp_ln_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
+static __global__ __launch_bounds__(256) void encp_ln_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
                                                           const float* __restrict__ bias, const bf16_t* res,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* y, int rows, int C) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void encp_ln_sum_kernel(const float* __restric
 }
 
 // a + b (+ per-row or broadcast fp32 row g) -> bf16 : the MRTE sum  attn_out + ssl_enc + ge  (mrte_model.py:35-36)
-__global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg,
+static __global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg,
                                  bf16_t* __restrict__ y, int rows, int C) {
     const size_t n = (size_t)rows * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -79,7 +79,7 @@ __device__ __forceinline__ void ff_pack16(const float (&v)[16], u32x4& a, u32x4&
     }
 }
 
-__global__ __launch_bounds__(256, 1) void flowfuse_kernel(FlowFuseArgs a) {
+static __global__ __launch_bounds__(256, 1) void flowfuse_kernel(FlowFuseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* Hb = lds + FF_LDS_H;
     unsigned char* Ab = lds + FF_LDS_A;

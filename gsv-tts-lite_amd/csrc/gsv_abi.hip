@@ -1,46 +1,13 @@
-// C ABI of the MI355X GPT-SoVITS hot path (include/gsv_tts_hip.h): handle management, weight
-// repacking into library-owned arenas, kernel sequencing, hipGraph capture of the decode step.
+// C ABI of the MI355X GPT-SoVITS hot path (include/gsv_tts_hip.h), GPT part: handle management, weight
+// repacking into library-owned arenas, kernel sequencing, hipGraph capture of the decode step.  (SoVITS: gsv_voc.hip.)
 // No allocation happens inside a step; nothing here falls back to a CPU or library path.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/gsv_tts_hip.h"
+#include "abi_common.h"
 #include "t2s_decode.h"
 #include "t2s_megastep.h"
-#include "t2s_prefill.h"
-#include "tapgemm.h"
-#include "wconv.h"
-#include "wups.h"
-#include "flowfuse.h"
-#include "encp.h"
-#include "voc_kernels.h"
-#include "gsv_error.h"
-
-using namespace gsv;
 
 namespace {
-
 thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
 }
-
-}  // namespace
 
 int gsv::abi_fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -51,258 +18,6 @@ int gsv::abi_fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-
-namespace {
-
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(GSV_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-// ---------------------------------------------------------------------------------------------
-// tapgemm host side
-// ---------------------------------------------------------------------------------------------
-struct PackedConv {
-    void* w = nullptr;
-    float* bias = nullptr;
-    int cout = 0, cin = 0, cin_pad = 0, k = 1, dil = 1, pad = 0, u = 0;
-    int nphase = 1, ntaps = 1, mtiles = 1;
-};
-
-template <typename CT>
-int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_t sm, int64_t sc, int64_t sk,
-              int dil, int pad, int u, const float* bias_src, float bias_scale, hipStream_t st) {
-    constexpr int KS = MfmaK<CT>::KS;
-    if (cin % KS != 0) return fail(GSV_ERR_ARG, "tapgemm: cin %d not a multiple of %d", cin, KS);
-    pc.cout = cout; pc.cin = cin; pc.cin_pad = cin; pc.k = k; pc.dil = dil; pc.pad = pad; pc.u = u;
-    pc.nphase = u > 0 ? u : 1;
-    pc.ntaps = u > 0 ? cdiv(k, u) : k;
-    pc.mtiles = cdiv(cout, 32);
-    if (pc.nphase > 10 || pc.ntaps > 12) return fail(GSV_ERR_ARG, "tapgemm: too many phases/taps");
-    const size_t elems = (size_t)pc.nphase * pc.ntaps * pc.mtiles * (cin / KS) * 64 * (KS / 2);
-    // + one all-zero fragment: what the pipelined loop fetches for iterations past the end
-    HIPCHK(hipMalloc(&pc.w, (elems + 64 * (KS / 2)) * sizeof(CT)));
-    HIPCHK(hipMemsetAsync((CT*)pc.w + elems, 0, 64 * (KS / 2) * sizeof(CT), st));
-    const int blocks = (int)std::min<size_t>(2048, (elems + 255) / 256);
-    hipLaunchKernelGGL((tapgemm_pack_kernel<CT>), dim3(blocks), dim3(256), 0, st, src, (CT*)pc.w, cout, cin, k, sm, sc,
-                       sk, pc.nphase, pc.ntaps, u, pad, pc.mtiles);
-    if (bias_src) {
-        HIPCHK(hipMalloc(&pc.bias, sizeof(float) * cout));
-        hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, bias_src, pc.bias, (size_t)cout,
-                           bias_scale);
-    }
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-void free_conv(PackedConv& pc) {
-    if (pc.w) (void)hipFree(pc.w);
-    if (pc.bias) (void)hipFree(pc.bias);
-    pc.w = nullptr; pc.bias = nullptr;
-}
-
-struct Epi {
-    const float* add = nullptr; int ld_add = 0;
-    const void* res = nullptr; int ld_res = 0;
-    const float* mask = nullptr;
-    float scale = 1.0f; int act = ACT_NONE; int accumulate = 0; float in_slope = 1.0f;
-    bool use_bias = true;
-};
-
-struct Branch {
-    const PackedConv* pc;
-    const void* X;
-    void* Y;
-    const void* res;
-};
-
-// One launch for up to 3 convolutions of the same shape class (same cin/cout/ld/rows, different
-// kernel size, dilation, weights and buffers): blockIdx.z is the branch.
-template <typename IT, typename CT, typename OT>
-int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n_rows, const Epi& e, hipStream_t st) {
-    const PackedConv& pc = *brs[0].pc;
-    if (nbr < 1 || nbr > 3) return fail(GSV_ERR_ARG, "tapgemm: 1..3 branches");
-    for (int i = 1; i < nbr; ++i)
-        if (brs[i].pc->cout != pc.cout || brs[i].pc->cin != pc.cin || brs[i].pc->u != 0 || pc.u != 0)
-            return fail(GSV_ERR_ARG, "tapgemm: branches must be plain convs of one shape");
-    TapGemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.X = brs[0].X; a.ldx = ldx; a.n_in = n_in; a.cin = pc.cin; a.W = pc.w; a.cout = pc.cout; a.mtiles = pc.mtiles;
-    a.ntaps = pc.ntaps; a.nphase = pc.nphase;
-    a.tstep = pc.dil; a.tpad = pc.pad; a.tu = pc.u;
-    a.omul = pc.u > 0 ? pc.u : 1;
-    a.nbranch = nbr;
-    if (nbr > 1) { a.X1 = brs[1].X; a.W1 = brs[1].pc->w; a.res1 = brs[1].res; a.bias1 = e.use_bias ? brs[1].pc->bias : nullptr; a.Y1 = brs[1].Y;
-                   a.ntaps1 = brs[1].pc->ntaps; a.tstep1 = brs[1].pc->dil; a.tpad1 = brs[1].pc->pad; }
-    if (nbr > 2) { a.X2 = brs[2].X; a.W2 = brs[2].pc->w; a.res2 = brs[2].res; a.bias2 = e.use_bias ? brs[2].pc->bias : nullptr; a.Y2 = brs[2].Y;
-                   a.ntaps2 = brs[2].pc->ntaps; a.tstep2 = brs[2].pc->dil; a.tpad2 = brs[2].pc->pad; }
-    a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
-    a.res = brs[0].res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
-    a.accumulate = e.accumulate; a.Y = brs[0].Y; a.ldy = ldy; a.n_rows = n_rows;
-    // tile choice.  Enough rows to fill the chip several times over -> wide tiles (weights reused
-    // across 64 rows/channels per wave); short sequences (prefill, flow, conditioning GEMV) ->
-    // one 32x32 tile per block with the 4 waves splitting K.
-    int span = 0;
-    for (int i = 0; i < nbr; ++i) {
-        const PackedConv& q = *brs[i].pc;
-        for (int r = 0; r < q.nphase; ++r) {
-            int lo = 1 << 30, hi = -(1 << 30);
-            for (int t = 0; t < q.ntaps; ++t) {
-                const int sh = q.u > 0 ? (r + q.pad) / q.u - t : t * q.dil - q.pad;
-                lo = std::min(lo, sh); hi = std::max(hi, sh);
-            }
-            span = std::max(span, hi - lo);
-        }
-    }
-    const int nz = nbr > 1 ? nbr : pc.nphase;
-    const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * nz;   // blocks at (WM,WN) = (1,1)
-    const bool splitk = tiles11 < 256;
-    const bool wide_m = !splitk && pc.mtiles >= 2 && tiles11 >= 1024;
-    const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * nz >= 1024;
-    // mid-size problems (the 256-channel resblock stage: 5000 rows x 8 m-tiles x 3 branches): 64-row waves at two
-    // blocks per CU measured 40.9 us vs 48.8 us for the 32-row tile (tools/tg_bench.hip)
-    const bool mid_n = !splitk && !wide_m && !wide_n && (long)cdiv(n_rows, 256) * pc.mtiles * nz >= 256;
-    const int bn = splitk ? 32 : ((wide_n || mid_n) ? 256 : 128);
-    const int kcb = (wide_n || mid_n) ? 128 : 256;    // staged bytes per row per chunk
-    size_t lds = (size_t)(bn + span) * (kcb + 16);
-    if (splitk) lds = std::max(lds, (size_t)3 * 16 * 64 * sizeof(float));
-    if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "tapgemm: tap span %d needs %zu B of LDS", span, lds);
-    dim3 blk(256);
-    auto launch = [&](auto kern, dim3 grid) -> int {
-        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, blk, lds, st, a);
-        return GSV_OK;
-    };
-    int rc;
-    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, true>, dim3(cdiv(n_rows, 32), pc.mtiles, nz));
-    else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), nz));
-    else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), nz));
-    else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
-    else if (mid_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false, 1, 2, 4>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
-    else rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, false>, dim3(cdiv(n_rows, 128), pc.mtiles, nz));
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-template <typename IT, typename CT, typename OT>
-int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, int n_rows, const Epi& e,
-             hipStream_t st) {
-    Branch b{&pc, X, Y, e.res};
-    return run_conv_multi<IT, CT, OT>(&b, 1, ldx, n_in, ldy, n_rows, e, st);
-}
-
-// The weights-in-registers path for the Generator's resblock convs (wconv.h).  Returns 1 when the
-// launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
-inline bool wconv_channels(int C) {
-    return C == 16 || C == 24 || C == 32 || C == 48 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256;
-}
-template <typename AT>
-int run_wconv(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
-    (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
-    return -1;
-}
-template <>
-int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
-    const int C = brs[0].pc->cout;
-    if (!wconv_channels(C)) return -1;
-    const int Ck = C == 24 ? 32 : C;   // 24 channels live in rows of 32 (zero pad channels, zero weight rows): the 32 kernel
-    int order[3] = {0, 1, 2};
-    for (int i = 0; i < 3; ++i) {
-        const PackedConv& q = *brs[i].pc;
-        if (q.cin != Ck || q.cout != C || q.u != 0 || (q.k != 3 && q.k != 7 && q.k != 11) || q.dil < 1 || q.dil > 5 ||
-            q.pad != (q.k - 1) / 2 * q.dil || ld < Ck)
-            return -1;
-    }
-    std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
-    // blocks are dealt in proportion to taps + a per-tile overhead (staging, epilogue) in tap units; both the
-    // overhead and the block count per shape are measured (tools/tg_bench.hip)
-    const int msp = C == 256 ? 4 : (C == 192 ? 3 : 1);   // blocks that share a row-tile walk (output slices split between them)
-    int nblk = C >= 64 ? 256 : (C >= 32 ? 512 : (C == 24 ? 512 : 768));
-    const double ovh = C >= 96 ? 8.0 : (C == 64 ? 14.0 : (C == 48 ? 30.0 : 50.0));
-    double tot = 0;
-    for (int i = 0; i < 3; ++i) tot += brs[i].pc->k + ovh;
-    int nb[3], used = 0;
-    for (int i = 0; i < 3; ++i) { nb[i] = std::max(msp, (int)(nblk * (brs[order[i]].pc->k + ovh) / tot) / msp * msp); used += nb[i]; }
-    nb[0] += (nblk - used) / msp * msp;
-    nblk = nb[0] + nb[1] + nb[2];
-    WConvArgs a;
-    memset(&a, 0, sizeof(a));
-    const Branch &b0 = brs[order[0]], &b1 = brs[order[1]], &b2 = brs[order[2]];
-    a.X0 = (const bf16_t*)b0.X; a.X1 = (const bf16_t*)b1.X; a.X2 = (const bf16_t*)b2.X;
-    a.W0 = (const uint4*)b0.pc->w; a.W1 = (const uint4*)b1.pc->w; a.W2 = (const uint4*)b2.pc->w;
-    a.b0 = b0.pc->bias; a.b1 = b1.pc->bias; a.b2 = b2.pc->bias;
-    a.R0 = (const bf16_t*)b0.res; a.R1 = (const bf16_t*)b1.res; a.R2 = (const bf16_t*)b2.res;
-    a.Y0 = (bf16_t*)b0.Y; a.Y1 = (bf16_t*)b1.Y; a.Y2 = (bf16_t*)b2.Y;
-    a.k0 = b0.pc->k; a.k1 = b1.pc->k; a.k2 = b2.pc->k;
-    a.d0 = b0.pc->dil; a.d1 = b1.pc->dil; a.d2 = b2.pc->dil;
-    a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
-    a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope; a.cout = C;
-    if ((b0.res == nullptr) != (b1.res == nullptr) || (b0.res == nullptr) != (b2.res == nullptr)) return -1;
-    auto launch = [&](auto kern, size_t lds) -> int {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
-        HIPCHK(hipGetLastError());
-        return GSV_OK;
-    };
-    if (C == 256) return launch(wconv_kernel<256, 2, 64, 2, 4>, wconv_lds_bytes<256, 2, 64, 2, 4>());   // K split in the block, slices over 4 blocks
-    if (C == 192) return launch(wconv_kernel<192, 2, 64, 2, 3>, wconv_lds_bytes<192, 2, 64, 2, 3>());
-    if (C == 128) return launch(wconv_kernel<128, 4, 64>, wconv_lds_bytes<128, 4, 64>());
-    if (C == 96) return launch(wconv_kernel<96, 4, 64>, wconv_lds_bytes<96, 4, 64>());     // 3 slices + a staging-only wave
-    if (C == 64) return launch(wconv_kernel<64, 2, 128>, wconv_lds_bytes<64, 2, 128>());
-    if (C == 48) return launch(wconv_kernel<48, 2, 64>, wconv_lds_bytes<48, 2, 64>());
-    if (Ck == 32) return launch(wconv_kernel<32, 1, 256>, wconv_lds_bytes<32, 1, 256>());
-    return launch(wconv_kernel<16, 1, 256>, wconv_lds_bytes<16, 1, 256>());
-}
-
-
-// Upsampling layer (transposed conv) on the weights-in-registers kernel (wups.h); -1 = shape not covered (caller
-// falls back to tapgemm), 0 = launched, > 0 = GSV_ERR_*.
-template <typename AT>
-int run_wups(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
-    (void)pc; (void)X; (void)ldx; (void)n_in; (void)Y; (void)ldy; (void)in_slope; (void)st;
-    return -1;
-}
-template <>
-int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
-    if (pc.u < 1 || getenv("GSV_NO_WUPS")) return -1;
-    WUpsArgs a;
-    a.X = (const bf16_t*)X; a.W = (const uint4*)pc.w; a.bias = pc.bias; a.Y = (bf16_t*)Y;
-    a.ldx = ldx; a.ldy = ldy; a.n_in = n_in; a.u = pc.u; a.tpad = pc.pad; a.mtiles = pc.mtiles; a.cout = pc.cout;
-    a.cvalid = std::min(ldy, (pc.cout + 15) / 16 * 16); a.in_slope = in_slope;
-    auto launch = [&](auto kern, size_t lds, int ms, int bn, int pg, int max_blocks) -> int {
-        if (pc.u % pg != 0) return -1;
-        const int groups = (pc.u / pg) * cdiv(pc.mtiles, ms);
-        a.nwalk = std::max(1, std::min(cdiv(n_in, bn), max_blocks / groups));
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(a.nwalk * groups), dim3(256), lds, st, a);
-        HIPCHK(hipGetLastError());
-        return GSV_OK;
-    };
-#define GSV_WUPS(CIN, MS, BN, NT, PG, MAXB)                                                     \
-    if (pc.cin == CIN && pc.ntaps == NT && ldx >= CIN)                                           \
-        return launch(wups_kernel<CIN, MS, BN, NT, PG>, wups_lds_bytes<CIN, MS, BN, NT, PG>(), MS, BN, PG, MAXB);
-    GSV_WUPS(512, 4, 32, 2, 1, 512)
-    GSV_WUPS(256, 4, 64, 2, 2, 256)
-    GSV_WUPS(128, 2, 128, 4, 2, 256)
-    GSV_WUPS(64, 1, 256, 1, 2, 512)
-    GSV_WUPS(32, 1, 256, 1, 2, 768)
-    // 768 -> 384 channels (v2ProPlus stage 0) stays on tapgemm: 96 fragments per wave spill, and its 500 rows per 10 s of
-    // audio give a block one tile to amortise a 393 KB weight load over (measured 47 vs 40 us)
-    GSV_WUPS(384, 2, 64, 2, 1, 264)
-    GSV_WUPS(192, 4, 64, 4, 1, 256)
-    GSV_WUPS(96, 2, 128, 1, 2, 512)
-    GSV_WUPS(48, 1, 256, 1, 2, 768)
-#undef GSV_WUPS
-    return -1;
-}
-
-}  // namespace
 
 // =============================================================================================
 // GPT
@@ -969,801 +684,6 @@ int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream) {
     T2SBound* b = t2s_find(h, batch);
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     return t2s_token(h, b->st, 0, S(stream));
-}
-
-}  // extern "C"
-
-// =============================================================================================
-// SoVITS flow + Generator
-// =============================================================================================
-struct VocFlow {
-    PackedConv pre, cond, post;      // post packed NEGATED: x1 + (-(W out + b)) in the epilogue
-    PackedConv in_l[4], rs_res[3], rs_skip[4];
-    void* ff_w = nullptr;            // flowfuse.h weight arena (bf16 mode, hidden 192 / half 96 only)
-    float* ff_b = nullptr;           // flowfuse.h bias arena
-    int parity = 0;                  // 1: this layer sees the tensor channel-reversed (odd number of Flips before it)
-};
-struct VocResBlock {
-    PackedConv c1[3], c2[3];
-    int k = 3;
-};
-struct VocStage {
-    PackedConv up;
-    std::vector<VocResBlock> rb;
-    int cin = 0, cout = 0, u = 1;
-};
-
-struct EncLayer {
-    PackedConv qkv, o, c1, c2;
-    float *relk = nullptr, *relv = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
-};
-struct EncP {
-    bool ready = false;
-    PackedConv ssl_proj, c_pre, text_pre, c_post, proj, xq, xkv, xo;
-    float *text_emb = nullptr, *codebook = nullptr;
-    int n_text = 0, n_code = 0;
-    std::vector<EncLayer> ssl, text, enc2;
-    std::vector<float*> owned;       // small fp32 tensors (norms, relative embeddings, tables)
-};
-
-struct gsv_voc {
-    gsv_voc_config cfg;
-    std::map<std::string, std::pair<float*, int64_t>> staged;
-    bool finalized = false;
-    std::vector<VocFlow> flows;
-    PackedConv conv_pre, cond, conv_post;
-    PackedConv cond_all;             // every flow's cond_layer stacked: one launch for the whole flow
-    float* post_w = nullptr;         // conv_post weight [C][7] fp32 for conv_post_kernel
-    int post_c = 0;
-    bool fused_flow = false;
-    EncP enc;                        // enc_p in HIP (bf16 mode, when its tensors were loaded)
-    std::vector<VocStage> stages;
-    int total_up = 1;
-    int max_stage_elems_per_frame = 0;  // max over stages of ld(C) * time multiplier
-};
-
-namespace {
-
-inline int ld_of(int c) { return (c + 15) / 16 * 16; }
-
-// conditioning GEMV / small-row 1x1 convs (bf16 in, fp32 out): the latency-shaped rowgemm when the
-// contraction is 512 or 1024 channels, else the generic kernel
-template <typename AT>
-int run_cond(const PackedConv& pc, const void* X, int ldx, int rows, float* Y, int ldy, hipStream_t st) {
-    if (sizeof(AT) == 2 && pc.u == 0 && pc.k == 1 && (pc.cin == 512 || pc.cin == 1024)) {
-        RowGemmArgs ra;
-        ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
-        ra.bias = pc.bias; ra.relu = 0;
-        ra.Y = Y; ra.ldy = ldy; ra.split_stride = 0;
-        const dim3 grid(cdiv(rows, 32), pc.mtiles, 1);
-        if (pc.cin == 512) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 8>), grid, dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 16>), grid, dim3(256), 0, st, ra);
-        HIPCHK(hipGetLastError());
-        return GSV_OK;
-    }
-    Epi ec;
-    return run_conv<AT, AT, float>(pc, X, ldx, rows, Y, ldy, rows, ec, st);
-}
-
-struct VocWs {
-    // channels-last buffers (element type AT unless noted)
-    void *zin, *zflip, *h, *outp, *a, *acts, *ge_cl;
-    float *gc, *condbuf;
-    void* st[11];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}
-    size_t bytes;
-};
-
-template <typename AT>
-VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
-    const gsv_voc_config& c = v->cfg;
-    const int H = c.hidden_channels, C = c.inter_channels;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
-    VocWs w;
-    w.zin = take(sizeof(AT) * (size_t)T * C);
-    w.zflip = take(sizeof(AT) * (size_t)T * C);
-    w.h = take(sizeof(AT) * (size_t)T * H);
-    w.outp = take(sizeof(AT) * (size_t)T * H);
-    w.a = take(sizeof(AT) * (size_t)T * 2 * H);
-    w.acts = take(sizeof(AT) * (size_t)T * H);
-    w.ge_cl = take(sizeof(AT) * (size_t)Tg * c.gin_channels);
-    w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H * std::max(1, c.n_flows));
-    w.condbuf = (float*)take(sizeof(float) * (size_t)Tg * c.upsample_initial_channel);
-    const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
-    for (int i = 0; i < 11; ++i) w.st[i] = take(sizeof(AT) * se);
-    w.bytes = off;
-    return w;
-}
-
-template <typename AT>
-int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStream_t st) {
-    const gsv_voc_config& c = v->cfg;
-    const int H = c.hidden_channels, C = c.inter_channels, half = C / 2;
-    AT* x = (AT*)w.zin;
-    AT* xf = (AT*)w.zflip;
-    if (v->fused_flow && sizeof(AT) == 2) {
-        // one launch for every flow's conditioning, then one fused kernel per coupling layer; no Flip passes
-        const int ldg_all = 8 * H * c.n_flows;
-        if (int rc = run_cond<AT>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, st)) return rc;
-        HIPCHK(hipFuncSetAttribute((const void*)flowfuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS_TOTAL));
-        for (int f = c.n_flows - 1; f >= 0; --f) {
-            VocFlow& F = v->flows[f];
-            FlowFuseArgs a;
-            a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
-            a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
-            a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
-            const int nt = cdiv(T, FF_VR), nx = std::min(8, cdiv(nt, 32));
-            a.per_xcd = cdiv(nt, nx);
-            a.dbg = nullptr;
-            static const bool ff_debug = getenv("GSV_FF_DEBUG") != nullptr;
-            long long* dbg = nullptr;
-            if (ff_debug) { HIPCHK(hipMalloc(&dbg, 32 * sizeof(long long))); HIPCHK(hipMemset(dbg, 0, 32 * sizeof(long long))); a.dbg = dbg; }
-            hipLaunchKernelGGL(flowfuse_kernel, dim3(8 * a.per_xcd), dim3(256), FF_LDS_TOTAL, st, a);
-            if (ff_debug) {
-                long long h[32];
-                HIPCHK(hipStreamSynchronize(st));
-                HIPCHK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[flowfuse f=%d]", f);
-                for (int i = 1; i < 32 && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
-                fprintf(stderr, "\n");
-                (void)hipFree(dbg);
-            }
-        }
-        HIPCHK(hipGetLastError());
-        return GSV_OK;
-    }
-    const int ew = std::min(2048, cdiv(T * H, 256));
-    for (int f = c.n_flows - 1; f >= 0; --f) {
-        VocFlow& F = v->flows[f];
-        hipLaunchKernelGGL((flip_kernel<AT>), dim3(std::min(2048, cdiv(T * C, 256))), dim3(256), 0, st, x, xf, C, T, C);
-        std::swap(x, xf);  // x is now the flipped tensor
-        Epi ep; ep.mask = mask;
-        if (int rc = run_conv<AT, AT, AT>(F.pre, x, C, T, w.h, H, T, ep, st)) return rc;
-        Epi ec;
-        if (int rc = run_conv<AT, AT, float>(F.cond, w.ge_cl, c.gin_channels, Tg, w.gc, 8 * H, Tg, ec, st)) return rc;
-        for (int l = 0; l < 4; ++l) {
-            Epi ei; ei.add = w.gc + (size_t)l * 2 * H; ei.ld_add = Tg == 1 ? 0 : 8 * H;
-            if (int rc = run_conv<AT, AT, AT>(F.in_l[l], w.h, H, T, w.a, 2 * H, T, ei, st)) return rc;
-            hipLaunchKernelGGL((gate_kernel<AT>), dim3(ew), dim3(256), 0, st, (const AT*)w.a, (AT*)w.acts, H, T);
-            Epi es; es.accumulate = l > 0;
-            if (int rc = run_conv<AT, AT, AT>(F.rs_skip[l], w.acts, H, T, w.outp, H, T, es, st)) return rc;
-            if (l < 3) {
-                Epi er; er.res = w.h; er.ld_res = H; er.mask = mask;
-                if (int rc = run_conv<AT, AT, AT>(F.rs_res[l], w.acts, H, T, w.h, H, T, er, st)) return rc;
-            }
-        }
-        // x1 = (x1 - (post(out*mask)+b)*mask) * mask, binary mask; post is packed negated
-        Epi eo; eo.res = x + half; eo.ld_res = C; eo.mask = mask;
-        if (int rc = run_conv<AT, AT, AT>(F.post, w.outp, H, T, x + half, C, T, eo, st)) return rc;
-    }
-    if (x != (AT*)w.zin) HIPCHK(hipMemcpyAsync(w.zin, x, sizeof(AT) * (size_t)T * C, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-template <typename AT>
-int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st) {
-    const gsv_voc_config& c = v->cfg;
-    const int C0 = c.upsample_initial_channel;
-    if (int rc = run_cond<AT>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, st)) return rc;
-    AT* x = (AT*)w.st[1];
-    Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0;
-    if (int rc = run_conv<AT, AT, AT>(v->conv_pre, w.zin, c.inter_channels, T, x, ld_of(C0), T, ep, st)) return rc;
-    int Tc = T;
-    AT* xu = (AT*)w.st[0];
-    const int NB = (int)v->stages[0].rb.size();
-    if (NB != 3) return fail(GSV_ERR_ARG, "the fused branch launch expects 3 resblock kernels per stage");
-    for (size_t i = 0; i < v->stages.size(); ++i) {
-        VocStage& sg = v->stages[i];
-        const int ldi = ld_of(sg.cin), ldo = ld_of(sg.cout);
-        const int Tn = Tc * sg.u;
-        // pad channels feed zero-weight k-steps but must not hold NaN/Inf bit patterns.  The wconv path writes whole
-        // rows (its pad outputs are exact zeros: zero weight rows, zero bias, zero residual), so there only the
-        // transposed conv's output buffer needs clearing; the tapgemm path writes `cout` channels per row.
-        const bool wc = sizeof(AT) == 2 && wconv_channels(sg.cout);
-        if (ldo != sg.cout) {
-            for (int q = 0; q < 11; ++q)
-                if (wc ? q == 0 : q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
-        }
-        Epi eu; eu.in_slope = 0.1f;
-        int ru = run_wups<AT>(sg.up, x, ldi, Tc, xu, ldo, 0.1f, st);
-        if (ru > 0) return ru;
-        if (ru < 0)
-            if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
-        if (ldo != sg.cout) HIPCHK(hipMemsetAsync(x, 0, sizeof(AT) * (size_t)Tn * ldo, st));
-        // the three resblocks (k = 3, 7, 11) advance in lock step: one launch per conv position
-        const AT* cur[3] = {xu, xu, xu};
-        for (int d = 0; d < 3; ++d) {
-            Branch b1[3], b2[3];
-            for (int j = 0; j < 3; ++j) {
-                AT* t1 = (AT*)w.st[2 + 3 * j];
-                AT* dst = (AT*)w.st[2 + 3 * j + 1 + (d & 1)];
-                b1[j] = Branch{&sg.rb[j].c1[d], cur[j], t1, nullptr};
-                b2[j] = Branch{&sg.rb[j].c2[d], t1, dst, cur[j]};
-            }
-            // bf16, 16..128 channels: weights-in-registers kernel; the first conv writes lrelu(t1), which is
-            // the only form its consumer reads, so the second conv stages its input without arithmetic
-            int rw = run_wconv<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
-            if (rw > 0) return rw;
-            if (rw != 0 && wc && ldo != sg.cout) return fail(GSV_ERR_STATE, "wconv declined a padded stage whose buffers were not cleared");
-            if (rw == 0) {
-                rw = run_wconv<AT>(b2, ldo, Tn, 1.0f, 1.0f, st);
-                if (rw > 0) return rw;
-                if (rw != 0) return fail(GSV_ERR_STATE, "wconv accepted the first conv of a pair but not the second");
-            } else {
-                Epi e1; e1.in_slope = 0.1f;
-                if (int rc = run_conv_multi<AT, AT, AT>(b1, 3, ldo, Tn, ldo, Tn, e1, st)) return rc;
-                Epi e2; e2.in_slope = 0.1f; e2.ld_res = ldo;
-                if (int rc = run_conv_multi<AT, AT, AT>(b2, 3, ldo, Tn, ldo, Tn, e2, st)) return rc;
-            }
-            for (int j = 0; j < 3; ++j) cur[j] = (const AT*)b2[j].Y;
-        }
-        const size_t n = (size_t)Tn * ldo;
-        hipLaunchKernelGGL((avg3_kernel<AT>), dim3((unsigned)std::min<size_t>(4096, (n / 8 + 255) / 256)), dim3(256), 0, st,
-                           cur[0], cur[1], cur[2], x, n);
-        Tc = Tn;
-    }
-    if (sizeof(AT) == 2 && v->post_w && (v->post_c == 16 || v->post_c == 24)) {
-        const int ldp = ld_of(v->post_c);
-        if (v->post_c == 16) hipLaunchKernelGGL((conv_post_kernel<AT, 16>), dim3(cdiv(Tc, 256)), dim3(256), 0, st, (const AT*)x, ldp, (const float*)v->post_w, out, Tc);
-        else hipLaunchKernelGGL((conv_post_kernel<AT, 24>), dim3(cdiv(Tc, 256)), dim3(256), 0, st, (const AT*)x, ldp, (const float*)v->post_w, out, Tc);
-    } else {
-        Epi eo; eo.in_slope = 0.01f; eo.act = ACT_TANH; eo.use_bias = false;
-        if (int rc = run_conv<AT, AT, float>(v->conv_post, x, ld_of(v->stages.back().cout), Tc, out, 1, Tc, eo, st)) return rc;
-    }
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-template <typename AT>
-int voc_prepare(gsv_voc* v, VocWs& w, const float* z, const float* ge, int T, int Tg, hipStream_t st) {
-    const gsv_voc_config& c = v->cfg;
-    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(T, 32), cdiv(c.inter_channels, 32)), dim3(256), 0, st, z,
-                       (AT*)w.zin, c.inter_channels, T, c.inter_channels);
-    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(c.gin_channels, 32)), dim3(256), 0, st, ge,
-                       (AT*)w.ge_cl, c.gin_channels, Tg, c.gin_channels);
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-template <typename AT>
-int voc_run(gsv_voc* v, int what, const float* z, const float* mask, const float* ge, int T, int Tg, float* out,
-            void* ws, size_t ws_bytes, hipStream_t st) {
-    if (!v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
-    if (T < 1 || (Tg != 1 && Tg != T)) return fail(GSV_ERR_ARG, "bad T/Tg");
-    VocWs w = voc_layout<AT>(v, T, Tg, (char*)ws);
-    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "vocoder workspace %zu < %zu", ws_bytes, w.bytes);
-    if (int rc = voc_prepare<AT>(v, w, z, ge, T, Tg, st)) return rc;
-    if (what & 1)
-        if (int rc = voc_flow_impl<AT>(v, w, mask, T, Tg, st)) return rc;
-    if (what == 1) {  // flow only: back to channels-first fp32
-        hipLaunchKernelGGL((cl_to_cf_kernel<AT>), dim3(cdiv(T, 32), cdiv(v->cfg.inter_channels, 32)), dim3(256), 0, st,
-                           (const AT*)w.zin, out, v->cfg.inter_channels, T, v->cfg.inter_channels);
-        HIPCHK(hipGetLastError());
-        return GSV_OK;
-    }
-    return voc_dec_impl<AT>(v, w, T, Tg, out, st);
-}
-
-// ---- enc_p (bf16): weights -------------------------------------------------------------------
-int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
-    EncP& E = v->enc;
-    auto get = [&](const std::string& n, int64_t numel, const float** out) -> int {
-        auto it = v->staged.find(n);
-        if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing tensor '%s'", n.c_str());
-        if (numel > 0 && it->second.second != numel) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", n.c_str(), (long long)it->second.second, (long long)numel);
-        *out = it->second.first;
-        return GSV_OK;
-    };
-    auto keep = [&](const std::string& n, int64_t numel, float** out) -> int {   // private fp32 copy
-        const float* s;
-        if (int rc = get(n, numel, &s)) return rc;
-        float* d;
-        HIPCHK(hipMalloc(&d, sizeof(float) * (size_t)v->staged[n].second));
-        HIPCHK(hipMemcpyAsync(d, s, sizeof(float) * (size_t)v->staged[n].second, hipMemcpyDeviceToDevice, st));
-        E.owned.push_back(d);
-        *out = d;
-        return GSV_OK;
-    };
-    auto conv = [&](PackedConv& pc, const std::string& base, int cout, int cin, int k) -> int {
-        const float *w, *b;
-        if (int rc = get(base + ".weight", (int64_t)cout * cin * k, &w)) return rc;
-        if (int rc = get(base + ".bias", cout, &b)) return rc;
-        return pack_conv<bf16_t>(pc, w, cout, cin, k, (int64_t)cin * k, k, 1, 1, (k - 1) / 2, 0, b, 1.f, st);
-    };
-    // several 1x1 convs of one input stacked along the output channels (q|k|v)
-    auto stacked = [&](PackedConv& pc, const std::vector<std::string>& bases, int cout_each, int cin) -> int {
-        const int n = (int)bases.size();
-        float *w, *b;
-        HIPCHK(hipMalloc(&w, sizeof(float) * (size_t)n * cout_each * cin));
-        HIPCHK(hipMalloc(&b, sizeof(float) * (size_t)n * cout_each));
-        temps.push_back(w); temps.push_back(b);
-        for (int i = 0; i < n; ++i) {
-            const float *ws, *bs;
-            if (int rc = get(bases[i] + ".weight", (int64_t)cout_each * cin, &ws)) return rc;
-            if (int rc = get(bases[i] + ".bias", cout_each, &bs)) return rc;
-            HIPCHK(hipMemcpyAsync(w + (size_t)i * cout_each * cin, ws, sizeof(float) * (size_t)cout_each * cin, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(b + (size_t)i * cout_each, bs, sizeof(float) * cout_each, hipMemcpyDeviceToDevice, st));
-        }
-        return pack_conv<bf16_t>(pc, w, n * cout_each, cin, 1, cin, 1, 0, 1, 0, 0, b, 1.f, st);
-    };
-    const int Hc = v->cfg.hidden_channels;                   // 192
-    const int Fc = 4 * Hc;                                   // filter channels (768)
-    auto encoder = [&](std::vector<EncLayer>& Ls, const std::string& pre, int n_layers) -> int {
-        Ls.resize(n_layers);
-        for (int i = 0; i < n_layers; ++i) {
-            EncLayer& L = Ls[i];
-            const std::string a = pre + "attn_layers." + std::to_string(i) + ".";
-            if (int rc = stacked(L.qkv, {a + "conv_q", a + "conv_k", a + "conv_v"}, Hc, Hc)) return rc;
-            if (int rc = conv(L.o, a + "conv_o", Hc, Hc, 1)) return rc;
-            if (int rc = keep(a + "emb_rel_k", 0, &L.relk)) return rc;
-            if (int rc = keep(a + "emb_rel_v", 0, &L.relv)) return rc;
-            if (v->staged[a + "emb_rel_k"].second != 9 * (Hc / 2)) return fail(GSV_ERR_ARG, "enc_p: expected window 4, 2 heads");
-            const std::string s = std::to_string(i);
-            if (int rc = keep(pre + "norm_layers_1." + s + ".gamma", Hc, &L.g1)) return rc;
-            if (int rc = keep(pre + "norm_layers_1." + s + ".beta", Hc, &L.b1)) return rc;
-            if (int rc = keep(pre + "norm_layers_2." + s + ".gamma", Hc, &L.g2)) return rc;
-            if (int rc = keep(pre + "norm_layers_2." + s + ".beta", Hc, &L.b2)) return rc;
-            auto it = v->staged.find(pre + "ffn_layers." + s + ".conv_1.weight");
-            if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing enc_p ffn tensors");
-            const int k = (int)(it->second.second / ((int64_t)Fc * Hc));
-            if (k != 3) return fail(GSV_ERR_ARG, "enc_p: FFN kernel size %d (expected 3)", k);
-            if (int rc = conv(L.c1, pre + "ffn_layers." + s + ".conv_1", Fc, Hc, k)) return rc;
-            if (int rc = conv(L.c2, pre + "ffn_layers." + s + ".conv_2", Hc, Fc, k)) return rc;
-        }
-        return GSV_OK;
-    };
-    int nl = 0;
-    while (v->staged.count("enc_p.encoder_text.attn_layers." + std::to_string(nl) + ".conv_q.weight")) ++nl;
-    if (nl < 2 || nl % 2) return fail(GSV_ERR_ARG, "enc_p: %d text encoder layers", nl);
-    if (int rc = conv(E.ssl_proj, "enc_p.ssl_proj", Hc, 768, 1)) return rc;
-    if (int rc = encoder(E.ssl, "enc_p.encoder_ssl.", nl / 2)) return rc;
-    if (int rc = encoder(E.text, "enc_p.encoder_text.", nl)) return rc;
-    if (int rc = encoder(E.enc2, "enc_p.encoder2.", nl / 2)) return rc;
-    if (int rc = keep("enc_p.text_embedding.weight", 0, &E.text_emb)) return rc;
-    E.n_text = (int)(v->staged["enc_p.text_embedding.weight"].second / Hc);
-    if (int rc = keep("quantizer.vq.layers.0._codebook.embed", 0, &E.codebook)) return rc;
-    E.n_code = (int)(v->staged["quantizer.vq.layers.0._codebook.embed"].second / 768);
-    const std::string m = "enc_p.mrte.";
-    if (int rc = conv(E.c_pre, m + "c_pre", 512, Hc, 1)) return rc;
-    if (int rc = conv(E.text_pre, m + "text_pre", 512, Hc, 1)) return rc;
-    if (int rc = conv(E.c_post, m + "c_post", Hc, 512, 1)) return rc;
-    if (int rc = conv(E.xq, m + "cross_attention.conv_q", 512, 512, 1)) return rc;
-    if (int rc = stacked(E.xkv, {m + "cross_attention.conv_k", m + "cross_attention.conv_v"}, 512, 512)) return rc;
-    if (int rc = conv(E.xo, m + "cross_attention.conv_o", 512, 512, 1)) return rc;
-    if (int rc = conv(E.proj, "enc_p.proj", 2 * v->cfg.inter_channels, Hc, 1)) return rc;
-    E.ready = true;
-    return GSV_OK;
-}
-
-void encp_free(gsv_voc* v) {
-    EncP& E = v->enc;
-    for (PackedConv* p : {&E.ssl_proj, &E.c_pre, &E.text_pre, &E.c_post, &E.proj, &E.xq, &E.xkv, &E.xo}) free_conv(*p);
-    for (auto* Ls : {&E.ssl, &E.text, &E.enc2})
-        for (EncLayer& L : *Ls) { free_conv(L.qkv); free_conv(L.o); free_conv(L.c1); free_conv(L.c2); }
-    for (float* p : E.owned) (void)hipFree(p);
-    E.owned.clear();
-    E.ready = false;
-}
-
-// ---- enc_p (bf16): run ------------------------------------------------------------------------
-struct EncWs {
-    bf16_t *y768, *y, *t, *qkv, *att, *tmp, *ffn, *ssl512, *text512, *xq, *xkv, *xatt, *xo, *xsum;
-    float *stats, *part;
-    size_t bytes;
-};
-EncWs encp_layout(const gsv_voc* v, int T, int P, char* base) {
-    size_t off = 0;
-    auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
-    const int Hc = v->cfg.hidden_channels, R = std::max(T, P);
-    EncWs w;
-    w.y768 = (bf16_t*)take(2 * (size_t)T * 768);
-    w.y = (bf16_t*)take(2 * (size_t)T * Hc);
-    w.t = (bf16_t*)take(2 * (size_t)P * Hc);
-    w.qkv = (bf16_t*)take(2 * (size_t)R * 3 * Hc);
-    w.att = (bf16_t*)take(2 * (size_t)R * Hc);
-    w.tmp = (bf16_t*)take(2 * (size_t)R * Hc);
-    w.ffn = (bf16_t*)take(2 * (size_t)R * 4 * Hc);
-    w.ssl512 = (bf16_t*)take(2 * (size_t)T * 512);
-    w.text512 = (bf16_t*)take(2 * (size_t)P * 512);
-    w.xq = (bf16_t*)take(2 * (size_t)T * 512);
-    w.xkv = (bf16_t*)take(2 * (size_t)P * 1024);
-    w.xatt = (bf16_t*)take(2 * (size_t)T * 512);
-    w.xo = (bf16_t*)take(2 * (size_t)T * 512);
-    w.xsum = (bf16_t*)take(2 * (size_t)T * 512);
-    w.stats = (float*)take(4 * (size_t)T * 2 * v->cfg.inter_channels);
-    w.part = (float*)take(4 * (size_t)3 * R * Hc);
-    w.bytes = off;
-    return w;
-}
-
-// dense layer of enc_p on the latency-shaped rowgemm (bf16 in; bf16 or raw fp32 split partials out)
-int enc_gemm(const PackedConv& pc, const bf16_t* X, int ldx, int rows, bool with_bias, int relu, void* Y, int ldy, bool out_f32,
-             int nsplit, size_t split_stride, hipStream_t st) {
-    RowGemmArgs ra;
-    ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = pc.ntaps; ra.pad = pc.pad;
-    ra.mtiles = pc.mtiles; ra.bias = with_bias ? pc.bias : nullptr; ra.relu = relu; ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
-    const int total = pc.ntaps * (pc.cin / 16);
-    if (pc.u != 0 || pc.dil != 1 || total % (4 * nsplit) != 0 || pc.cout % 32 != 0) return fail(GSV_ERR_ARG, "enc_p: layer shape does not fit rowgemm");
-    const int kpw = total / (4 * nsplit);
-    const dim3 grid(cdiv(rows, 32), pc.mtiles, nsplit);
-#define GSV_ENC_GEMM(K)                                                                                            \
-    if (kpw == K) {                                                                                                  \
-        if (out_f32) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, K>), grid, dim3(256), 0, st, ra);              \
-        else hipLaunchKernelGGL((rowgemm_kernel<bf16_t, bf16_t, K>), grid, dim3(256), 0, st, ra);                    \
-        return GSV_OK;                                                                                               \
-    }
-    GSV_ENC_GEMM(3) GSV_ENC_GEMM(8) GSV_ENC_GEMM(9) GSV_ENC_GEMM(12)
-#undef GSV_ENC_GEMM
-    return fail(GSV_ERR_ARG, "enc_p: no rowgemm instantiation for %d k-steps per wave", kpw);
-}
-
-int encp_encoder(gsv_voc* v, std::vector<EncLayer>& Ls, bf16_t* x, int R, EncWs& w, hipStream_t st) {
-    const int Hc = v->cfg.hidden_channels;
-    float* part = w.part;                                    // raw fp32 tiles: [3][R][Hc]
-    const size_t ps = (size_t)R * Hc;
-    for (EncLayer& L : Ls) {
-        if (int rc = enc_gemm(L.qkv, x, Hc, R, true, 0, w.qkv, 3 * Hc, false, 1, 0, st)) return rc;
-        EncAttnArgs a;
-        a.Q = w.qkv; a.ldq = 3 * Hc; a.K = w.qkv; a.ldk = 3 * Hc; a.V = w.qkv; a.ldv = 3 * Hc;
-        a.qoff = 0; a.koff = Hc; a.voff = 2 * Hc; a.O = w.att; a.ldo = Hc; a.Tq = R; a.Tk = R; a.H = 2;
-        a.scale = 1.0f / sqrtf((float)(Hc / 2)); a.relk = L.relk; a.relv = L.relv; a.window = 4; a.slice = nullptr; a.P = nullptr;
-        hipLaunchKernelGGL(encp_attn_kernel<96>, dim3(2, cdiv(R, 32)), dim3(256), encp_attn_lds_bytes<96>(), st, a);
-        if (int rc = enc_gemm(L.o, w.att, Hc, R, false, 0, part, Hc, true, 1, 0, st)) return rc;
-        hipLaunchKernelGGL(encp_ln_sum_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const float*)part, 1, (size_t)0, (const float*)L.o.bias,
-                           (const bf16_t*)x, (const float*)L.g1, (const float*)L.b1, x, R, Hc);
-        if (int rc = enc_gemm(L.c1, x, Hc, R, true, 1, w.ffn, 4 * Hc, false, 1, 0, st)) return rc;
-        if (int rc = enc_gemm(L.c2, w.ffn, 4 * Hc, R, false, 0, part, Hc, true, 3, ps, st)) return rc;
-        hipLaunchKernelGGL(encp_ln_sum_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, (const float*)part, 3, ps, (const float*)L.c2.bias,
-                           (const bf16_t*)x, (const float*)L.g2, (const float*)L.b2, x, R, Hc);
-    }
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg,
-             const int64_t* slice, float* m_p, float* logs_p, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
-    EncP& E = v->enc;
-    const int Hc = v->cfg.hidden_channels, C = v->cfg.inter_channels, T = 2 * n_codes;
-    if (Hc != 192) return fail(GSV_ERR_ARG, "enc_p: hidden_channels %d (the attention kernel is built for 2 heads of 96)", Hc);
-    EncWs w = encp_layout(v, T, P, (char*)ws);
-    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "enc_p workspace %zu < %zu", ws_bytes, w.bytes);
-    HIPCHK(hipFuncSetAttribute((const void*)encp_attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, encp_attn_lds_bytes<96>()));
-    HIPCHK(hipFuncSetAttribute((const void*)encp_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, encp_attn_lds_bytes<128>()));
-    hipLaunchKernelGGL(encp_gather_kernel, dim3(T), dim3(128), 0, st, codes, n_codes, E.n_code, (const float*)E.codebook, 768, 2, w.y768);
-    hipLaunchKernelGGL(encp_gather_kernel, dim3(P), dim3(96), 0, st, text, P, E.n_text, (const float*)E.text_emb, Hc, 1, w.t);
-    if (int rc = enc_gemm(E.ssl_proj, w.y768, 768, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
-    if (int rc = encp_encoder(v, E.ssl, w.y, T, w, st)) return rc;
-    if (int rc = encp_encoder(v, E.text, w.t, P, w, st)) return rc;
-    // MRTE (mrte_model.py:20-38)
-    if (int rc = enc_gemm(E.c_pre, w.y, Hc, T, true, 0, w.ssl512, 512, false, 1, 0, st)) return rc;
-    if (int rc = enc_gemm(E.text_pre, w.t, Hc, P, true, 0, w.text512, 512, false, 1, 0, st)) return rc;
-    if (int rc = enc_gemm(E.xq, w.ssl512, 512, T, true, 0, w.xq, 512, false, 1, 0, st)) return rc;
-    if (int rc = enc_gemm(E.xkv, w.text512, 512, P, true, 0, w.xkv, 1024, false, 1, 0, st)) return rc;
-    EncAttnArgs a;
-    a.Q = w.xq; a.ldq = 512; a.K = w.xkv; a.ldk = 1024; a.V = w.xkv; a.ldv = 1024; a.qoff = 0; a.koff = 0; a.voff = 512;
-    a.O = w.xatt; a.ldo = 512; a.Tq = T; a.Tk = P; a.H = 4; a.scale = 1.0f / sqrtf(128.0f); a.relk = nullptr; a.relv = nullptr;
-    a.window = 0; a.slice = slice; a.P = attn;
-    hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 32)), dim3(256), encp_attn_lds_bytes<128>(), st, a);
-    if (int rc = enc_gemm(E.xo, w.xatt, 512, T, true, 0, w.xo, 512, false, 1, 0, st)) return rc;
-    hipLaunchKernelGGL(encp_add3_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const bf16_t*)w.xo, (const bf16_t*)w.ssl512, ge512,
-                       Tg == 1 ? 0 : 512, w.xsum, T, 512);
-    if (int rc = enc_gemm(E.c_post, w.xsum, 512, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
-    if (int rc = encp_encoder(v, E.enc2, w.y, T, w, st)) return rc;
-    if (int rc = enc_gemm(E.proj, w.y, Hc, T, true, 0, w.stats, 2 * C, true, 1, 0, st)) return rc;
-    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats, m_p, C, T, 2 * C);
-    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats + C, logs_p, C, T, 2 * C);
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
-template <typename CT>
-int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
-    const gsv_voc_config& c = v->cfg;
-    const int H = c.hidden_channels, C = c.inter_channels, half = C / 2, gin = c.gin_channels;
-    auto get = [&](const std::string& n, int64_t numel, const float** out) -> int {
-        auto it = v->staged.find(n);
-        if (it == v->staged.end()) return fail(GSV_ERR_STATE, "missing tensor '%s'", n.c_str());
-        if (it->second.second != numel) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", n.c_str(), (long long)it->second.second, (long long)numel);
-        *out = it->second.first;
-        return GSV_OK;
-    };
-    std::vector<float*> temps;
-    auto folded = [&](const std::string& base, int rows, int row_elems, float sign, const float** out) -> int {
-        const float *g, *vv;
-        if (int rc = get(base + ".weight_g", rows, &g)) return rc;
-        if (int rc = get(base + ".weight_v", (int64_t)rows * row_elems, &vv)) return rc;
-        float* wbuf;
-        HIPCHK(hipMalloc(&wbuf, sizeof(float) * (size_t)rows * row_elems));
-        temps.push_back(wbuf);
-        hipLaunchKernelGGL(weight_norm_fold_kernel, dim3(rows), dim3(256), 0, st, g, vv, wbuf, row_elems, sign);
-        *out = wbuf;
-        return GSV_OK;
-    };
-    int rc = GSV_OK;
-    v->flows.resize(c.n_flows);
-    // the fused coupling-layer kernel (flowfuse.h): bf16, hidden 192, 96 + 96 channels, even flow count
-    const bool fuse = sizeof(CT) == 2 && H == FF_H && half == FF_HALF && c.n_flows % 2 == 0 && c.n_flows > 0;
-    float* cond_w_all = nullptr;
-    float* cond_b_all = nullptr;
-    float* skip_b = nullptr;   // the four skip biases of the layer being packed (stream-ordered reuse)
-    if (fuse) {
-        HIPCHK(hipMalloc(&cond_w_all, sizeof(float) * (size_t)c.n_flows * 8 * H * gin));
-        HIPCHK(hipMalloc(&cond_b_all, sizeof(float) * (size_t)c.n_flows * 8 * H));
-        temps.push_back(cond_w_all); temps.push_back(cond_b_all);
-        HIPCHK(hipMalloc(&skip_b, sizeof(float) * 4 * FF_H));
-        temps.push_back(skip_b);
-    }
-    // pack one conv of a fused layer into its weight arena at fragment offset `frag`
-    auto ff_pack = [&](VocFlow& F, int frag, const float* src, int cout, int cin, int k, int64_t sm, int64_t sc, int64_t sk, int pad) {
-        const int mt = cdiv(cout, 32);
-        const size_t elems = (size_t)k * mt * (cin / 16) * 64 * 8;
-        hipLaunchKernelGGL((tapgemm_pack_kernel<bf16_t>), dim3((unsigned)std::min<size_t>(2048, (elems + 255) / 256)), dim3(256), 0, st,
-                           src, (bf16_t*)F.ff_w + (size_t)frag * 512, cout, cin, k, sm, sc, sk, 1, k, 0, pad, mt);
-    };
-    auto ff_bias = [&](VocFlow& F, int off, const float* src, int n, float scale, bool reverse) {
-        hipLaunchKernelGGL(scale_copy_rev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, F.ff_b + off, n, scale, reverse ? 1 : 0);
-    };
-    for (int f = 0; f < c.n_flows && !rc; ++f) {
-        VocFlow& F = v->flows[f];
-        const std::string p = "flow.flows." + std::to_string(2 * f) + ".";
-        const float *w, *b;
-        F.parity = (c.n_flows - f) % 2;
-        if (fuse) {
-            if (!F.ff_w) HIPCHK(hipMalloc(&F.ff_w, (size_t)FF_W_TOTAL * 1024));
-            if (!F.ff_b) HIPCHK(hipMalloc(&F.ff_b, sizeof(float) * FF_T_TOTAL));
-        }
-        if ((rc = get(p + "pre.weight", (int64_t)H * half, &w)) || (rc = get(p + "pre.bias", H, &b))) break;
-        if ((rc = pack_conv<CT>(F.pre, w, H, half, 1, half, 1, 0, 1, 0, 0, b, 1.f, st))) break;
-        if (fuse) {   // parity 1: the conv-input half is stored channel-reversed
-            ff_pack(F, FF_W_PRE, F.parity ? w + (half - 1) : w, H, half, 1, half, F.parity ? -1 : 1, 0, 0);
-            ff_bias(F, FF_T_PRE, b, H, 1.f, false);
-        }
-        if ((rc = folded(p + "enc.cond_layer", 8 * H, gin, 1.f, &w)) || (rc = get(p + "enc.cond_layer.bias", 8 * H, &b))) break;
-        if ((rc = pack_conv<CT>(F.cond, w, 8 * H, gin, 1, gin, 1, 0, 1, 0, 0, b, 1.f, st))) break;
-        if (fuse) {
-            HIPCHK(hipMemcpyAsync(cond_w_all + (size_t)f * 8 * H * gin, w, sizeof(float) * (size_t)8 * H * gin, hipMemcpyDeviceToDevice, st));
-            HIPCHK(hipMemcpyAsync(cond_b_all + (size_t)f * 8 * H, b, sizeof(float) * 8 * H, hipMemcpyDeviceToDevice, st));
-        }
-        for (int l = 0; l < 4 && !rc; ++l) {
-            const std::string il = p + "enc.in_layers." + std::to_string(l), rl = p + "enc.res_skip_layers." + std::to_string(l);
-            if ((rc = folded(il, 2 * H, H * 5, 1.f, &w)) || (rc = get(il + ".bias", 2 * H, &b))) break;
-            if ((rc = pack_conv<CT>(F.in_l[l], w, 2 * H, H, 5, (int64_t)H * 5, 5, 1, 1, 2, 0, b, 1.f, st))) break;
-            if (fuse) {
-                ff_pack(F, FF_W_IN + l * FF_W_IN_L, w, 2 * H, H, 5, (int64_t)H * 5, 5, 1, 2);
-                ff_bias(F, FF_T_IN + l * 384, b, 2 * H, 1.f, false);
-            }
-            const int R = l < 3 ? 2 * H : H;
-            if ((rc = folded(rl, R, H, 1.f, &w)) || (rc = get(rl + ".bias", R, &b))) break;
-            if (l < 3) {
-                if ((rc = pack_conv<CT>(F.rs_res[l], w, H, H, 1, H, 1, 0, 1, 0, 0, b, 1.f, st))) break;
-                if ((rc = pack_conv<CT>(F.rs_skip[l], w + (size_t)H * H, H, H, 1, H, 1, 0, 1, 0, 0, b + H, 1.f, st))) break;
-            } else {
-                if ((rc = pack_conv<CT>(F.rs_skip[l], w, H, H, 1, H, 1, 0, 1, 0, 0, b, 1.f, st))) break;
-            }
-            if (fuse) {
-                if (l < 3) {
-                    ff_pack(F, FF_W_RES + l * 6 * FF_KSH, w, H, H, 1, H, 1, 0, 0);
-                    ff_bias(F, FF_T_RES + l * 192, b, H, 1.f, false);
-                }
-                ff_pack(F, FF_W_SKIP + l * 6 * FF_KSH, l < 3 ? w + (size_t)H * H : w, H, H, 1, H, 1, 0, 0);
-                hipLaunchKernelGGL(scale_copy_rev_kernel, dim3(1), dim3(256), 0, st, l < 3 ? b + H : b, skip_b + l * 192, H, 1.f, 0);
-                if (l == 3) hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(256), 0, st, (const float*)skip_b, F.ff_b + FF_T_SKIP, H);
-            }
-        }
-        if (rc) break;
-        if ((rc = get(p + "post.weight", (int64_t)half * H, &w)) || (rc = get(p + "post.bias", half, &b))) break;
-        float* neg;
-        HIPCHK(hipMalloc(&neg, sizeof(float) * half * H));
-        temps.push_back(neg);
-        hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(half * H, 256)), dim3(256), 0, st, w, neg, (size_t)half * H, -1.0f);
-        if ((rc = pack_conv<CT>(F.post, neg, half, H, 1, H, 1, 0, 1, 0, 0, b, -1.f, st))) break;
-        if (fuse) {   // parity 1: the updated half is stored channel-reversed -> reversed output rows and bias
-            ff_pack(F, FF_W_POST, F.parity ? neg + (size_t)(half - 1) * H : neg, half, H, 1, F.parity ? -(int64_t)H : (int64_t)H, 1, 0, 0);
-            ff_bias(F, FF_T_POST, b, half, -1.f, F.parity != 0);
-        }
-    }
-    if (!rc && fuse) {
-        free_conv(v->cond_all);
-        rc = pack_conv<CT>(v->cond_all, cond_w_all, c.n_flows * 8 * H, gin, 1, gin, 1, 0, 1, 0, 0, cond_b_all, 1.f, st);
-    }
-    v->fused_flow = fuse && !rc;
-    const int C0 = c.upsample_initial_channel;
-    const float *w = nullptr, *b = nullptr;
-    if (!rc) rc = get("dec.conv_pre.weight", (int64_t)C0 * C * 7, &w);
-    if (!rc) rc = get("dec.conv_pre.bias", C0, &b);
-    if (!rc) rc = pack_conv<CT>(v->conv_pre, w, C0, C, 7, (int64_t)C * 7, 7, 1, 1, 3, 0, b, 1.f, st);
-    if (!rc) rc = get("dec.cond.weight", (int64_t)C0 * gin, &w);
-    if (!rc) rc = get("dec.cond.bias", C0, &b);
-    if (!rc) rc = pack_conv<CT>(v->cond, w, C0, gin, 1, gin, 1, 0, 1, 0, 0, b, 1.f, st);
-    v->stages.resize(c.n_upsample);
-    int ch = C0, tm = 1;
-    v->max_stage_elems_per_frame = ld_of(C0);
-    constexpr int KS = MfmaK<CT>::KS;
-    for (int i = 0; i < c.n_upsample && !rc; ++i) {
-        VocStage& sg = v->stages[i];
-        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i], co = ch / 2;
-        sg.cin = ch; sg.cout = co; sg.u = u;
-        tm *= u;
-        v->max_stage_elems_per_frame = std::max(v->max_stage_elems_per_frame, ld_of(co) * tm);
-        const std::string un = "dec.ups." + std::to_string(i);
-        if ((rc = get(un + ".weight", (int64_t)ch * co * k, &w)) || (rc = get(un + ".bias", co, &b))) break;
-        // ConvTranspose1d weight [Cin][Cout][k]: element (m=co, c=ci, kk) at ci*(Cout*k) + co*k + kk
-        const int cin_pad = (ch + KS - 1) / KS * KS;
-        if (cin_pad != ch) { rc = fail(GSV_ERR_ARG, "stage %d: %d input channels not a multiple of %d", i, ch, KS); break; }
-        if ((rc = pack_conv<CT>(sg.up, w, co, ch, k, k, (int64_t)co * k, 1, 1, (k - u) / 2, u, b, 1.f, st))) break;
-        sg.rb.resize(c.n_resblock_kernels);
-        const int cpad = (co + KS - 1) / KS * KS;  // contraction over zero-padded channels when co % KS != 0
-        for (int j = 0; j < c.n_resblock_kernels && !rc; ++j) {
-            VocResBlock& rb = sg.rb[j];
-            rb.k = c.resblock_kernel_sizes[j];
-            const std::string rn = "dec.resblocks." + std::to_string(i * c.n_resblock_kernels + j);
-            for (int d = 0; d < 3 && !rc; ++d) {
-                for (int which = 0; which < 2 && !rc; ++which) {
-                    const std::string cn = rn + (which ? ".convs2." : ".convs1.") + std::to_string(d);
-                    if ((rc = get(cn + ".weight", (int64_t)co * co * rb.k, &w)) || (rc = get(cn + ".bias", co, &b))) break;
-                    const float* wsrc = w;
-                    if (cpad != co) {  // re-lay as [co][cpad][k] with zero channels
-                        float* padded;
-                        HIPCHK(hipMalloc(&padded, sizeof(float) * (size_t)co * cpad * rb.k));
-                        temps.push_back(padded);
-                        HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * (size_t)co * cpad * rb.k, st));
-                        HIPCHK(hipMemcpy2DAsync(padded, sizeof(float) * cpad * rb.k, w, sizeof(float) * co * rb.k,
-                                                sizeof(float) * co * rb.k, co, hipMemcpyDeviceToDevice, st));
-                        wsrc = padded;
-                    }
-                    const int dil = which ? 1 : c.resblock_dilations[d];
-                    PackedConv& pc = which ? rb.c2[d] : rb.c1[d];
-                    rc = pack_conv<CT>(pc, wsrc, co, cpad, rb.k, (int64_t)cpad * rb.k, rb.k, 1, dil, dil * (rb.k - 1) / 2, 0, b, 1.f, st);
-                }
-            }
-        }
-        ch = co;
-    }
-    v->total_up = tm;
-    if (!rc) rc = get("dec.conv_post.weight", (int64_t)ch * 7, &w);
-    if (!rc) {
-        const int cpad = (ch + KS - 1) / KS * KS;
-        const float* wsrc = w;
-        if (cpad != ch) {
-            float* padded;
-            HIPCHK(hipMalloc(&padded, sizeof(float) * (size_t)cpad * 7));
-            temps.push_back(padded);
-            HIPCHK(hipMemsetAsync(padded, 0, sizeof(float) * (size_t)cpad * 7, st));
-            HIPCHK(hipMemcpyAsync(padded, w, sizeof(float) * (size_t)ch * 7, hipMemcpyDeviceToDevice, st));
-            wsrc = padded;
-        }
-        rc = pack_conv<CT>(v->conv_post, wsrc, 1, cpad, 7, (int64_t)cpad * 7, 7, 1, 1, 3, 0, nullptr, 1.f, st);
-        if (!rc) {   // plain fp32 copy [ch][7] for the one-output-channel tail kernel
-            if (v->post_w) (void)hipFree(v->post_w);
-            HIPCHK(hipMalloc(&v->post_w, sizeof(float) * (size_t)ch * 7));
-            HIPCHK(hipMemcpyAsync(v->post_w, w, sizeof(float) * (size_t)ch * 7, hipMemcpyDeviceToDevice, st));
-            v->post_c = ch;
-        }
-    }
-    if (!rc && sizeof(CT) == 2 && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize(v, temps, st);
-    (void)hipStreamSynchronize(st);
-    for (float* t : temps) (void)hipFree(t);
-    if (rc) return rc;
-    for (auto& kv : v->staged) (void)hipFree(kv.second.first);
-    v->staged.clear();
-    v->finalized = true;
-    return GSV_OK;
-}
-
-void voc_free(gsv_voc* v) {
-    for (auto& kv : v->staged) (void)hipFree(kv.second.first);
-    v->staged.clear();
-    for (VocFlow& F : v->flows) {
-        free_conv(F.pre); free_conv(F.cond); free_conv(F.post);
-        if (F.ff_w) (void)hipFree(F.ff_w);
-        if (F.ff_b) (void)hipFree(F.ff_b);
-        F.ff_w = nullptr; F.ff_b = nullptr;
-        for (auto& p : F.in_l) free_conv(p);
-        for (auto& p : F.rs_res) free_conv(p);
-        for (auto& p : F.rs_skip) free_conv(p);
-    }
-    free_conv(v->conv_pre); free_conv(v->cond); free_conv(v->conv_post); free_conv(v->cond_all);
-    encp_free(v);
-    if (v->post_w) (void)hipFree(v->post_w);
-    v->post_w = nullptr;
-    for (VocStage& s : v->stages) {
-        free_conv(s.up);
-        for (VocResBlock& r : s.rb)
-            for (int d = 0; d < 3; ++d) { free_conv(r.c1[d]); free_conv(r.c2[d]); }
-    }
-}
-
-}  // namespace
-
-extern "C" {
-
-int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out) {
-    if (!cfg || !out) return fail(GSV_ERR_ARG, "null argument");
-    if (cfg->n_upsample < 1 || cfg->n_upsample > 8 || cfg->n_resblock_kernels < 1 || cfg->n_resblock_kernels > 4 ||
-        cfg->n_flows < 1 || cfg->inter_channels % 32 != 0 || cfg->hidden_channels % 16 != 0 || cfg->gin_channels % 16 != 0 ||
-        cfg->upsample_initial_channel % 32 != 0)
-        return fail(GSV_ERR_ARG, "unsupported vocoder configuration");
-    for (int i = 0; i < cfg->n_upsample; ++i)
-        if (cfg->upsample_rates[i] < 1 || cfg->upsample_rates[i] > 10 || (cfg->upsample_kernel_sizes[i] - cfg->upsample_rates[i]) % 2 != 0)
-            return fail(GSV_ERR_ARG, "unsupported upsample stage %d", i);
-    if (cfg->dtype != GSV_F32 && cfg->dtype != GSV_BF16) return fail(GSV_ERR_ARG, "bad dtype");
-    gsv_voc* v = new gsv_voc();
-    v->cfg = *cfg;
-    *out = v;
-    return GSV_OK;
-}
-
-int gsv_voc_destroy(gsv_voc* v) {
-    if (!v) return GSV_OK;
-    (void)hipDeviceSynchronize();
-    voc_free(v);
-    delete v;
-    return GSV_OK;
-}
-
-int gsv_voc_load_tensor(gsv_voc* v, const char* name, const float* data, int64_t numel, void* stream) {
-    if (!v || !name || !data || numel < 1) return fail(GSV_ERR_ARG, "null argument");
-    if (v->finalized) return fail(GSV_ERR_STATE, "vocoder already finalized");
-    std::string n(name);
-    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0 && n.compare(0, 6, "enc_p.") != 0 && n.compare(0, 10, "quantizer.") != 0)
-        return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow / dec / enc_p / quantizer", name);
-    auto it = v->staged.find(n);
-    if (it != v->staged.end()) { (void)hipFree(it->second.first); v->staged.erase(it); }
-    float* p;
-    HIPCHK(hipMalloc(&p, sizeof(float) * numel));
-    HIPCHK(hipMemcpyAsync(p, data, sizeof(float) * numel, hipMemcpyDeviceToDevice, S(stream)));
-    v->staged[n] = {p, numel};
-    return GSV_OK;
-}
-
-int gsv_voc_finalize(gsv_voc* v, void* stream) {
-    if (!v) return fail(GSV_ERR_ARG, "null handle");
-    if (v->finalized) return GSV_OK;
-    return v->cfg.dtype == GSV_BF16 ? voc_finalize_impl<bf16_t>(v, S(stream)) : voc_finalize_impl<float>(v, S(stream));
-}
-
-int gsv_voc_has_enc_p(gsv_voc* v) { return v && v->finalized && v->enc.ready ? 1 : 0; }
-
-size_t gsv_voc_enc_workspace(gsv_voc* v, int n_codes, int n_text) {
-    if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1) return 0;
-    return encp_layout(v, 2 * n_codes, n_text, nullptr).bytes;
-}
-
-int gsv_voc_enc_p(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge512, int Tg,
-                  const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
-                  void* stream) {
-    if (!v || !v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
-    if (!v->enc.ready) return fail(GSV_ERR_STATE, "enc_p tensors were not loaded (or the handle is not bf16)");
-    if (!codes || !text || !ge512 || !m_p || !logs_p || !workspace) return fail(GSV_ERR_ARG, "null argument");
-    if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != 2 * n_codes)) return fail(GSV_ERR_ARG, "enc_p: bad lengths");
-    return encp_run(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
-}
-
-size_t gsv_voc_workspace(gsv_voc* v, int T) {
-    if (!v || !v->finalized || T < 1) return 0;
-    return v->cfg.dtype == GSV_BF16 ? voc_layout<bf16_t>(v, T, T, nullptr).bytes : voc_layout<float>(v, T, T, nullptr).bytes;
-}
-
-int gsv_voc_flow_dec(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* out,
-                     void* workspace, size_t workspace_bytes, void* stream) {
-    if (!v || !z_p || !y_mask || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
-    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream))
-                                    : voc_run<float>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream));
-}
-
-int gsv_voc_flow(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* z_out,
-                 void* workspace, size_t workspace_bytes, void* stream) {
-    if (!v || !z_p || !y_mask || !ge || !z_out || !workspace) return fail(GSV_ERR_ARG, "null argument");
-    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 1, z_p, y_mask, ge, T, Tg, z_out, workspace, workspace_bytes, S(stream))
-                                    : voc_run<float>(v, 1, z_p, y_mask, ge, T, Tg, z_out, workspace, workspace_bytes, S(stream));
-}
-
-int gsv_voc_dec(gsv_voc* v, const float* z, const float* ge, int T, int Tg, float* out, void* workspace,
-                size_t workspace_bytes, void* stream) {
-    if (!v || !z || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
-    return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 2, z, nullptr, ge, T, Tg, out, workspace, workspace_bytes, S(stream))
-                                    : voc_run<float>(v, 2, z, nullptr, ge, T, Tg, out, workspace, workspace_bytes, S(stream));
 }
 
 }  // extern "C"

@@ -40,7 +40,7 @@ __device__ __forceinline__ float mish_f(float x) {
 }
 
 // 64 x 64 output tile per block, 4 waves (2 x 2) of 32 x 32, K staged through LDS in chunks of 32.
-__global__ __launch_bounds__(256) void fgemm_kernel(FGemmArgs a) {
+static __global__ __launch_bounds__(256) void fgemm_kernel(FGemmArgs a) {
     constexpr int KC = 32, LD = KC + 1;
     __shared__ float xs[64 * LD];
     __shared__ float ws[64 * LD];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void fgemm_kernel(FGemmArgs a) {
 }
 
 // out[c][r] = in[r][c] for r < rows, c < cols  (in row stride ldi, out row stride ldo)
-__global__ void transpose_kernel(const float* __restrict__ in, long long ldi, float* __restrict__ out, long long ldo, int rows,
+static __global__ void transpose_kernel(const float* __restrict__ in, long long ldi, float* __restrict__ out, long long ldo, int rows,
                                  int cols) {
     __shared__ float t[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -104,7 +104,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, long long ldi, fl
 }
 
 // conv weight [cout][cin][k] -> [cout][k][cin] (the row a k-tap "overlapping rows" GEMM contracts with)
-__global__ void conv_weight_kc_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int k) {
+static __global__ void conv_weight_kc_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int k) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)cout * cin * k) return;
     const int t = (int)(i % k), c = (int)((i / k) % cin), o = (int)(i / ((long long)k * cin));
@@ -112,7 +112,7 @@ __global__ void conv_weight_kc_kernel(const float* __restrict__ w, float* __rest
 }
 
 // Conv1dGLU tail, modules.py:248-254: y = x + a * sigmoid(b), conv output rows [a | b] of 2*C
-__global__ void glu_residual_kernel(const float* __restrict__ x, const float* __restrict__ conv, float* __restrict__ y, int rows,
+static __global__ void glu_residual_kernel(const float* __restrict__ x, const float* __restrict__ conv, float* __restrict__ y, int rows,
                                     int C) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)rows * C) return;
@@ -122,7 +122,7 @@ __global__ void glu_residual_kernel(const float* __restrict__ x, const float* __
 }
 
 // in-place softmax of each row of S [rows][cols]; one wave per row
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, int rows, int cols) {
+static __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, int rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
 
 // temporal_avg_pool (modules.py:409-419: every element divided by the length, then summed) + the v2Pro tail
 // ge = PReLU(pool + sv) (models.py:374-377).  One thread per channel; F [T][C].
-__global__ void pool_prelu_kernel(const float* __restrict__ F, int T, int C, const float* __restrict__ sv,
+static __global__ void pool_prelu_kernel(const float* __restrict__ F, int T, int C, const float* __restrict__ sv,
                                   const float* __restrict__ prelu_w, float* __restrict__ ge) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -161,7 +161,7 @@ __global__ void pool_prelu_kernel(const float* __restrict__ F, int T, int C, con
 
 // y[n] = bias[n] + sum_k x[k] * W[n][k]: one wave per output row, 16-byte loads (the 20480 -> gin sv_emb linear is
 // 84 MB of fp32 weights read once: HBM-bound, so every CU streams rows instead of 16 GEMM tiles doing it)
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
+static __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ y, int N, int K) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 }
 
 // reflect padding of `pad` samples on both sides (torch.stft center=True, pad_mode="reflect")
-__global__ void reflect_pad_kernel(const float* __restrict__ x, int n, int pad, float* __restrict__ out) {
+static __global__ void reflect_pad_kernel(const float* __restrict__ x, int n, int pad, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + 2 * pad) return;
     int s = i - pad;
@@ -192,7 +192,7 @@ __global__ void reflect_pad_kernel(const float* __restrict__ x, int n, int pad, 
 
 // windowed DFT rows: D[2j][k] = hann[k] cos(2 pi j k / n_fft), D[2j+1][k] = -hann[k] sin(2 pi j k / n_fft),
 // hann periodic (torch.hann_window default); evaluated in fp64, stored fp32
-__global__ void dft_rows_kernel(float* __restrict__ D, int n_fft, int bins) {
+static __global__ void dft_rows_kernel(float* __restrict__ D, int n_fft, int bins) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)bins * n_fft) return;
     const int k = (int)(i % n_fft), jbin = (int)(i / n_fft);
@@ -204,7 +204,7 @@ __global__ void dft_rows_kernel(float* __restrict__ D, int n_fft, int bins) {
 }
 
 // |re + i im| of Z [T][2*bins] -> spec [bins][T] (channels-first, what the reference's Spectrogram returns)
-__global__ void magnitude_t_kernel(const float* __restrict__ Z, int T, int bins, float* __restrict__ spec) {
+static __global__ void magnitude_t_kernel(const float* __restrict__ Z, int T, int bins, float* __restrict__ spec) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)T * bins) return;
     const int t = (int)(i % T), b = (int)(i / T);
@@ -213,7 +213,7 @@ __global__ void magnitude_t_kernel(const float* __restrict__ Z, int T, int bins,
 }
 
 // row sums of squares: out[r] = sum_c x[r][c]^2
-__global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x, long long ld, int rows, int cols,
+static __global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x, long long ld, int rows, int cols,
                                                     float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void rowsq_kernel(const float* __restrict__ x,
 }
 
 // core_vq.py:124-128: dist = -(|x|^2 - 2 x.e + |e|^2), code = first arg-max; margin = best - second best
-__global__ __launch_bounds__(256) void nearest_code_kernel(const float* __restrict__ dot, const float* __restrict__ x2,
+static __global__ __launch_bounds__(256) void nearest_code_kernel(const float* __restrict__ dot, const float* __restrict__ x2,
                                                            const float* __restrict__ e2, int rows, int bins,
                                                            long long* __restrict__ codes, float* __restrict__ margin) {
     const int lane = threadIdx.x & 63;

@@ -783,7 +783,7 @@ __device__ __forceinline__ void t2s_block_argmax(float& v, int& idx, float* sv, 
         if (sv[i] > v || (sv[i] == v && si[i] < idx)) { v = sv[i]; idx = si[i]; }
 }
 
-__global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
+static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x;
     // re-initialise the persistent step's counters from the kernel that precedes it in the chain

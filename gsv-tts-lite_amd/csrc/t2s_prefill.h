@@ -24,7 +24,7 @@ struct EmbedArgs {
     int lx_max, ly_max, l_max, n_phoneme, V;
 };
 
-__global__ __launch_bounds__(128) void t2s_embed_kernel(EmbedArgs a) {
+static __global__ __launch_bounds__(128) void t2s_embed_kernel(EmbedArgs a) {
     const int t = blockIdx.x, b = blockIdx.y, c = threadIdx.x * 4;
     const int lx = (int)a.x_lens[b], ly = (int)a.y_lens[b];
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(128) void t2s_embed_kernel(EmbedArgs a) {
 }
 
 // y[row] = LayerNorm(x[row]) over 512, one wave per row, two-pass like torch
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+static __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                       const float* __restrict__ bta, float* __restrict__ y, int rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -173,7 +173,7 @@ __device__ __forceinline__ int vpos(int kk) {
     return (blk >> 1) * 16 + 8 * hf + (kk & 3) + 4 * (blk & 1);
 }
 
-__global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnMfmaArgs a) {
+static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(PrefillAttnMfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
     const int h = blockIdx.x, r = blockIdx.y, qg = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 
 // y[row] = LayerNorm(sum_s P[s][row] + bias + res[row]) over 512 (post-LN block, t2s_model.py:55-63): the
 // consumer of rowgemm's raw (split) tiles; partials are added in split order, then bias, then the residual
-__global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
+static __global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
                                                           const float* __restrict__ bias, const float* res,
                                                           const float* __restrict__ g, const float* __restrict__ bta,
                                                           float* y, int rows, bf16_t* yb = nullptr) {   // y may alias res (row-wise in place)
@@ -547,7 +547,7 @@ struct PrefillFinishArgs {
     const int32_t* slots;  // state slot of every row, or null = slot0 + row
 };
 
-__global__ __launch_bounds__(128) void t2s_prefill_finish_kernel(PrefillFinishArgs a) {
+static __global__ __launch_bounds__(128) void t2s_prefill_finish_kernel(PrefillFinishArgs a) {
     const int r = blockIdx.x, c = threadIdx.x * 4;
     const int lx = (int)a.x_lens[r], L = lx + (int)a.y_lens[r];
     const int last = L > 0 ? L - 1 : 0;

@@ -181,7 +181,7 @@ template <> struct Stage16<bf16_t, bf16_t> {
 // OCC: blocks the kernel is compiled to co-reside per CU (register budget 512/OCC per lane).
 template <typename IT, typename CT, typename OT, int WM, int WN, int KCB = 256, bool SPLITK = false, int MB = 1,
           int OCC = 1, int PFT = 4>
-__global__ __launch_bounds__(256, OCC) void tapgemm_kernel(TapGemmArgs a) {
+static __global__ __launch_bounds__(256, OCC) void tapgemm_kernel(TapGemmArgs a) {
     constexpr int KS = MfmaK<CT>::KS;
     constexpr int E = KS / 2;                 // elements per lane per fragment
     constexpr int KC = KCB / (int)sizeof(CT); // channels staged per chunk

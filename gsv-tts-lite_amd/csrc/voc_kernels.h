@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const AT* __restrict__ x
 }
 
 // W = v * (g / ||v||) per output row (torch.nn.utils.weight_norm, dim=0); one block per row
-__global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
+static __global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                         float* __restrict__ w, int row_elems, float sign) {
     __shared__ float red[8];
     const int r = blockIdx.x;
@@ -129,19 +129,19 @@ __global__ void weight_norm_fold_kernel(const float* __restrict__ g, const float
     for (int i = threadIdx.x; i < row_elems; i += blockDim.x) w[(size_t)r * row_elems + i] = vr[i] * f;
 }
 
-__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float s) {
+static __global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n, float s) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = src[i] * s;
 }
 
 // dst[i] = s * src[i]  or, reversed, s * src[n-1-i]
-__global__ void scale_copy_rev_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float s, int reverse) {
+static __global__ void scale_copy_rev_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, float s, int reverse) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = s * src[reverse ? n - 1 - i : i];
 }
 
 // dst[c] = (t[c] + t[n+c]) + (t[2n+c] + t[3n+c])
-__global__ void sum4_kernel(const float* __restrict__ t, float* __restrict__ dst, int n) {
+static __global__ void sum4_kernel(const float* __restrict__ t, float* __restrict__ dst, int n) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n) dst[c] = (t[c] + t[n + c]) + (t[2 * n + c] + t[3 * n + c]);
 }
@@ -165,7 +165,7 @@ __global__ void pack_qkv_panel_kernel(const float* __restrict__ w, WT* __restric
         dst[i] = from_f32<WT>(w[(size_t)row * 512 + c]);
     }
 }
-__global__ void pack_qkv_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
+static __global__ void pack_qkv_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 16 * 96) {
         const int r = i % 96, h = i / 96;
