@@ -127,6 +127,8 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
             const int nt = cdiv(T, FF_VR), nx = std::min(8, cdiv(nt, 32));
             a.per_xcd = cdiv(nt, nx);
             a.dbg = nullptr;
+            static const bool ff_norot = getenv("GSV_FF_NOROT") != nullptr;
+            a.rot_k = ff_norot ? 0 : 1;
             static const bool ff_debug = getenv("GSV_FF_DEBUG") != nullptr;
             long long* dbg = nullptr;
             if (ff_debug) { HIPCHK(hipMalloc(&dbg, 32 * sizeof(long long))); HIPCHK(hipMemset(dbg, 0, 32 * sizeof(long long))); a.dbg = dbg; }
