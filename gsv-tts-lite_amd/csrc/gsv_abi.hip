@@ -3,7 +3,7 @@
 // No allocation happens inside a step; nothing here falls back to a CPU or library path.
 #include "abi_common.h"
 #include "t2s_decode.h"
-#include "t2s_megastep.h"
+#include "t2s_batch.h"
 
 namespace {
 thread_local std::string g_err;
@@ -26,14 +26,15 @@ struct T2SLayer {
     void *wqkv_p = nullptr, *wo_p = nullptr, *w1 = nullptr, *w2_p = nullptr;  // decode panels (WT)
     float *bqkv_p = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr,
           *ln2g = nullptr, *ln2b = nullptr;
-    PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill (tapgemm fragments)
+    PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill / batched step (MFMA fragments)
+    void *f8_qkv = nullptr, *f8_w1 = nullptr, *f8_w2 = nullptr;    // GSV_FP8: e4m3 fragments of the batched step (t2s_batch.h)
+    float *s_qkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;      // ... and their per-output-channel scales
     unsigned have = 0;
 };
 
 struct T2SBound {
     gsv_t2s_state st;
-    hipGraphExec_t graph = nullptr;       // 2-kernels-per-layer step
-    hipGraphExec_t graph_mega = nullptr;  // persistent (megastep) step
+    hipGraphExec_t graph = nullptr;       // the captured decode step
 };
 
 struct gsv_t2s {
@@ -44,6 +45,9 @@ struct gsv_t2s {
     PackedConv g_bert;
     unsigned have_io = 0;
     bool finalized = false;
+    bool fp8 = false;              // GSV_FP8: e4m3 QKV / FFN weights in the batched step (everything else as GSV_BF16)
+    int batched_min = 0;           // batch size from which the step is the batched chain
+    unsigned dbg_skip = 0;         // GSV_BSTEP_SKIP (tuning aid): bit i drops launch K(i+1) of the batched chain -- timing only
     std::map<int, T2SBound> bound;
     // scratch sized for the largest bound batch
     int scratch_b = 0;
@@ -51,11 +55,21 @@ struct gsv_t2s {
     TokPart* tokpart = nullptr;
     hipStream_t cap_stream = nullptr;
     unsigned long long* dbg = nullptr;
-    void* mega_layers = nullptr;   // device MegaLayer<WT>[n_layer]
-    unsigned* mega_cnt = nullptr;  // [scratch_b][2*n_layer] + 1 (err)
 };
 
 namespace {
+
+// e4m3 fragments + per-output-channel scales of one [cout][cin] linear (GSV_FP8 handles)
+int t2s_pack_fp8(const float* data, int cout, int cin, void** frag, float** scale, hipStream_t st) {
+    const int mtiles = cdiv(cout, 32);
+    if (!*scale) HIPCHK(hipMalloc(scale, sizeof(float) * mtiles * 32));
+    if (!*frag) HIPCHK(hipMalloc(frag, (size_t)mtiles * (cin / 32) * 64 * 16));
+    HIPCHK(hipMemsetAsync(*scale, 0, sizeof(float) * mtiles * 32, st));
+    hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(cdiv(cout, 4)), dim3(256), 0, st, data, cin, *scale, cout);
+    hipLaunchKernelGGL(fp8_pack_kernel, dim3(1024), dim3(256), 0, st, data, (const float*)*scale, (uint32_t*)*frag, cout, cin, mtiles);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
 
 template <typename WT>
 int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float* data, int64_t numel, hipStream_t st) {
@@ -76,6 +90,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         free_conv(L.g_qkv);
         if (int rc = pack_conv<WT>(L.g_qkv, data, 3 * kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         L.g_qkv.bias = keep;
+        if (h->fp8) if (int rc = t2s_pack_fp8(data, 3 * kD, kD, &L.f8_qkv, &L.s_qkv, st)) return rc;
         L.have |= 1u << 0;
     } else if (key == "qkv.bias") {
         if (int rc = want(3 * kD)) return rc;
@@ -99,6 +114,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         hipLaunchKernelGGL((convert_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w1, (size_t)kF * kD);
         free_conv(L.g_w1);
         if (int rc = pack_conv<WT>(L.g_w1, data, kF, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        if (h->fp8) if (int rc = t2s_pack_fp8(data, kF, kD, &L.f8_w1, &L.s_w1, st)) return rc;
         L.have |= 1u << 4;
     } else if (key == "mlp.0.bias") {
         if (int rc = copy_f32(&L.b1, kF, 1u << 5)) return rc;
@@ -108,6 +124,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p, kNJ, kFJ);
         free_conv(L.g_w2);
         if (int rc = pack_conv<WT>(L.g_w2, data, kD, kF, 1, kF, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        if (h->fp8) if (int rc = t2s_pack_fp8(data, kD, kF, &L.f8_w2, &L.s_w2, st)) return rc;
         L.have |= 1u << 6;
     } else if (key == "mlp.2.bias") {
         if (int rc = copy_f32(&L.b2, kD, 1u << 7)) return rc;
@@ -178,14 +195,10 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     HIPCHK(hipMalloc(&h->zpart, sizeof(float) * B * kNJ * kD));
     HIPCHK(hipMalloc(&h->tokpart, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
-    if (h->mega_cnt) (void)hipFree(h->mega_cnt);
-    HIPCHK(hipMalloc(&h->mega_cnt, sizeof(unsigned) * ((size_t)B * 2 * h->cfg.n_layer + 1)));
-    HIPCHK(hipMemset(h->mega_cnt, 0, sizeof(unsigned) * ((size_t)B * 2 * h->cfg.n_layer + 1)));
     h->scratch_b = B;
     // graphs captured against the old scratch pointers are stale
     for (auto& kv : h->bound)
-        { if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
-          if (kv.second.graph_mega) { (void)hipGraphExecDestroy(kv.second.graph_mega); kv.second.graph_mega = nullptr; } }
+        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
     return GSV_OK;
 }
 
@@ -253,83 +266,91 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
     a.pe = h->pe_audio; a.xcur = h->xcur; a.T = s.max_kv; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.n_pos = h->cfg.n_pos;
     a.advance = advance;
     a.logits = s.logits; a.fctl = s.fctl;
-    a.mega_cnt = h->mega_cnt; a.mega_n = 2 * h->cfg.n_layer;
-    if (a.mega_n > 256) a.mega_cnt = nullptr;
     hipLaunchKernelGGL(t2s_token_kernel, dim3(s.batch), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
 
-constexpr int kMegaMaxBatch = 4;  // 48 blocks per sequence, one block per CU, all co-resident
-
-template <typename WT>
-int t2s_mega_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st) {
-    const int NL = h->cfg.n_layer, B = s.batch;
-    if (B > kMegaMaxBatch) return fail(GSV_ERR_ARG, "megastep supports batch <= %d", kMegaMaxBatch);
-    if (2 * NL > 256) return fail(GSV_ERR_ARG, "megastep supports at most 128 layers");
-    // hand-off counters are zeroed by the token kernel that precedes this launch in every step
-    MegaArgs<WT> a;
-    a.layers = (const MegaLayer<WT>*)h->mega_layers; a.n_layer = NL; a.xin = xsrc; a.xbuf = h->xbuf; a.x1buf = h->x1buf;
-    a.ypart = h->ypart; a.zpart = h->zpart; a.kc = (WT*)s.k_cache; a.vc = (WT*)s.v_cache;
-    a.layer_elems = (size_t)B * kH * s.max_kv * kDh; a.T = s.max_kv; a.kv_len = s.kv_len; a.cnt = h->mega_cnt;
-    a.err = h->mega_cnt + (size_t)h->scratch_b * 2 * NL;
-    hipLaunchKernelGGL((t2s_megastep_kernel<WT>), dim3(kMegaRoles, B), dim3(kNT), 0, st, a);
-    HIPCHK(hipGetLastError());
-    return GSV_OK;
-}
-
 // batched step (bf16, B >= kBatchedMin): the prompt GEMM chain on B rows + one attention block per (head, sequence)
-constexpr int kBatchedMin = 36;   // measured: step 0.87 / 0.93 / 0.99 ms at B = 24 / 32 / 64 vs 0.82 / 0.91 / 1.65 for the per-sequence kernels
+// From this many sequences on, the bf16 / fp8 step is the batched chain (t2s_batch.h: weights streamed once per step)
+// instead of the per-sequence kernels (weights re-streamed per sequence from L2).  GSV_BATCHED_MIN overrides it at
+// handle creation (bench / tuning aid).
+constexpr int kBatchedMinDefault = 12;
+constexpr size_t kPrefillLdsMax = 160 * 1024;
 
 template <typename WT>
 int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
     const int B = s.batch, T = s.max_kv;
     float* qkv = h->ypart;                                   // [B][1536]
     float* attn = qkv + (size_t)B * 3 * kD;                  // [B][512]
-    float* ybuf = attn + (size_t)B * kD;                     // [B][512]
-    bf16_t* fb16 = (bf16_t*)(ybuf + (size_t)B * kD);         // [B][2048] bf16
-    float* part = h->zpart;                                  // [4][B][512]
-    float* x = h->xbuf;                                      // layer input / output
+    float* y1 = attn + (size_t)B * kD;                       // [B][512]  pre-LN1 rows
+    float* y2 = y1 + (size_t)B * kD;                         // [B][512]  pre-LN2 rows
+    void* hid = h->zpart;                                    // [B][2048] bf16 | e4m3
     const size_t layer_elems = (size_t)B * kH * T * kDh;
     const int rtiles = cdiv(B, 32);
-    auto gemm = [&](auto kern, const void* X, int ldx, const PackedConv& pc, const float* bias, int relu, void* Y, int ldy, int nsplit,
-                    size_t split_stride) {
-        RowGemmArgs ra;
-        ra.X = X; ra.ldx = ldx; ra.M = B; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
-        ra.bias = bias; ra.relu = relu; ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
-        hipLaunchKernelGGL(kern, dim3(rtiles, pc.mtiles, nsplit), dim3(256), 0, st, ra);
+    const bool f8 = h->fp8;
+    const unsigned skip = h->dbg_skip;
+    auto run = [&](auto kern, int nthreads, const BGemmArgs& ba) {
+        hipLaunchKernelGGL(kern, dim3(rtiles, ba.mtiles), dim3(nthreads), 0, st, ba);
     };
-    const float* xin = h->xcur;
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
-        gemm(rowgemm_kernel<float, float>, xin, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
+        if (!(skip & 1)) {   // K1: [LayerNorm2 of layer l-1] -> QKV
+            BGemmArgs g{};
+            g.M = B; g.ldx = kD; g.W = (const uint4*)(f8 ? L.f8_qkv : L.g_qkv.w); g.wscale = L.s_qkv; g.mtiles = 3 * kD / 32; g.cout = 3 * kD;
+            g.bias = L.g_qkv.bias; g.Y = qkv; g.ldy = 3 * kD;
+            if (l == 0) {
+                g.X = h->xcur;
+                if (f8) run(bgemm_kernel<PRO_NONE, float, float, 4, true>, 256, g);
+                else run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
+            } else {
+                g.X = y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = h->xbuf;
+                if (f8) run(bgemm_kernel<PRO_LN, float, float, 4, true>, 256, g);
+                else run(bgemm_kernel<PRO_LN, float, float, 4, false>, 256, g);
+            }
+        }
         BatchAttnArgs<WT> ba;
         ba.qkv = qkv; ba.kc = (WT*)s.k_cache + (size_t)l * layer_elems; ba.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
         ba.kv_len = s.kv_len; ba.T = T; ba.out = attn;
-        hipLaunchKernelGGL((t2s_batch_attn_kernel<WT>), dim3(kH, B), dim3(256), 0, st, ba);
-        gemm(rowgemm_kernel<float, float>, attn, kD, L.g_out, nullptr, 0, ybuf, kD, 1, 0);
-        hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)ybuf, 1, (size_t)0, (const float*)L.bo, xin,
-                           (const float*)L.ln1g, (const float*)L.ln1b, x, B);
-        gemm(rowgemm_kernel<float, bf16_t>, x, kD, L.g_w1, L.b1, 1, fb16, kF, 1, 0);
-        gemm(rowgemm_kernel<bf16_t, float>, fb16, kF, L.g_w2, nullptr, 0, part, kD, 4, (size_t)B * kD);
-        hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)part, 4, (size_t)B * kD, (const float*)L.b2,
-                           (const float*)x, (const float*)L.ln2g, (const float*)L.ln2b, x, B);
-        xin = x;
+        if (!(skip & 2)) hipLaunchKernelGGL((t2s_batch_attn_kernel<WT>), dim3(kH, B), dim3(256), 0, st, ba);
+        if (!(skip & 4)) {   // K3: out-proj + bias + residual -> pre-LN1
+            BGemmArgs g{};
+            g.M = B; g.X = attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
+            g.res = l == 0 ? h->xcur : h->xbuf; g.ldres = kD; g.Y = y1; g.ldy = kD;
+            run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
+        }
+        if (!(skip & 8)) {   // K4: [LayerNorm1] -> W1 + bias + ReLU
+            BGemmArgs g{};
+            g.M = B; g.X = y1; g.ldx = kD; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = h->x1buf;
+            g.W = (const uint4*)(f8 ? L.f8_w1 : L.g_w1.w); g.wscale = L.s_w1; g.mtiles = kF / 32; g.cout = kF; g.bias = L.b1; g.relu = 1;
+            g.Y = hid; g.ldy = kF;
+            if (f8) run(bgemm_kernel<PRO_LN, float, fp8_t, 4, true>, 256, g);
+            else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false>, 256, g);
+        }
+        if (!(skip & 16)) {   // K5: W2 over the full K + bias + residual -> pre-LN2
+            BGemmArgs g{};
+            g.M = B; g.X = hid; g.ldx = kF; g.W = (const uint4*)(f8 ? L.f8_w2 : L.g_w2.w); g.wscale = L.s_w2; g.mtiles = kD / 32; g.cout = kD;
+            g.bias = L.b2; g.res = h->x1buf; g.ldres = kD; g.Y = y2; g.ldy = kD;
+            if (f8) run(bgemm_kernel<PRO_NONE, fp8_t, float, 16, true>, 1024, g);
+            else run(bgemm_kernel<PRO_NONE, bf16_t, float, 16, false>, 1024, g);
+        }
     }
+    const T2SLayer& LL = h->layers.back();
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)y2, (const float*)LL.ln2g, (const float*)LL.ln2b, h->xbuf, B);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
 
 template <typename WT>
-int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, bool mega, hipStream_t st) {
+int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
     if (int rc = t2s_token(h, s, 1, st)) return rc;
     if constexpr (sizeof(WT) == 2) {
-        if (s.batch >= kBatchedMin && s.max_kv <= 1024 && !getenv("GSV_NO_BATCHED_STEP")) {
+        if (s.batch >= h->batched_min && s.max_kv <= 1024) {
             if (int rc = t2s_batched_layers<WT>(h, s, st)) return rc;
             return t2s_logits<WT>(h, s, 0, h->xbuf, 0, s.batch, h->cfg.vocab, 1, st);
         }
     }
-    if (int rc = mega ? t2s_mega_layers<WT>(h, s, h->xcur, st) : t2s_layers<WT>(h, s, h->xcur, st)) return rc;
+    if (int rc = t2s_layers<WT>(h, s, h->xcur, st)) return rc;
     return t2s_logits<WT>(h, s, 1, nullptr, 0, s.batch, h->cfg.vocab, 1, st);
 }
 
@@ -347,15 +368,15 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     float* hlast = fbuf + (size_t)M * kF;
     const size_t layer_elems = (size_t)s.batch * kH * T * kDh;
     const int qsplit = std::max(1, std::min(16, 256 / (kH * nrows)));
+    // LDS-staged attention: the whole prompt's K/V of one head sit in LDS.  Each numerics mode is gated by ITS kernel's
+    // footprint only (fp32 parity mode: 4*(69*l_max + 136) B -> l_max <= 591; bf16: 144*ceil(l_max/32)*32 + ... -> l_max <= 1056,
+    // i.e. every prompt the reference's largest default bucket (1024) accepts).  The dynamic-LDS attribute is raised once, at finalize.
     const size_t lds = sizeof(float) * ((size_t)l_max * 33 + (size_t)l_max * 32 + 4 * (size_t)l_max + 128 + 8);
-    if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
-    HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nkt_max = cdiv(l_max, 32);
     const size_t lds_mfma = (size_t)nkt_max * 32 * 80 + 128 * 80 + (size_t)32 * (nkt_max * 64 + 16);
-    if (sizeof(WT) == 2) {
-        if (lds_mfma > 160 * 1024) return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit", l_max);
-        HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma));
-    }
+    if (sizeof(WT) == 2 ? lds_mfma > kPrefillLdsMax : lds > kPrefillLdsMax)
+        return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit of the %s mode (%d positions)",
+                    l_max, sizeof(WT) == 2 ? "bf16" : "fp32", sizeof(WT) == 2 ? 1056 : 591);
     if constexpr (sizeof(WT) == 2) {
         // bf16 mode: latency-shaped GEMMs (rowgemm_kernel), flash attention on the matrix cores, and
         // bias + residual + LayerNorm in the consumer of the raw (split) GEMM tiles
@@ -432,29 +453,42 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
 
 }  // namespace
 
+// One class of decode-step kernels (all layers' launches of it) captured into a hipGraph and replayed `iters` times
+// between two events on `st`: no host launch cost in the figure (an eager sweep is host-bound below ~3 us per launch).
+// The result still contains the dependent-launch gap that every kernel of a real step pays too.
 template <typename WT>
 static int t2s_time_impl(gsv_t2s* h, T2SBound* b, int iters, float* out_ms, hipStream_t st) {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     const int NL = h->cfg.n_layer;
-    // save the sequence position: the sweeps below re-run real kernels on the live state
     for (int cls = 0; cls < 4; ++cls) {
-        for (int rep = 0; rep < 2; ++rep) {  // rep 0 = warm-up
-            HIPCHK(hipEventRecord(e0, st));
-            int launches = 0;
-            for (int it = 0; it < (rep ? iters : 1); ++it) {
-                if (cls == 0) for (int l = 0; l < NL; ++l, ++launches) t2s_launch_attn<WT>(h, b->st, l, h->xcur, st);
-                if (cls == 1) for (int l = 0; l < NL; ++l, ++launches) t2s_launch_ffn<WT>(h, b->st, l, st);
-                if (cls == 2) { for (int l = 0; l < NL; ++l, ++launches) if (int rc = t2s_logits<WT>(h, b->st, 1, nullptr, 0, b->st.batch, h->cfg.vocab, 0, st)) return rc; }
-                if (cls == 3) { for (int l = 0; l < NL; ++l, ++launches) if (int rc = t2s_token(h, b->st, 0, st)) return rc; }
-            }
-            HIPCHK(hipEventRecord(e1, st));
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep) out_ms[cls] = ms / (float)launches;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = GSV_OK;
+        for (int l = 0; l < NL && !rc; ++l) {
+            if (cls == 0) t2s_launch_attn<WT>(h, b->st, l, h->xcur, h->cap_stream);
+            if (cls == 1) t2s_launch_ffn<WT>(h, b->st, l, h->cap_stream);
+            if (cls == 2) rc = t2s_logits<WT>(h, b->st, 1, nullptr, 0, b->st.batch, h->cfg.vocab, 0, h->cap_stream);
+            if (cls == 3) rc = t2s_token(h, b->st, 0, h->cap_stream);
         }
+        hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        HIPCHK(hipGraphLaunch(exec, st));                    // warm-up
+        HIPCHK(hipEventRecord(e0, st));
+        for (int it = 0; it < iters; ++it) HIPCHK(hipGraphLaunch(exec, st));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        out_ms[cls] = ms / (float)(iters * NL);
+        (void)hipGraphExecDestroy(exec);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -472,9 +506,13 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
         return fail(GSV_ERR_ARG, "unsupported GPT shape: hidden %d heads %d (kernels are specialised for 512/16)", cfg->hidden, cfg->n_head);
     if (cfg->vocab < 2 || cfg->vocab > kNP * 128 || cfg->n_layer < 1 || cfg->n_pos < 1)
         return fail(GSV_ERR_ARG, "unsupported vocab/n_layer/n_pos");
-    if (cfg->dtype != GSV_F32 && cfg->dtype != GSV_BF16) return fail(GSV_ERR_ARG, "bad dtype");
+    if (cfg->dtype != GSV_F32 && cfg->dtype != GSV_BF16 && cfg->dtype != GSV_FP8) return fail(GSV_ERR_ARG, "bad dtype");
     gsv_t2s* h = new gsv_t2s();
     h->cfg = *cfg;
+    if (cfg->dtype == GSV_FP8) { h->fp8 = true; h->cfg.dtype = GSV_BF16; }   // bf16 everywhere but the batched step's QKV / FFN
+    h->batched_min = kBatchedMinDefault;
+    if (const char* e = getenv("GSV_BATCHED_MIN")) h->batched_min = std::max(1, atoi(e));
+    if (const char* e = getenv("GSV_BSTEP_SKIP")) h->dbg_skip = (unsigned)atoi(e);
     h->layers.resize(cfg->n_layer);
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -489,13 +527,11 @@ int gsv_t2s_destroy(gsv_t2s* h) {
     (void)hipDeviceSynchronize();
     for (auto& kv : h->bound) {
         if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
-        if (kv.second.graph_mega) (void)hipGraphExecDestroy(kv.second.graph_mega);
     }
-    if (h->mega_layers) (void)hipFree(h->mega_layers);
-    if (h->mega_cnt) (void)hipFree(h->mega_cnt);
     for (T2SLayer& L : h->layers) {
         for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
-                        (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b})
+                        (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b, L.f8_qkv, L.f8_w1, L.f8_w2,
+                        (void*)L.s_qkv, (void*)L.s_w1, (void*)L.s_w2})
             if (p) (void)hipFree(p);
         free_conv(L.g_qkv); L.g_out.bias = nullptr; free_conv(L.g_out); L.g_w1.bias = nullptr; free_conv(L.g_w1);
         L.g_w2.bias = nullptr; free_conv(L.g_w2);
@@ -532,16 +568,10 @@ int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
     for (int l = 0; l < h->cfg.n_layer; ++l)
         if (h->layers[l].have != 0xfffu) return fail(GSV_ERR_STATE, "layer %d incomplete (mask 0x%x)", l, h->layers[l].have);
     if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
-    {   // device table of per-layer pointers for the persistent step
-        struct Raw { const void *wqkv, *wo, *w1, *w2p; const float *bqkv, *bo, *b1, *b2, *ln1g, *ln1b, *ln2g, *ln2b; };
-        static_assert(sizeof(Raw) == sizeof(MegaLayer<float>) && sizeof(Raw) == sizeof(MegaLayer<bf16_t>), "layout");
-        std::vector<Raw> tab(h->cfg.n_layer);
-        for (int l = 0; l < h->cfg.n_layer; ++l) {
-            const T2SLayer& L = h->layers[l];
-            tab[l] = Raw{L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.bqkv_p, L.bo, L.b1, L.b2, L.ln1g, L.ln1b, L.ln2g, L.ln2b};
-        }
-        if (!h->mega_layers) HIPCHK(hipMalloc(&h->mega_layers, sizeof(Raw) * tab.size()));
-        HIPCHK(hipMemcpy(h->mega_layers, tab.data(), sizeof(Raw) * tab.size(), hipMemcpyHostToDevice));
+    if (h->cfg.dtype == GSV_BF16) {
+        HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
+    } else {
+        HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
     }
     HIPCHK(hipStreamSynchronize(S(stream)));
     h->finalized = true;
@@ -557,7 +587,6 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     if (int rc = t2s_ensure_scratch(h, st->batch)) return rc;
     T2SBound& b = h->bound[st->batch];
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
-    if (b.graph_mega) { (void)hipGraphExecDestroy(b.graph_mega); b.graph_mega = nullptr; }
     b.st = *st;
     return GSV_OK;
 }
@@ -620,6 +649,11 @@ int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream) {
     if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
     T2SBound* b = t2s_find(h, batch);
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    if (h->cfg.dtype == GSV_BF16 && batch >= h->batched_min && b->st.max_kv <= 1024) {   // the path gsv_t2s_decode takes
+        HIPCHK(hipMemcpyAsync(h->xcur, x, sizeof(float) * (size_t)batch * kD, hipMemcpyDeviceToDevice, S(stream)));
+        if (int rc = t2s_batched_layers<bf16_t>(h, b->st, S(stream))) return rc;
+        return t2s_logits<bf16_t>(h, b->st, 0, h->xbuf, 0, batch, h->cfg.vocab, 1, S(stream));
+    }
     int rc = h->cfg.dtype == GSV_BF16 ? t2s_layers<bf16_t>(h, b->st, x, S(stream)) : t2s_layers<float>(h, b->st, x, S(stream));
     if (rc) return rc;
     return h->cfg.dtype == GSV_BF16 ? t2s_logits<bf16_t>(h, b->st, 1, nullptr, 0, batch, h->cfg.vocab, 1, S(stream))
@@ -632,17 +666,16 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     const bool bf = h->cfg.dtype == GSV_BF16;
     const bool graph = (use_graph & 1) != 0;
-    const bool mega = (use_graph & 2) != 0 && batch <= kMegaMaxBatch && 2 * h->cfg.n_layer <= 256;
     if (!graph) {
         for (int i = 0; i < n_steps; ++i)
-            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, mega, S(stream)) : t2s_step<float>(h, b->st, mega, S(stream))) return rc;
+            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream)) : t2s_step<float>(h, b->st, S(stream))) return rc;
         return GSV_OK;
     }
-    hipGraphExec_t& exec = mega ? b->graph_mega : b->graph;
+    hipGraphExec_t& exec = b->graph;
     if (!exec) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = bf ? t2s_step<bf16_t>(h, b->st, mega, h->cap_stream) : t2s_step<float>(h, b->st, mega, h->cap_stream);
+        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream) : t2s_step<float>(h, b->st, h->cap_stream);
         hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -654,14 +687,6 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
     return GSV_OK;
 }
 
-/* 1 if any persistent-step hand-off ever timed out on this handle (results are then invalid) */
-int gsv_t2s_megastep_error(gsv_t2s* h) {
-    if (!h || !h->mega_cnt) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, h->mega_cnt + (size_t)h->scratch_b * 2 * h->cfg.n_layer, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)v;
-}
-
 int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream) {
     if (!h || !h->finalized || !out_ms || iters < 1) return fail(GSV_ERR_STATE, "bad call");
     T2SBound* b = t2s_find(h, batch);
@@ -670,12 +695,13 @@ int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* 
                                     : t2s_time_impl<float>(h, b, iters, out_ms, S(stream));
 }
 
+int gsv_t2s_batched_min(gsv_t2s* h) { return h && h->cfg.dtype == GSV_BF16 ? h->batched_min : 0x7fffffff; }
+
 int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
     if (!h) return fail(GSV_ERR_ARG, "null handle");
     h->dbg = (unsigned long long*)buf;
     for (auto& kv : h->bound)
-        { if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
-          if (kv.second.graph_mega) { (void)hipGraphExecDestroy(kv.second.graph_mega); kv.second.graph_mega = nullptr; } }
+        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
     return GSV_OK;
 }
 

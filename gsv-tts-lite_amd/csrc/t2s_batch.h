@@ -1,0 +1,336 @@
+// Batched decode step for gfx950: one token per sequence for B >= kBatchedMin sequences at once.
+//
+// Reference: T2SBlock.decode_next_token gsv_tts/GPT_SoVITS/GPT/t2s_model.py:67-105 on B rows, i.e. the
+// linears of :80-85 (qkv), :97 (out_proj), :100-103 (mlp) as [B x K] x [K x N] contractions, the two
+// LayerNorms of :98,104 and the K/V append + SDPA of :87-93.
+//
+// The step is launch/latency bound up to a few hundred sequences (24 layers x a chain of dependent kernels of a
+// few microseconds each), so the design removes dependent launches, not bytes: FIVE launches per layer
+//   K1  [LayerNorm2 of the previous layer] -> QKV GEMM (+bias)                 bgemm<PRO_LN, ...>
+//   K2  K/V append + softmax(q K^T) V per (head, sequence)                      t2s_batch_attn_kernel
+//   K3  out-proj GEMM + bias + residual  -> pre-LN1 rows                        bgemm<PRO_NONE, ...>
+//   K4  [LayerNorm1] -> W1 GEMM + bias + ReLU -> hidden (bf16 | fp8)            bgemm<PRO_LN, ...>
+//   K5  W2 GEMM over the full K = 2048 + bias + residual -> pre-LN2 rows        bgemm<..., NW = 16>
+// (it was seven: the two LayerNorm launches are now the prologue of their consumer -- a GEMM block reads its
+// 32 rows over the full K = 512 anyway, so the statistics cost one LDS exchange and no extra traffic -- and the
+// 4-way split-K of W2 with its partial tensors is one 16-wave block per tile that reduces in LDS).
+//
+// A block owns one 32x32 output tile; each of its NW waves owns 8 MFMA k-steps (128 channels) and has ALL of its
+// operands in flight at once (weight fragments packed at load + the X rows straight from global in B-fragment
+// layout), so a block costs one memory latency, 8 MFMAs, an LDS reduction and a store.
+//
+// fp8 (BASELINE configs[4]): the QKV / W1 / W2 weights as OCP e4m3 with one fp32 scale per output channel, the
+// activations as e4m3 at unit scale (post-LayerNorm rows and ReLU outputs are O(1); saturating), contraction on
+// v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate, scale in the epilogue.  K/V cache and out-proj stay bf16.
+#pragma once
+#include "t2s_prefill.h"
+
+namespace gsv {
+
+constexpr int PRO_NONE = 0;   // X is the operand (fp32 / bf16 / fp8 rows)
+constexpr int PRO_LN = 1;     // X = LayerNorm(pre-LN fp32 rows [M][512]) * g + b, K = 512
+
+typedef uint8_t fp8_t;        // raw OCP e4m3 bits
+
+struct BGemmArgs {
+    const void* X;        // [M][ldx]
+    int ldx, M;
+    const float* lng;     // PRO_LN: LayerNorm weight / bias [512]
+    const float* lnb;
+    float* xout;          // PRO_LN: the normalised rows [M][512] fp32 (the block's residual later), written by column tile 0; or null
+    const uint4* W;       // weight fragments: bf16 [mtile][kstep][64 lanes][16 B]; fp8 [mtile][kstep pair][64 lanes][16 B]
+    const float* wscale;  // fp8: dequantisation scale per output channel
+    int mtiles, cout;
+    const float* bias;    // [cout] or null
+    const float* res;     // residual rows fp32 [M][ldres] or null
+    int ldres, relu;
+    void* Y;              // [M][ldy]: fp32, bf16 or fp8 (saturating e4m3 at unit scale)
+    int ldy;
+};
+
+__device__ __forceinline__ float clamp_e4m3(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+
+// 8 floats -> 8 e4m3 bytes (two dwords), round-to-nearest-even in hardware (v_cvt_pk_fp8_f32, OCP on gfx950)
+__device__ __forceinline__ void pack_fp8x8(const float (&v)[8], uint32_t& lo, uint32_t& hi) {
+    int a = 0, b = 0;
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(v[0]), clamp_e4m3(v[1]), a, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(v[2]), clamp_e4m3(v[3]), a, true);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(v[4]), clamp_e4m3(v[5]), b, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(v[6]), clamp_e4m3(v[7]), b, true);
+    lo = (uint32_t)a; hi = (uint32_t)b;
+}
+
+// First channel of the g-th group of 8 channels a lane (half hf) of wave `wid` contributes.  bf16: k-step g of the
+// wave, the MFMA's own order (16 channels per k-step, 8 per lane half).  fp8: k-steps are PAIRED so that one 16-byte
+// load feeds two MFMAs -- a lane half owns 16 consecutive channels of each 32-channel pair (a contraction may
+// enumerate its index in any order as long as both operands agree; the packer uses the same map).
+template <bool F8> __device__ __forceinline__ int bg_chan(int wid, int g, int hf) {
+    if constexpr (F8) return wid * 128 + (g >> 1) * 32 + hf * 16 + (g & 1) * 8;
+    else return wid * 128 + g * 16 + hf * 8;
+}
+
+template <int PRO, typename XT, typename OT, int NW, bool F8>
+__global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
+    constexpr int NRED = NW == 4 ? 3 * 16 * 64 : NW * 16 * 64;
+    __shared__ __attribute__((aligned(16))) float red[NRED];
+    __shared__ __attribute__((aligned(16))) float gsm[PRO == PRO_LN ? 2 * kD : 4];
+    __shared__ float stat[PRO == PRO_LN ? NW * 32 * 2 : 2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 31, hf = lane >> 5;
+    const int rt = blockIdx.x, mt = blockIdx.y;
+    const int row = rt * 32 + j;
+    const int rowc = min(row, a.M - 1);
+    constexpr int KS = NW * 8;                              // k-steps of the whole contraction
+
+    // ---- everything in flight at once: weight fragments, then the X rows
+    u32x4 wf[F8 ? 4 : 8];
+    if constexpr (F8) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            wf[p] = __builtin_bit_cast(u32x4, a.W[((size_t)mt * (KS / 2) + wid * 4 + p) * 64 + lane]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            wf[s] = __builtin_bit_cast(u32x4, a.W[((size_t)mt * KS + wid * 8 + s) * 64 + lane]);
+    }
+    // epilogue operands (bias, fp8 scale, residual) of the lanes that will write the tile: addresses are known now
+    constexpr int NEP = NW == 4 ? 4 : 1;                     // f32x4 per writer lane
+    const bool writer = NW == 4 ? wid == 0 : tid < 256;
+    const int erow = NW == 4 ? row : rt * 32 + (tid >> 3);
+    const int ech = NW == 4 ? mt * 32 + 16 * hf : mt * 32 + (tid & 7) * 4;
+    f32x4 e_bias[NEP], e_scale[NEP], e_res[NEP];
+#pragma unroll
+    for (int g = 0; g < NEP; ++g) { e_bias[g] = f32x4{0.f, 0.f, 0.f, 0.f}; e_scale[g] = f32x4{1.f, 1.f, 1.f, 1.f}; e_res[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (writer) {
+        if (a.bias) {
+#pragma unroll
+            for (int g = 0; g < NEP; ++g) e_bias[g] = *reinterpret_cast<const f32x4*>(a.bias + ech + 4 * g);
+        }
+        if constexpr (F8) {
+#pragma unroll
+            for (int g = 0; g < NEP; ++g) e_scale[g] = *reinterpret_cast<const f32x4*>(a.wscale + ech + 4 * g);
+        }
+        if (a.res) {
+            const float* rp = a.res + (size_t)min(erow, a.M - 1) * a.ldres + ech;
+#pragma unroll
+            for (int g = 0; g < NEP; ++g) e_res[g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+        }
+    }
+    uint32_t xb[8][4];   // bf16: xb[g][0..3] = 8 bf16 of group g; fp8: xb[g][0..1] = 8 e4m3 of group g
+    if constexpr (sizeof(XT) == 4) {
+        const float* xp = reinterpret_cast<const float*>(a.X) + (size_t)rowc * a.ldx;
+        f32x4 lo[8], hi[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int c = bg_chan<F8>(wid, g, hf);
+            lo[g] = *reinterpret_cast<const f32x4*>(xp + c);
+            hi[g] = *reinterpret_cast<const f32x4*>(xp + c + 4);
+        }
+        if constexpr (PRO == PRO_LN) {
+            // LayerNorm statistics of the row: this lane holds 64 of its 512 values; the other half of the row's
+            // lanes and the other waves meet in LDS (one barrier).  var = E[x^2] - mean^2 as the decode kernels.
+            if (tid < 128) {
+                *reinterpret_cast<f32x4*>(gsm + tid * 4) = *reinterpret_cast<const f32x4*>(a.lng + tid * 4);
+                *reinterpret_cast<f32x4*>(gsm + kD + tid * 4) = *reinterpret_cast<const f32x4*>(a.lnb + tid * 4);
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s += lo[g][i]; q = fmaf(lo[g][i], lo[g][i], q);
+                    s += hi[g][i]; q = fmaf(hi[g][i], hi[g][i], q);
+                }
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (hf == 0) { stat[(wid * 32 + j) * 2] = s; stat[(wid * 32 + j) * 2 + 1] = q; }
+            __syncthreads();
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { ts += stat[(w * 32 + j) * 2]; tq += stat[(w * 32 + j) * 2 + 1]; }
+            const float mean = ts * (1.0f / kD);
+            const float var = fmaxf(tq * (1.0f / kD) - mean * mean, 0.f);
+            const float rs = 1.0f / sqrtf(var + kEps);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int c = bg_chan<F8>(wid, g, hf);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gsm + c), g1 = *reinterpret_cast<const f32x4*>(gsm + c + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(gsm + kD + c), b1 = *reinterpret_cast<const f32x4*>(gsm + kD + c + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[g][i] = (lo[g][i] - mean) * rs * g0[i] + b0[i];
+                    hi[g][i] = (hi[g][i] - mean) * rs * g1[i] + b1[i];
+                }
+                if (mt == 0 && a.xout != nullptr && row < a.M) {
+                    *reinterpret_cast<f32x4*>(a.xout + (size_t)row * kD + c) = lo[g];
+                    *reinterpret_cast<f32x4*>(a.xout + (size_t)row * kD + c + 4) = hi[g];
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if constexpr (F8) {
+                const float v[8] = {lo[g][0], lo[g][1], lo[g][2], lo[g][3], hi[g][0], hi[g][1], hi[g][2], hi[g][3]};
+                pack_fp8x8(v, xb[g][0], xb[g][1]);
+            } else {
+                xb[g][0] = pack_bf16x2(lo[g][0], lo[g][1]);
+                xb[g][1] = pack_bf16x2(lo[g][2], lo[g][3]);
+                xb[g][2] = pack_bf16x2(hi[g][0], hi[g][1]);
+                xb[g][3] = pack_bf16x2(hi[g][2], hi[g][3]);
+            }
+        }
+    } else if constexpr (sizeof(XT) == 2) {
+        static_assert(sizeof(XT) != 2 || !F8, "bf16 rows feed the bf16 contraction");
+        const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.X) + (size_t)rowc * a.ldx;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(xp + bg_chan<false>(wid, g, hf));
+            xb[g][0] = t[0]; xb[g][1] = t[1]; xb[g][2] = t[2]; xb[g][3] = t[3];
+        }
+    } else {
+        static_assert(sizeof(XT) != 1 || F8, "fp8 rows feed the fp8 contraction");
+        const fp8_t* xp = reinterpret_cast<const fp8_t*>(a.X) + (size_t)rowc * a.ldx;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                        // 16 consecutive channels = both k-steps of the pair
+            const u32x4 t = *reinterpret_cast<const u32x4*>(xp + bg_chan<true>(wid, 2 * p, hf));
+            xb[2 * p][0] = t[0]; xb[2 * p][1] = t[1]; xb[2 * p + 1][0] = t[2]; xb[2 * p + 1][1] = t[3];
+        }
+    }
+
+    // all loads issued, THEN arithmetic: hipcc otherwise re-uses operand registers and interleaves the later loads
+    // with the MFMAs (measured in the ISA: 8 of 16 loads up front), i.e. two exposed memory latencies instead of one
+    asm volatile("" : "+v"(wf[0]) : : "memory");
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if constexpr (F8) {
+            const uint64_t av = (uint64_t)wf[g >> 1][(g & 1) * 2] | ((uint64_t)wf[g >> 1][(g & 1) * 2 + 1] << 32);
+            const uint64_t bv = (uint64_t)xb[g][0] | ((uint64_t)xb[g][1] << 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)av, (long)bv, acc, 0, 0, 0);
+        } else {
+            const u32x4 bv = {xb[g][0], xb[g][1], xb[g][2], xb[g][3]};
+            Mma<bf16_t>::run(acc, wf[g], bv);
+        }
+    }
+
+    // ---- the NW partial tiles meet in LDS, summed in wave order (bit-reproducible)
+    const int chl = 16 * hf;                                 // register q = channel mt*32 + chl + q (packer's row permutation)
+    if constexpr (NW == 4) {
+        if (wid > 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[((wid - 1) * 16 + q) * 64 + lane] = acc[q];
+        }
+        __syncthreads();
+        if (wid > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += red[(w * 16 + q) * 64 + lane];
+        if (row >= a.M) return;
+        const int ch = mt * 32 + chl;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            v[q] = acc[q];
+            if constexpr (F8) v[q] *= e_scale[q >> 2][q & 3];
+            v[q] += e_bias[q >> 2][q & 3];
+            if (a.relu) v[q] = fmaxf(v[q], 0.f);
+            v[q] += e_res[q >> 2][q & 3];
+        }
+        if constexpr (sizeof(OT) == 4) {
+            float* yp = reinterpret_cast<float*>(a.Y) + (size_t)row * a.ldy + ch;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(yp + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        } else if constexpr (sizeof(OT) == 2) {
+            bf16_t* yp = reinterpret_cast<bf16_t*>(a.Y) + (size_t)row * a.ldy + ch;
+            u32x4 oa, ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                oa[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                ob[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            }
+            *reinterpret_cast<u32x4*>(yp) = oa;
+            *reinterpret_cast<u32x4*>(yp + 8) = ob;
+        } else {
+            fp8_t* yp = reinterpret_cast<fp8_t*>(a.Y) + (size_t)row * a.ldy + ch;
+            uint32_t o0, o1, o2, o3;
+            const float v0[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+            const float v1[8] = {v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]};
+            pack_fp8x8(v0, o0, o1);
+            pack_fp8x8(v1, o2, o3);
+            *reinterpret_cast<u32x4*>(yp) = u32x4{o0, o1, o2, o3};
+        }
+    } else {
+        // 16 waves: every wave parks its tile, then wave w sums register w over the 16 waves (16 LDS reads instead
+        // of 240 by one wave), the tile is transposed through LDS and the first four waves write whole rows
+        static_assert(NW == 16, "NW");
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[(q * NW + wid) * 64 + lane] = acc[q];
+        __syncthreads();
+        float r = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r += red[(wid * NW + w) * 64 + lane];
+        __syncthreads();
+        red[j * 33 + chl + wid] = r;                        // tile [32 rows][33]: register `wid` of lane (j, hf)
+        __syncthreads();
+        if (tid >= 256) return;
+        const int orow = tid >> 3, c4 = (tid & 7) * 4;
+        const int grow = rt * 32 + orow;
+        if (grow >= a.M) return;
+        const int ch = mt * 32 + c4;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = red[orow * 33 + c4 + i];
+            if constexpr (F8) v[i] *= e_scale[0][i];
+            v[i] += e_bias[0][i];
+            if (a.relu) v[i] = fmaxf(v[i], 0.f);
+            v[i] += e_res[0][i];
+        }
+        static_assert(NW != 16 || sizeof(OT) == 4, "the 16-wave form writes fp32 rows");
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.Y) + (size_t)grow * a.ldy + ch) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// ---- fp8 weight packing --------------------------------------------------------------------------
+// scale[m] = max_c |W[m][c]| / 448 (1 for an all-zero row)
+static __global__ __launch_bounds__(256) void fp8_row_scale_kernel(const float* __restrict__ W, int cin, float* __restrict__ scale, int cout) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= cout) return;
+    float mx = 0.f;
+    for (int c = lane; c < cin; c += 64) mx = fmaxf(mx, fabsf(W[(size_t)m * cin + c]));
+    mx = wave_max(mx);
+    if (lane == 0) scale[m] = mx > 0.f ? mx * (1.0f / 448.f) : 1.0f;
+}
+
+// dst [mtile][kstep pair][64 lanes][16 bytes]: byte e of lane (mr, hf) = W[m(mr)][pair*32 + hf*16 + e] / scale[m],
+// the same row permutation as tapgemm_pack_kernel (a lane's 16 D registers are 16 consecutive channels)
+static __global__ __launch_bounds__(256) void fp8_pack_kernel(const float* __restrict__ W, const float* __restrict__ scale,
+                                                       uint32_t* __restrict__ dst, int cout, int cin, int mtiles) {
+    const int npair = cin / 32;
+    const size_t total = (size_t)mtiles * npair * 64 * 4;    // dwords
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        size_t r = idx;
+        const int d = r % 4; r /= 4;
+        const int lane = r % 64; r /= 64;
+        const int p = r % npair; r /= npair;
+        const int mt = (int)r;
+        const int mr = lane & 31, hf = lane >> 5;
+        const int m = mt * 32 + 16 * ((mr >> 2) & 1) + (mr & 3) + 4 * (mr >> 3);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < cout) {
+            const float inv = 1.0f / scale[m];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = clamp_e4m3(W[(size_t)m * cin + p * 32 + hf * 16 + d * 4 + i] * inv);
+        }
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        dst[idx] = (uint32_t)w;
+    }
+}
+
+}  // namespace gsv

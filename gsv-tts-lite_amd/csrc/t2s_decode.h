@@ -628,7 +628,7 @@ struct LogitsArgs {
     int slot0;           // first state slot of row 0
     const int32_t* slots;// or: state slot of every row (refills of scattered slots); null = slot0 + row
     const int32_t* step;
-    const int32_t* ctl;  // {use_override, suppress_steps, rep_enabled, -}
+    const int32_t* ctl;  // {sample_mode, suppress_steps, rep_enabled, -, top_k, seed_lo, seed_hi, suppress_first}
     const float* fctl;   // {rep_penalty}
     const uint8_t* seen; // [B][V]
     float* logits;       // [B][V]
@@ -669,7 +669,9 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
         const int v = min(vbase + wid * rww + min(u, rww - 1), a.V - 1);
         row_load<WT>(a.wp + (size_t)v * kD, wr[u]);
     }
-    const bool sup = a.step[b] < a.ctl[1];
+    // the first sample (the prefill's logits: vlimit < V) is suppressed unconditionally by infer / infer_stream
+    // (t2s_model.py:415-416; ctl[7] set by the host), later samples while step < initial_suppression_steps (:444-445)
+    const bool sup = a.step[b] < a.ctl[1] || (a.vlimit < a.V && a.ctl[7] != 0);
     const bool rep = a.ctl[2] != 0;
     const float rp = a.fctl[0];
     const int oi = sumN_index<8>();
@@ -746,8 +748,6 @@ struct TokenArgs {
     const float* pe;         // [n_pos][512] alpha_audio * pe
     float* xcur;             // [B][512]
     int T, V, eos, n_pos, advance;
-    unsigned* mega_cnt;      // [B][mega_n] hand-off counters of the persistent step, zeroed here (or null)
-    int mega_n;
     const float* logits;     // [B][V] penalised logits of the pending sample (device sampling, ctl[0] == 2)
     const float* fctl;       // fctl[1] = temperature
 };
@@ -786,9 +786,6 @@ __device__ __forceinline__ void t2s_block_argmax(float& v, int& idx, float* sv, 
 static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x;
-    // re-initialise the persistent step's counters from the kernel that precedes it in the chain
-    // (kernel->kernel ordering; a captured memset node was observed to race with the first replay)
-    if (a.mega_cnt != nullptr && tid < a.mega_n) a.mega_cnt[(size_t)b * a.mega_n + tid] = 0u;
     // ---- device sampling (ctl[0] == 2): temperature, top-k with the reference's tie rule, then the
     // exponential race of GPT/utils.py:56-59 as a Gumbel argmax: argmax p/q, q ~ Exp(1)  ==  argmax (x - log q)
     int sampled = -1;

@@ -13,13 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsv_hip.so")
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
-GSV_F32, GSV_BF16 = 0, 1
+GSV_F32, GSV_BF16, GSV_FP8 = 0, 1, 2
 
 EXPORTS = [
     "gsv_version", "gsv_last_error",
     "gsv_t2s_create", "gsv_t2s_destroy", "gsv_t2s_load_tensor", "gsv_t2s_finalize", "gsv_t2s_bind_state",
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_prefill_slots", "gsv_t2s_decode_hidden",
-    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_megastep_error",
+    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
     "gsv_align_workspace", "gsv_align_viterbi",
@@ -80,7 +80,7 @@ def lib():
         "gsv_t2s_decode": [vp, i, i, i, vp],
         "gsv_t2s_flush": [vp, i, vp],
         "gsv_t2s_set_debug": [vp, vp],
-        "gsv_t2s_megastep_error": [vp],
+        "gsv_t2s_batched_min": [vp],
         "gsv_t2s_time_kernels": [vp, i, i, ctypes.POINTER(ctypes.c_float), vp],
         "gsv_voc_create": [ctypes.POINTER(VocConfig), ctypes.POINTER(vp)],
         "gsv_voc_destroy": [vp],
@@ -130,7 +130,10 @@ def dtype_code(torch_dtype) -> int:
         return GSV_F32
     if torch_dtype == torch.bfloat16:
         return GSV_BF16
-    raise ValueError("the MI355X hot path supports float32 (parity) and bfloat16 (production); got %s" % torch_dtype)
+    if torch_dtype == torch.float8_e4m3fn:   # gsv_t2s only: bf16 + e4m3 QKV / FFN in the batched decode step
+        return GSV_FP8
+    raise ValueError("the MI355X hot path supports float32 (parity), bfloat16 (production) and float8_e4m3fn (GPT batched step); "
+                     "got %s" % torch_dtype)
 
 
 def current_stream_ptr(device=None) -> int:

@@ -1,0 +1,180 @@
+"""Multi-GPU continuous-batching engine: one process per GPU, utterances dealt on demand, no data-path collective.
+
+What it distributes is the reference's own work queue.  `Text2SemanticDecoder.infer_batched`
+(gsv_tts/GPT_SoVITS/GPT/t2s_model.py:555-734) keeps B slots busy and refills a finished slot from the head of
+the request list (:696-722); `TTS.infer_batched` (gsv_tts/TTS.py:616-633) builds that list from every cut segment
+of every text, balances the vocoder batches (:705-720) and puts the audio back in input order (:820-865).
+Utterances are independent through GPT and vocoder, so scale-out is: weights replicated, every rank runs the same
+slot loop over ITS slots, and the only shared thing is the head of the queue.
+
+  * dealing   requests are sorted longest-first (expected cost = phonemes, LPT order) and ranks pull chunks of a few
+              from ONE shared cursor when a slot frees up -- an atomic counter in the process group's store (a host
+              round trip per chunk, off the GPU's critical path; `store.add` is the c10d primitive for exactly this).
+              A rank whose utterances turn out short simply comes back sooner: dynamic dealing, no length oracle.
+              The static snake partition (`scheduler.shard_indices`) remains as the store-less fallback.
+  * speakers  `ge`, prompt tokens, prompt phonemes / BERT features exist only on the rank that ran the
+              reference-audio models.  `SpeakerBook.sync` broadcasts them ONCE per new key over RCCL/xGMI
+              (a few hundred KB, latency-bound) and every later request with that key is a dictionary hit.
+  * gather    per-utterance results (token ids, audio) are variable-length host objects: `all_gather_object`
+              keyed by the GLOBAL request index (`semantic_orig_idx` semantics kept globally).
+
+Greedy decoding is placement-invariant (rows are independent through every kernel), so N ranks return exactly
+the tokens one rank returns (tests/test_engine_*.py).  Device sampling keys its noise by slot, so sampled runs are
+reproducible per (seed, world size), not across world sizes.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+import threading
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def _dist_on(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+# ----------------------------------------------------------------------------------------------- dealing
+class RequestSource:
+    """Hands out global request indices in `order`.  Single process: sequentially.  Multi-rank: `chunk` at a time
+    from a cursor shared through `store` (every rank constructs the source with the same `order` and `key`)."""
+
+    def __init__(self, order: Sequence[int], store=None, key: str = "gsv/cursor", chunk: int = 2):
+        self.order = list(order)
+        self.store, self.key, self.chunk = store, key, max(1, int(chunk))
+        self._local: List[int] = []
+        self._pos = 0            # store-less cursor
+        self.taken: List[int] = []
+
+    def next(self) -> Optional[int]:
+        if not self._local:
+            if self.store is None:
+                lo, hi = self._pos, min(self._pos + self.chunk, len(self.order))
+                self._pos = hi
+            else:
+                hi = int(self.store.add(self.key, self.chunk))      # atomic fetch-add on the rendezvous store
+                lo, hi = hi - self.chunk, min(hi, len(self.order))
+            if lo >= len(self.order):
+                return None
+            self._local = self.order[lo:hi]
+        i = self._local.pop(0)
+        self.taken.append(i)
+        return i
+
+
+_RUN_COUNTER = itertools.count()
+
+
+def _default_store():
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        return _get_default_store()
+    except Exception:
+        return None
+
+
+def lpt_order(costs: Sequence[float]) -> List[int]:
+    """longest processing time first; ties by index (every rank computes the same order)"""
+    return sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+
+
+# ----------------------------------------------------------------------------------------------- speakers
+class SpeakerBook:
+    """Per-process cache of reference-speaker tensors, filled by ONE broadcast per new key."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = torch.device(device), group
+        self.entries: Dict[str, List[torch.Tensor]] = {}
+        self.broadcasts = 0      # number of tensor broadcasts issued (tests / bench read it)
+
+    def sync(self, key: str, tensors: Optional[List[torch.Tensor]], src: int = 0) -> List[torch.Tensor]:
+        """`tensors` is the list on `src` (None elsewhere).  Returns the list on every rank."""
+        if key in self.entries:
+            return self.entries[key]
+        if not _dist_on(self.group):
+            assert tensors is not None, "single process: the speaker tensors must be given"
+            self.entries[key] = [t.to(self.device) for t in tensors]
+            return self.entries[key]
+        rank = dist.get_rank(self.group)
+        meta = [[(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]] if rank == src else [None]
+        dist.broadcast_object_list(meta, src=src, group=self.group)
+        out = []
+        for i, (shape, dt) in enumerate(meta[0]):
+            t = tensors[i].to(self.device).contiguous() if rank == src else \
+                torch.empty(shape, dtype=getattr(torch, dt), device=self.device)
+            dist.broadcast(t, src=src, group=self.group)
+            self.broadcasts += 1
+            out.append(t)
+        self.entries[key] = out
+        return out
+
+
+# ----------------------------------------------------------------------------------------------- engine
+class ContinuousBatchingEngine:
+    """Drives `decoder.infer_batched` (the reference's slot loop) on this rank's share of a global request list.
+
+    decoder   a Text2SemanticDecoder-like object: infer_batched(xs, ys, berts, ..., source=, slots=) ->
+              (list of token tensors in completion order, tensor of GLOBAL request indices)
+    vocode    optional callable(list of (global index, tokens)) -> dict index -> payload (the vocoder stage of this rank)
+    """
+
+    def __init__(self, decoder, slots: int = 32, chunk: int = 2, group=None, store=None):
+        self.decoder, self.slots, self.chunk, self.group = decoder, int(slots), int(chunk), group
+        self.store = store if store is not None else (_default_store() if _dist_on(group) else None)
+        self.rank = dist.get_rank(group) if _dist_on(group) else 0
+        self.world = dist.get_world_size(group) if _dist_on(group) else 1
+        self.last_taken: List[int] = []
+
+    def _source(self, costs: Sequence[float]) -> RequestSource:
+        order = lpt_order(costs)
+        run = next(_RUN_COUNTER)        # SPMD: every rank makes the same sequence of runs -> the same key
+        if self.world == 1:
+            return RequestSource(order, None, chunk=len(order) or 1)
+        if self.store is None:          # no store: static length-balanced partition (scheduler.shard_indices)
+            from .scheduler import shard_indices
+            mine = set(shard_indices([int(c) for c in costs], self.world, self.rank))
+            return RequestSource([i for i in order if i in mine], None, chunk=len(order) or 1)
+        return RequestSource(order, self.store, key="gsv/cursor/%d" % run, chunk=self.chunk)
+
+    def run_gpt(self, xs, ys, berts, costs: Optional[Sequence[float]] = None, **sampling):
+        """-> (pred, idx): this rank's finished requests, completion order, GLOBAL indices"""
+        if costs is None:
+            costs = [int(x.shape[0]) for x in xs]
+        src = self._source(costs)
+        pred, idx = self.decoder.infer_batched(xs, ys, berts, source=src, slots=self.slots, **sampling)
+        self.last_taken = list(src.taken)
+        return pred, idx
+
+    def gather(self, local: Dict[int, object], n_total: int, dst: Optional[int] = None) -> Optional[List[object]]:
+        """index -> payload of this rank  =>  the full list in global index order (on `dst`, or on every rank)"""
+        if self.world == 1:
+            parts = [local]
+        elif dst is None:
+            parts = [None] * self.world
+            dist.all_gather_object(parts, local, group=self.group)
+        else:
+            parts = [None] * self.world if self.rank == dst else None
+            dist.gather_object(local, parts, dst=dst, group=self.group)
+            if parts is None:
+                return None
+        out: List[object] = [None] * n_total
+        seen = 0
+        for p in parts:
+            for i, v in p.items():
+                if out[i] is not None:
+                    raise RuntimeError("request %d was produced by two ranks" % i)
+                out[i] = v
+                seen += 1
+        if seen != n_total:
+            raise RuntimeError("gather: %d of %d requests returned" % (seen, n_total))
+        return out
+
+    def run(self, xs, ys, berts, costs=None, vocode: Optional[Callable] = None, dst: Optional[int] = None, **sampling):
+        """GPT on this rank's share, optional per-rank vocoder stage, gather in input order."""
+        pred, idx = self.run_gpt(xs, ys, berts, costs, **sampling)
+        items = list(zip(idx.tolist(), pred))
+        local = vocode(items) if vocode is not None else {int(i): p.cpu() for i, p in items}
+        return self.gather(local, len(xs), dst=dst)

@@ -31,6 +31,21 @@ from .sovits import SynthesizerTrn
 from .t2s import Text2SemanticDecoder
 
 HEAD2VERSION = {b"01": "v2", b"05": "v2Pro", b"06": "v2ProPlus"}
+# md5 of the first 8 KiB of the official pretrained s2G*.pth files (they start with b"PK", so the two-byte tag says
+# nothing): reference Loader.py:22-40
+HASH_PRETRAINED = {
+    "dc3c97e17592963677a4a1681f30c653": "v2",         # s2G488k.pth
+    "6642b37f3dbb1f76882b69937c95a5f3": "v2",         # s2G2333K.pth
+    "c7e9fce2223f3db685cdfa1e6368728a": "v2Pro",      # s2Gv2Pro.pth
+    "66b313e39455b57ab1b0bc0b239c9d0a": "v2ProPlus",  # s2Gv2ProPlus.pth
+}
+
+
+def get_hash_from_file(path) -> str:
+    """Loader.py:35-40"""
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.md5(f.read(8192)).hexdigest()
 
 _GPT_KEY_MAP = [
     ("self_attn.in_proj_weight", "qkv.weight"), ("self_attn.in_proj_bias", "qkv.bias"),
@@ -83,7 +98,9 @@ def _synthetic(spec: str):
     return u.netloc, q
 
 
-def get_gpt_weights(gpt_path, tts_config) -> Gpt:
+def read_gpt_checkpoint(gpt_path):
+    """(config, state dict under the lite names): what the reference's module holds after Loader.get_gpt_weights
+    (:111-170) has loaded `gpt_path`; device-free, so that it can be compared with the reference on a CPU"""
     gpt_path = str(gpt_path)
     if gpt_path.startswith("synthetic://"):
         _, q = _synthetic(gpt_path)
@@ -98,6 +115,11 @@ def get_gpt_weights(gpt_path, tts_config) -> Gpt:
         blob = torch.load(gpt_path, map_location="cpu", weights_only=False)
         config = blob["config"]
         weights = remap_gpt_keys(blob["weight"], config["model"]["n_layer"])
+    return config, weights
+
+
+def get_gpt_weights(gpt_path, tts_config) -> Gpt:
+    config, weights = read_gpt_checkpoint(gpt_path)
     model = Text2SemanticDecoder(config)
     model.load_state_dict(weights)
     model.eval()
@@ -106,11 +128,14 @@ def get_gpt_weights(gpt_path, tts_config) -> Gpt:
 
 
 def read_sovits_file(path):
-    """handles the 2-byte version header that replaces b"PK" (reference Loader.py:42-57)"""
+    """handles the 2-byte version header that replaces b"PK", and the md5 table of the official pretrained files
+    (reference Loader.py:42-57)"""
     with open(path, "rb") as f:
         head = f.read(2)
         rest = f.read()
     version = HEAD2VERSION.get(head)
+    if version is None:
+        version = HASH_PRETRAINED.get(get_hash_from_file(path))
     data = (b"PK" + rest) if head != b"PK" else (head + rest)
     return torch.load(io.BytesIO(data), map_location="cpu", weights_only=False), version
 
@@ -138,7 +163,9 @@ def _build_sovits(hps: dict, weights: dict, tts_config) -> Sovits:
     return Sovits(vq, hp)
 
 
-def get_sovits_weights(sovits_path, tts_config) -> Sovits:
+def read_sovits_checkpoint(sovits_path):
+    """(hps dict with the version resolved, state dict with the Generator's weight norm folded): what the reference's
+    module holds after Loader.get_sovits_weights (:59-103); device-free"""
     sovits_path = str(sovits_path)
     if sovits_path.startswith("synthetic://"):
         _, q = _synthetic(sovits_path)
@@ -146,12 +173,12 @@ def get_sovits_weights(sovits_path, tts_config) -> Sovits:
         seed = int(q.get("seed", 1234))
         weights = {k: torch.from_numpy(v) for k, v in synth.sovits_weights(hps, seed=seed).items()}
         weights.update({k: torch.from_numpy(v) for k, v in synth.ref_audio_weights(hps, seed=seed).items()})
-        return _build_sovits(hps, weights, tts_config)
+        return hps, weights
     if os.path.isdir(sovits_path):
         from safetensors.torch import load_file
         with open(os.path.join(sovits_path, "hps.json")) as f:
             hps = json.load(f)
-        return _build_sovits(hps, load_file(os.path.join(sovits_path, "model.safetensors")), tts_config)
+        return hps, load_file(os.path.join(sovits_path, "model.safetensors"))
     blob, version = read_sovits_file(sovits_path)
     hps = json.loads(json.dumps(blob["config"], default=lambda o: dict(o)))
     hps["model"]["semantic_frame_rate"] = "25hz"
@@ -160,7 +187,12 @@ def get_sovits_weights(sovits_path, tts_config) -> Sovits:
         if version not in ("v2", "v2Pro", "v2ProPlus"):
             raise ValueError("The SoVITS checkpoint is not a v2 / v2Pro / v2ProPlus model")
     hps["model"]["version"] = version
-    return _build_sovits(hps, blob["weight"], tts_config)
+    return hps, fold_dec_weight_norm(blob["weight"])
+
+
+def get_sovits_weights(sovits_path, tts_config) -> Sovits:
+    hps, weights = read_sovits_checkpoint(sovits_path)
+    return _build_sovits(hps, weights, tts_config)
 
 
 def convert_to_safetensors(checkpoint_path, output_dir=None) -> str:

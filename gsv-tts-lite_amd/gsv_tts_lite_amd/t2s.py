@@ -90,9 +90,6 @@ class Text2SemanticDecoder:
         self.suppressed_tokens = [280, 486, self.EOS]
         self.cuda_graph_buckets = {}
         self.use_graph = True
-        # persistent decode step (csrc/t2s_megastep.h, batch <= 4): correct and stress-tested, but measured
-        # equal-to-slightly-slower than the per-layer graph (hand-off ~= kernel boundary), so off by default
-        self.use_megastep = False
         self._eos_pipe = None
         self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
         self._weights = None
@@ -120,6 +117,8 @@ class Text2SemanticDecoder:
             raise RuntimeError("load_state_dict() first")
         L = N.lib()
         self.device, self.dtype = device, dtype
+        # torch.float8_e4m3fn = GSV_FP8: e4m3 QKV / FFN weights in the batched decode step; K/V cache and the rest bf16
+        kv_dtype = torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype
         cfg = N.T2SConfig(self.num_layers, self.model_dim, self.num_head, self.vocab_size, self.EOS, 4000,
                           self.phoneme_vocab_size, N.dtype_code(dtype))
         h = ctypes.c_void_p()
@@ -137,6 +136,7 @@ class Text2SemanticDecoder:
             d = t.detach().to(device=device, dtype=torch.float32).contiguous()
             N.check(L.gsv_t2s_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
         N.check(L.gsv_t2s_finalize(h, stream))
+        self.batched_min = int(L.gsv_t2s_batched_min(h))   # batch size from which the step is the batched MFMA chain
 
         for batch_size, max_kv in gpt_cache:
             self.cuda_graph_buckets.setdefault(batch_size, [])
@@ -144,8 +144,8 @@ class Text2SemanticDecoder:
                 self.cuda_graph_buckets[batch_size].append(max_kv)
         max_elem = max(b * max(ts) for b, ts in self.cuda_graph_buckets.items())
         numel = self.num_layers * max_elem * self.model_dim
-        self.k_cache_root = torch.zeros(numel, dtype=dtype, device=device)
-        self.v_cache_root = torch.zeros(numel, dtype=dtype, device=device)
+        self.k_cache_root = torch.zeros(numel, dtype=kv_dtype, device=device)
+        self.v_cache_root = torch.zeros(numel, dtype=kv_dtype, device=device)
         dh = self.model_dim // self.num_head
         for b in sorted(self.cuda_graph_buckets):
             ts = sorted(self.cuda_graph_buckets[b])
@@ -239,20 +239,18 @@ class Text2SemanticDecoder:
         return self._rt[batch]["hidden"]
 
     def _decode(self, batch, n):
-        mode = (1 if self.use_graph else 0) | (2 if self.use_megastep else 0)
-        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, mode, N.current_stream_ptr(self.device)))
-
-    def megastep_error(self) -> bool:
-        return N.lib().gsv_t2s_megastep_error(self._h) != 0
+        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, 1 if self.use_graph else 0, N.current_stream_ptr(self.device)))
 
     def _flush(self, batch):
         N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))
 
-    def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0, top_p=1.0):
-        """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling"""
+    def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0, top_p=1.0,
+                 suppress_first=False):
+        """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling; suppress_first: the
+        prefill's sample never takes 280 / 486 / EOS whatever suppress_steps is (infer / infer_stream, t2s_model.py:415-416)"""
         lo, hi = int(seed) & 0x7fffffff, (int(seed) >> 31) & 0x7fffffff
-        rt["ctl"].copy_(torch.tensor([int(mode), int(suppress_steps), int(rep_enabled), 0, int(top_k or 0), lo, hi, 0],
-                                     dtype=torch.int32))
+        rt["ctl"].copy_(torch.tensor([int(mode), int(suppress_steps), int(rep_enabled), 0, int(top_k or 0), lo, hi,
+                                      int(bool(suppress_first))], dtype=torch.int32))
         rt["fctl"].copy_(torch.tensor([float(rep), float(temperature), float(1.0 if top_p is None else top_p), 0.0],
                                       dtype=torch.float32))
 
@@ -287,7 +285,8 @@ class Text2SemanticDecoder:
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1   # the device loop serves greedy and device sampling alike
         rep_on = repetition_penalty != 1.0
-        self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p)
+        self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p,
+                      suppress_first=True)
         rt["seen"].zero_()
         if rep_on:
             rt["seen"][0, y[0].to(self.device)] = 1
@@ -363,7 +362,8 @@ class Text2SemanticDecoder:
                 raise RuntimeError("no decode iterations: prompt fills the largest bucket")
             mode, seed = self._sampling_mode(top_k, top_p, generator)
             rep_on = repetition_penalty != 1.0
-            self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p)
+            self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p,
+                          suppress_first=True)
             rt["seen"].zero_()
             if rep_on:
                 rt["seen"][0, y[0].to(self.device)] = 1
@@ -407,26 +407,52 @@ class Text2SemanticDecoder:
     @torch.inference_mode()
     def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
                       top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
-                      repetition_penalty: float = 1.35, check_interval: int = 5, generator=None):
-        """t2s_model.py:555-734: continuous batching over the slots of one batch-size family."""
+                      repetition_penalty: float = 1.35, check_interval: int = 5, generator=None,
+                      source=None, slots: int = None):
+        """t2s_model.py:555-734: continuous batching over the slots of one batch-size family.
+
+        `source` (engine.RequestSource) replaces "the next request is x[cur]" (:696-700) by "the next request is
+        whatever the shared queue hands this rank": x / y / bert_feature are then the GLOBAL lists, the returned
+        indices are global, and `slots` names the batch-size family to run (default: as the reference, the
+        smallest family that holds len(x))."""
         B = len(x)
         sizes = sorted(self.cuda_graph_buckets)
-        batch_size = sizes[-1]
-        for s in sizes:
-            if s >= B:
-                batch_size = s
+        if slots is not None:
+            if slots not in self.cuda_graph_buckets:
+                raise ValueError("no KV bucket family of %d slots (have %s)" % (slots, sizes))
+            batch_size = slots
+        else:
+            batch_size = sizes[-1]
+            for s in sizes:
+                if s >= B:
+                    batch_size = s
+                    break
+        if source is None:
+            _it = iter(range(B))
+            nxt = lambda: next(_it, None)
+        else:
+            nxt = source.next
+        first = []
+        while len(first) < batch_size:
+            c = nxt()
+            if c is None:
                 break
+            first.append(c)
+        exhausted = len(first) < batch_size
         rt = self._rt[batch_size]
         buckets = self.cuda_graph_buckets[batch_size]
         caps = [b.max_kv_cache for b in buckets]
-        actual = min(B, batch_size)
+        actual = len(first)
+        dev = self.device
+        if actual == 0:
+            return [], torch.zeros(0, dtype=torch.int64, device=dev)
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1
         self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed, top_p)
-        dev = self.device
         rt["kv_len"].zero_()
         rt["x_len"].zero_()
-        xy, xl, yl, x_lens_h, y_lens_h = self.embed_prompt(x[:actual], y[:actual], bert_feature[:actual])
+        xy, xl, yl, x_lens_h, y_lens_h = self.embed_prompt([x[c] for c in first], [y[c] for c in first],
+                                                           [bert_feature[c] for c in first])
         lmax = xy.shape[1]
         bucket_i = len(caps) - 1
         for i, c in enumerate(caps):
@@ -445,10 +471,9 @@ class Text2SemanticDecoder:
             rt["tok_override"].copy_(tok)
 
         pred, orig = [], []
-        slot_orig = list(range(batch_size))
+        slot_orig = first + [-1] * (batch_size - actual)
         steps = [0] * batch_size
         ignore = [i >= actual for i in range(batch_size)]
-        cur = actual
         stop = False
         idx = 0
         while not stop:
@@ -510,7 +535,9 @@ class Text2SemanticDecoder:
                     if c >= mx + check_interval:
                         bucket_i = j
                         break
-                if cur == B:
+                cur = None if exhausted else nxt()
+                if cur is None:
+                    exhausted = True
                     ignore[i] = True
                     if all(ignore):
                         stop = True
@@ -522,7 +549,6 @@ class Text2SemanticDecoder:
                     refill.append((i, cur))
                     kv_h[i] = n_new            # what the slot holds once refilled: the next slots' bucket choice sees it
                     slot_orig[i] = cur
-                    cur += 1
             if refill and not stop:
                 # rows are independent through the prefill, so the window's refills run as ONE packed prefill into their
                 # scattered slots (gsv_t2s_prefill_slots) instead of one 170-launch chain per sequence

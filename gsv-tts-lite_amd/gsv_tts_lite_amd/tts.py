@@ -35,6 +35,7 @@ import numpy as np
 import torch
 
 from . import subtitles as sub
+from .batchmath import balance_order, split_bounds
 from .loader import Gpt, Sovits, convert_to_safetensors, get_gpt_weights, get_sovits_weights
 
 log = logging.getLogger("gsv_tts_lite_amd")
@@ -108,6 +109,31 @@ def cut_text(text: str, minlen: int = 10) -> list:
     return [s.strip() for s in out if s.strip()]
 
 
+class _EngineLock:
+    """One inference at a time per TTS (the reference's `_infer_lock`, TTS.py:145).  A streaming generator owns the
+    engine -- KV cache, enc_p overlap state -- from its first chunk to its last, so the lock stays held across its
+    yields; what must not happen is the SAME thread calling back in between two chunks and waiting for itself forever:
+    that raises instead.  An abandoned generator releases the lock when it is closed or collected."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._owner = None
+
+    def __enter__(self):
+        me = threading.get_ident()
+        if self._owner == me:
+            raise RuntimeError("this TTS is in the middle of an infer_stream() on this thread: exhaust or close() the "
+                               "generator before starting another inference")
+        self._lock.acquire()
+        self._owner = me
+        return self
+
+    def __exit__(self, *exc):
+        self._owner = None
+        self._lock.release()
+        return False
+
+
 class TTS:
     def __init__(self, gpt_cache=[(1, 512), (1, 768), (1, 1024), (4, 512), (4, 1024)], sovits_cache=[50, 55],
                  models_dir: str = None, device: str = None, dtype: str = None, use_flash_attn: bool = False,
@@ -133,7 +159,7 @@ class TTS:
         self.prompt_audio_cache: dict = {}
         self.samplerate, self.gpt_hz, self.sovits_hz = 32000, 25, 50
         self.audio_queue = None
-        self._infer_lock = threading.Lock()
+        self._infer_lock = _EngineLock()
         self._text_frontend = None
 
     # ------------------------------------------------------------------ model management
@@ -281,6 +307,47 @@ class TTS:
             self.cache_prompt_audio(path, text)
         c = self.prompt_audio_cache[path]
         return c["prompt"], c["phones1"], c["bert1"]
+
+    # ------------------------------------------------------------------ multi-GPU (one process per GPU, engine.py)
+    def _engine(self, t2s):
+        """the continuous-batching engine of this process group, or None in a single process"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        from .engine import ContinuousBatchingEngine, SpeakerBook
+        if getattr(self, "_speaker_book", None) is None:
+            self._speaker_book = SpeakerBook(self.tts_config.device)
+        return ContinuousBatchingEngine(t2s, slots=max(t2s.cuda_graph_buckets), chunk=2)
+
+    def _sync_speakers(self, prompt_paths, prompt_texts, spk_paths, sovits_model, src=0):
+        """SPMD: every rank calls infer_batched with the same arguments; the reference-audio models ran on rank `src`
+        only (cache_spk_audio / cache_prompt_audio there).  Each prompt / speaker key is broadcast once, ever."""
+        import torch.distributed as dist
+        book, me = self._speaker_book, dist.get_rank()
+        dev = self.tts_config.device
+        for p, text in dict(zip(prompt_paths, prompt_texts)).items():
+            key = "prompt:%s" % p
+            if key in book.entries:
+                continue
+            c = self.prompt_audio_cache.get(p) if me == src else None
+            if me == src and c is None:
+                self.cache_prompt_audio(p, text)
+                c = self.prompt_audio_cache[p]
+            got = book.sync(key, [c["prompt"], torch.tensor(c["phones1"], dtype=torch.int64, device=dev), c["bert1"]] if me == src else None, src=src)
+            if me != src:
+                self.prompt_audio_cache[p] = {"prompt": got[0], "phones1": got[1].tolist(), "bert1": got[2], "text": text}
+        names = []
+        for sp in spk_paths:
+            names += list(sp.keys()) if isinstance(sp, dict) else [sp]
+        for p in dict.fromkeys(names):
+            key = "ge:%s:%s" % (sovits_model, p)
+            if key in book.entries:
+                continue
+            if me == src and (p not in self.spk_audio_cache or sovits_model not in self.spk_audio_cache[p]["ge"]):
+                self.cache_spk_audio(p, sovits_model=sovits_model)
+            got = book.sync(key, [self.spk_audio_cache[p]["ge"][sovits_model]] if me == src else None, src=src)
+            if me != src:
+                self.spk_audio_cache.setdefault(p, {"ge": {}})["ge"][sovits_model] = got[0]
 
     # ------------------------------------------------------------------ trimming (TTS.py:1629-1664)
     @staticmethod
@@ -531,6 +598,10 @@ class TTS:
                     vq.enc_p.y_overlap = None
                     cur_text_l += len(text_cut)
             finally:
+                try:   # an abandoned stream must not leave its cross-fade state to the next one (other speed -> other shape)
+                    self.sovits_models[sovits_model].vq_model.enc_p.y_overlap = None
+                except Exception:
+                    pass
                 self._empty_cache()
 
     @torch.inference_mode()
@@ -569,6 +640,9 @@ class TTS:
                     for c in cut_text(t, cut_minlen):
                         segs.append(c)
                         seg2orig.append(i)
+                eng = self._engine(t2s)     # None in a single process
+                if eng is not None:         # reference-speaker tensors exist on rank 0 only: ONE broadcast per new key
+                    self._sync_speakers(prompt_audio_paths, prompt_audio_texts, spk_audio_paths, sovits_model)
                 feats = [self._phones_and_bert(s) for s in segs]
                 ids, prompts, berts, ges, phones2_all = [], [], [], [], []
                 word2ph_all = [f[1] for f in feats]
@@ -582,15 +656,15 @@ class TTS:
                     ges.append(self._ge_for(spk_audio_paths[o], sovits_model).squeeze(0))
                     phones2_all.append(ph2)
 
-                pred, orig_idx = t2s.infer_batched(ids, prompts, berts, top_k=top_k, top_p=top_p,
-                                                   temperature=temperature, repetition_penalty=repetition_penalty)
+                if eng is None:
+                    pred, orig_idx = t2s.infer_batched(ids, prompts, berts, top_k=top_k, top_p=top_p,
+                                                       temperature=temperature, repetition_penalty=repetition_penalty)
+                else:   # this rank's share of the segment queue (engine.py): global indices come back
+                    pred, orig_idx = eng.run_gpt(ids, prompts, berts, costs=[int(i.shape[0]) for i in ids], top_k=top_k, top_p=top_p,
+                                                 temperature=temperature, repetition_penalty=repetition_penalty)
                 lengths = torch.tensor([len(p) for p in pred])
-                order = torch.argsort(lengths)
+                order = balance_order(lengths)                     # short/long interleave, TTS.py:705-716
                 m = len(order)
-                inter = torch.zeros(m, dtype=torch.long)          # short/long interleave, TTS.py:709-716
-                inter[0::2] = torch.arange((m + 1) // 2)
-                inter[1::2] = torch.arange((m + 1) // 2, m).flip(0)
-                order = order[inter]
                 pred = [pred[i] for i in order.tolist()]
                 orig_idx = orig_idx.cpu()[order]
                 lengths = lengths[order]
@@ -631,20 +705,24 @@ class TTS:
                             part[-1]["end_s"] -= t / self.samplerate
                             subs_out.append(sub.sub2text_index(part, norm_all[o], segs[o]))
                         continue
-                    pos = 0.0
-                    for l in ln.tolist():
-                        nxt = pos + l * 2 * vq.samples_per_frame / speed
-                        a = audio[int(pos):int(nxt)]
-                        pos = nxt
+                    for lo, hi in split_bounds(ln.tolist(), vq.samples_per_frame, speed):   # TTS.py:806-811
+                        a = audio[lo:hi]
                         h, t = self._find_head_threshold_offsets(a), self._find_tail_threshold_offsets(a)
                         audios.append(a[h:-t].float().cpu().numpy())
 
-                ordered = [None] * len(audios)
-                ordered_subs = [None] * len(audios)
-                for cur, o in enumerate(orig_idx.tolist()):
-                    ordered[o] = audios[cur]
-                    if return_subtitles:
-                        ordered_subs[o] = subs_out[cur]
+                if eng is None:
+                    ordered = [None] * len(audios)
+                    ordered_subs = [None] * len(audios)
+                    for cur, o in enumerate(orig_idx.tolist()):
+                        ordered[o] = audios[cur]
+                        if return_subtitles:
+                            ordered_subs[o] = subs_out[cur]
+                else:   # every rank vocoded its own segments; all ranks assemble the full result (TTS.py:820-865)
+                    local = {int(o): (audios[cur], subs_out[cur] if return_subtitles else None)
+                             for cur, o in enumerate(orig_idx.tolist())}
+                    full = eng.gather(local, len(segs))
+                    ordered = [a for a, _ in full]
+                    ordered_subs = [sb for _, sb in full]
                 per_text = [[] for _ in range(n)]
                 per_text_subs = [[] for _ in range(n)]
                 last_orig, cur_text_l = None, 0

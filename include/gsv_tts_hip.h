@@ -35,6 +35,8 @@ extern "C" {
 
 #define GSV_F32 0         /* fp32 weights/KV/activations: the bit-exact-token parity mode */
 #define GSV_BF16 1        /* bf16 weights + KV (+ bf16 vocoder activations), fp32 accumulate */
+#define GSV_FP8 2         /* gsv_t2s only: GSV_BF16 plus OCP e4m3 QKV / FFN weights (per-output-channel scale) and e4m3
+                             activations on the fp8 MFMA in the batched decode step; K/V cache, out-proj, prefill: bf16 */
 
 int gsv_version(void);
 const char* gsv_last_error(void);
@@ -48,7 +50,7 @@ typedef struct {
     int n_layer, hidden, n_head, vocab, eos; /* config["model"], t2s_model.py:159-168 */
     int n_pos;                               /* rows of the sinusoidal tables (4000, t2s_model.py:212) */
     int n_phoneme;                           /* phoneme_vocab_size */
-    int dtype;                               /* GSV_F32 | GSV_BF16 */
+    int dtype;                               /* GSV_F32 | GSV_BF16 | GSV_FP8 */
 } gsv_t2s_config;
 
 /* replaces Text2SemanticDecoder.__init__ + Loader.get_gpt_weights (gsv_tts/Loader.py:111-170) */
@@ -83,8 +85,9 @@ typedef struct {
     float* logits;          /* [B][vocab] last logits after suppression/penalty (host sampling) */
     float* hidden;          /* [B][hidden] last final hidden state (Bucket.graph_xy_dec) */
     int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] == 1 */
-    int32_t* ctl;           /* [8]   {sample_mode, suppress_steps, rep_enabled, drop_eos_col_steps, top_k, seed_lo,
-                               seed_hi, -}; sample_mode 0 = greedy argmax, 1 = tok_override (host sampling),
+    int32_t* ctl;           /* [8]   {sample_mode, suppress_steps, rep_enabled, -, top_k, seed_lo, seed_hi,
+                               suppress_first}; suppress_first != 0: the prefill's sample never takes 280 / 486 / EOS
+                               (infer / infer_stream, t2s_model.py:415-416), independent of suppress_steps; sample_mode 0 = greedy argmax, 1 = tok_override (host sampling),
                                2 = device sampling: temperature fctl[1], top-k ctl[4] (<= 0: off; ties with the
                                k-th value are kept, GPT/utils.py:45-48), then argmax(softmax / Exp(1))
                                (utils.py:56-59) with a counter-based noise stream keyed by
@@ -122,22 +125,28 @@ int gsv_t2s_prefill_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows
 
 /* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
  * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
- * final hidden state to state.hidden and bumps kv_len.  No sampling. */
+ * final hidden state to state.hidden and bumps kv_len.  No sampling.  Takes the path gsv_t2s_decode would take for
+ * this batch size (per-sequence kernels, or the batched chain from gsv_t2s_batched_min sequences on). */
 int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
 
 /* The AR hot loop body (t2s_model.py:430-456 / 637-653, 727-728) `n_steps` times, all on device:
  * take the pending token (greedy argmax of the penalised logits, or tok_override), record it in
  * pre_tokens[b][kv_len[b]], build emb + alpha*pe[kv_len - x_len], run the layers, bump kv_len,
  * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
- * `use_graph` is a bit set: bit 0 = replay the step from a hipGraph captured on first use; bit 1 =
- * persistent step (all layers in one launch with in-kernel hand-offs; batch <= 4, else ignored). */
+ * `use_graph` != 0: replay the step from a hipGraph captured on first use (one per batch size).
+ * From a tuned batch size on (bf16 / fp8 handles) the step is the batched chain of csrc/t2s_batch.h: weights
+ * streamed once per step through MFMA GEMMs instead of once per sequence. */
 int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream);
-/* 1 if a hand-off of the persistent step ever hit its spin bound on this handle (results invalid) */
-int gsv_t2s_megastep_error(gsv_t2s* h);
-/* Measurement aid (bench.py `roofline`): average duration in ms of ONE launch of each decode-step
- * kernel class {attn, ffn, logits, token}, timed with hipEvents on `stream` around `iters`
- * back-to-back sweeps over all layers' launches of that class on the live state (every layer
- * streams its own weights, as in a real step).  out_ms: host float[4].  Leaves kv_len untouched. */
+/* Batch size from which gsv_t2s_decode runs the batched chain (INT_MAX on fp32 handles: never).  Tests mirror the
+ * choice in the oracle, whose reduced-precision modes round the operands each path rounds. */
+int gsv_t2s_batched_min(gsv_t2s* h);
+/* Measurement aid (bench.py `roofline`): average time in ms of ONE launch of each per-sequence decode-step
+ * kernel class {attn, ffn, logits, token}: the class's launches over all layers (every layer streams its own
+ * weights, as in a real step) are captured into a hipGraph and replayed `iters` times between two hipEvents on
+ * `stream` -- no host launch cost, but the dependent-launch gap every kernel of a real step pays is included.
+ * out_ms: host float[4].  kv_len is left untouched; the sweeps rewrite the K/V row AT kv_len, the pending
+ * token's pre_tokens / seen / eos_at entries and the partial-sum scratch, all of which the next real step
+ * (or prefill) overwrites -- call it between utterances, not inside one. */
 int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream);
 /* Bring-up aid: when `buf` (device, >= 16 x uint64) is non-null the LAST layer's attn/ffn kernels
  * write shader-clock timestamps of their phases into it (slots 0-6 attn, 8-12 ffn). */

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "gsv-tts-lite_amd"))
 
-from ref_harness import import_reference, reference_functions  # noqa: E402
+from ref_harness import import_reference, reference_functions, reference_statements  # noqa: E402
 from gsv_tts_lite_amd import synth  # noqa: E402
 
 import tqdm  # noqa: E402
@@ -387,12 +387,66 @@ def gen_refaudio(Syn):
     np.savez_compressed(os.path.join(GOLD, "refaudio.npz"), seed=1234, **META, **out)
 
 
+from gen_golden_inputs import FACADE_AUDIO, FACADE_LENGTHS, FACADE_SPLITS, facade_audio  # noqa: E402
+
+
+def gen_facade():
+    """The facade's own arithmetic, executed from the reference's source (TTS.py cannot be imported here):
+      TTS._find_head_threshold_offsets / _find_tail_threshold_offsets  TTS.py:1629-1662  (functions)
+      the sort + both-ends interleave of infer_batched                  TTS.py:705-720   (inline statements)
+      the split / trim loop of infer_batched                            TTS.py:806-816   (inline statements)
+    Inputs are regenerated from seeds (facade_audio, FACADE_LENGTHS); only outputs are stored."""
+    tf = reference_functions("gsv_tts/TTS.py", ["_find_head_threshold_offsets", "_find_tail_threshold_offsets"], {"torch": torch})
+    out = {}
+    head, tail = [], []
+    for case in FACADE_AUDIO:
+        a = tt(facade_audio(*case))
+        head.append(tf["_find_head_threshold_offsets"](None, a))
+        tail.append(tf["_find_tail_threshold_offsets"](None, a))
+    out["head"], out["tail"] = np.array(head, np.int64), np.array(tail, np.int64)
+    sort_code = reference_statements("gsv_tts/TTS.py", "infer_batched", "semantic_lengths = torch.tensor(", "semantic_lengths = semantic_lengths[idx_map]")
+
+    class Cfg:
+        device = torch.device("cpu")
+
+    class Self:
+        tts_config = Cfg()
+        _find_head_threshold_offsets = tf["_find_head_threshold_offsets"]
+        _find_tail_threshold_offsets = tf["_find_tail_threshold_offsets"]
+    for k, lens in enumerate(FACADE_LENGTHS):
+        ns = {"torch": torch, "self": Self(), "pred_semantic": [torch.zeros(l, dtype=torch.int64) for l in lens],
+              "semantic_orig_idx": torch.arange(100, 100 + len(lens))}
+        exec(sort_code, ns)
+        out["order_%d" % k] = ns["idx_map"].numpy()
+        out["orig_%d" % k] = ns["semantic_orig_idx"].numpy()
+    split_code = reference_statements("gsv_tts/TTS.py", "infer_batched", "last_actual_len = 0", "for j in range(len(semantic_list))")
+
+    class VQ:
+        samples_per_frame = 640
+    for k, (lens, speed) in enumerate(FACADE_SPLITS):
+        total = int(sum(lens) * 2 * 640 / speed) + 1
+        audio = tt(facade_audio(20 + k, total, 0, 0, 0.4))
+        pos = 0
+        for i, l in enumerate(lens):       # a quiet gap at the head of every utterance, so that the trims differ
+            audio[int(pos): int(pos) + 700 * (i + 1)] = 0
+            pos += l * 2 * 640 / speed
+        ns = {"torch": torch, "np": np, "self": Self(), "semantic_list": [None] * len(lens), "curr_lengths": torch.tensor(lens),
+              "vq_model": VQ(), "speed": speed, "audio_batch": audio, "generated_audios": []}
+        exec(split_code, ns)
+        out["split_%d_lens" % k] = np.array(lens, np.int64)
+        out["split_%d_speed" % k] = np.float64(speed)
+        out["split_%d_sizes" % k] = np.array([len(a) for a in ns["generated_audios"]], np.int64)
+        out["split_%d_sums" % k] = np.array([float(np.abs(a).astype(np.float64).sum()) for a in ns["generated_audios"]])
+    np.savez_compressed(os.path.join(GOLD, "facade.npz"), **META, **out)
+    print("facade: head", head, "tail", tail)
+
+
 if __name__ == "__main__":
     tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles", "refaudio"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles", "refaudio", "facade"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
@@ -402,3 +456,4 @@ if __name__ == "__main__":
     if "decode" in which: gen_decode(Syn)
     if "subtitles" in which: gen_subtitles()
     if "refaudio" in which: gen_refaudio(Syn)
+    if "facade" in which: gen_facade()

@@ -49,6 +49,52 @@ ORC_API void orc_set_num_threads(int n) {
 #endif
 }
 
+/* ------------------------------------------------------------------ reduced-precision modes
+ * The product's production modes store weights and K/V in bf16 (and, GSV_FP8, the QKV / FFN operands in OCP
+ * e4m3) with fp32 accumulation.  To pin THOSE kernels tightly -- same operands, only the summation order
+ * differs -- the restatement can round at the same places (weights are rounded by the caller):
+ *   ORC_R_KV      K/V rows rounded through bf16 when written to the cache (what later steps read back)
+ *   ORC_R_LIN     the input rows of every linear rounded to bf16 (MFMA operand type of the prompt / batched GEMMs)
+ *   ORC_R_ATTN    prompt attention: q and the un-normalised probabilities rounded to bf16 (MFMA flash attention)
+ *   ORC_R_FP8     qkv / mlp.0 / mlp.2 inputs rounded to e4m3 at unit scale, saturating (batched fp8 step)
+ * 0 = the fp32 reference arithmetic. */
+#define ORC_R_KV 1
+#define ORC_R_LIN 2
+#define ORC_R_ATTN 4
+#define ORC_R_FP8 8
+static int g_round = 0;
+ORC_API void orc_set_rounding(int flags) { g_round = flags; }
+ORC_API int orc_get_rounding(void) { return g_round; }
+
+static inline float bf16r(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* OCP e4m3fn: 3 mantissa bits, exponent bias 7, max 448, subnormal step 2^-9; round to nearest even, saturating */
+static inline float e4m3r(float f) {
+    if (f != f) return f;
+    float a = fabsf(f);
+    if (a > 448.f) a = 448.f;
+    if (a < 0.015625f) {
+        a = rintf(a * 512.f) / 512.f;
+    } else {
+        int e;
+        (void)frexpf(a, &e);
+        float step = ldexpf(1.f, e - 4);
+        a = rintf(a / step) * step;
+        if (a > 448.f) a = 448.f;
+    }
+    return copysignf(a, f);
+}
+ORC_API void orc_round_bf16(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = bf16r(x[i]); }
+ORC_API void orc_round_e4m3(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = e4m3r(x[i]); }
+
 /* ------------------------------------------------------------------ basic ops */
 
 static inline float dotf(const float* a, const float* b, int n) {
@@ -124,17 +170,35 @@ static layer_t layer_at(const float* pack, int l, int D) {
     return L;
 }
 
+/* a linear of the GPT stack whose input rows are rounded per g_round (f8ok: one of the fp8 linears) */
+static void linear_r(const float* x, int M, int K, const float* w, const float* b, int N, float* y, int act, int f8ok) {
+    const int f8 = f8ok && (g_round & ORC_R_FP8);
+    if (!f8 && !(g_round & ORC_R_LIN)) {
+        orc_linear(x, M, K, w, b, N, y, act);
+        return;
+    }
+    float* xr = (float*)malloc(sizeof(float) * (size_t)M * K);
+    for (size_t i = 0; i < (size_t)M * K; ++i) xr[i] = f8 ? e4m3r(x[i]) : bf16r(x[i]);
+    orc_linear(xr, M, K, w, b, N, y, act);
+    free(xr);
+}
+
 /* tail of a block shared by prefill and decode: x = LN1(x + attn@Wo^T + bo); x = LN2(x + MLP(x)) */
 static void block_tail(const layer_t* L, int M, int D, float* x, const float* attn, float* tmp_d,
                        float* tmp_f) {
     int F = 4 * D;
-    orc_linear(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0);
+    linear_r(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0, 0);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln1_g, L->ln1_b, 1e-5f, x);
-    orc_linear(x, M, D, L->w1, L->b1, F, tmp_f, 1);
-    orc_linear(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0);
+    linear_r(x, M, D, L->w1, L->b1, F, tmp_f, 1, 1);
+    linear_r(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0, 1);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln2_g, L->ln2_b, 1e-5f, x);
+}
+
+static inline void kv_store(float* dst, const float* src, int n) {
+    if (g_round & ORC_R_KV) for (int i = 0; i < n; ++i) dst[i] = bf16r(src[i]);
+    else memcpy(dst, src, sizeof(float) * n);
 }
 
 /*
@@ -154,7 +218,7 @@ ORC_API void orc_t2s_decode(const float* pack, int n_layer, int D, int H, int B,
     float* tmp_f = (float*)malloc(sizeof(float) * (size_t)B * 4 * D);
     for (int l = 0; l < n_layer; ++l) {
         layer_t L = layer_at(pack, l, D);
-        orc_linear(x, B, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0);
+        linear_r(x, B, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0, 1);
 #pragma omp parallel for collapse(2) schedule(static)
         for (int b = 0; b < B; ++b)
             for (int h = 0; h < H; ++h) {
@@ -163,8 +227,8 @@ ORC_API void orc_t2s_decode(const float* pack, int n_layer, int D, int H, int B,
                 float* K = kc + base;
                 float* V = vc + base;
                 const float* q = qkv + (size_t)b * 3 * D + h * Dh;
-                memcpy(K + (size_t)n * Dh, qkv + (size_t)b * 3 * D + D + h * Dh, sizeof(float) * Dh);
-                memcpy(V + (size_t)n * Dh, qkv + (size_t)b * 3 * D + 2 * D + h * Dh, sizeof(float) * Dh);
+                kv_store(K + (size_t)n * Dh, qkv + (size_t)b * 3 * D + D + h * Dh, Dh);
+                kv_store(V + (size_t)n * Dh, qkv + (size_t)b * 3 * D + 2 * D + h * Dh, Dh);
                 int len = n + 1;
                 float* s = (float*)malloc(sizeof(float) * len);
                 float mx = -INFINITY;
@@ -210,19 +274,24 @@ ORC_API void orc_t2s_prefill(const float* pack, int n_layer, int D, int H, int B
     float* tmp_f = (float*)malloc(sizeof(float) * M * 4 * D);
     for (int l = 0; l < n_layer; ++l) {
         layer_t L = layer_at(pack, l, D);
-        orc_linear(x, (int)M, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0);
+        linear_r(x, (int)M, D, L.qkv_w, L.qkv_b, 3 * D, qkv, 0, 0);
 #pragma omp parallel for collapse(2) schedule(static)
         for (int b = 0; b < B; ++b)
             for (int h = 0; h < H; ++h) {
                 size_t base = ((((size_t)l * Bc + (b0 + b)) * H + h) * (size_t)T) * Dh;
                 for (int t = 0; t < Lq; ++t) {
                     const float* r = qkv + ((size_t)b * Lq + t) * 3 * D;
-                    memcpy(kc + base + (size_t)t * Dh, r + D + h * Dh, sizeof(float) * Dh);
-                    memcpy(vc + base + (size_t)t * Dh, r + 2 * D + h * Dh, sizeof(float) * Dh);
+                    kv_store(kc + base + (size_t)t * Dh, r + D + h * Dh, Dh);
+                    kv_store(vc + base + (size_t)t * Dh, r + 2 * D + h * Dh, Dh);
                 }
                 float* s = (float*)malloc(sizeof(float) * Lq);
                 for (int i = 0; i < Lq; ++i) {
                     const float* q = qkv + ((size_t)b * Lq + i) * 3 * D + h * Dh;
+                    float qr[256];
+                    if ((g_round & ORC_R_ATTN) && Dh <= 256) {
+                        for (int d = 0; d < Dh; ++d) qr[d] = bf16r(q[d]);
+                        q = qr;
+                    }
                     const uint8_t* mr = mask + ((size_t)b * Lq + i) * Lq;
                     float mx = -INFINITY;
                     for (int t = 0; t < Lq; ++t) {
@@ -242,7 +311,7 @@ ORC_API void orc_t2s_prefill(const float* pack, int n_layer, int D, int H, int B
                         }
                     for (int t = 0; t < Lq; ++t)
                         if (mr[t]) {
-                            float p = s[t] / den;
+                            float p = ((g_round & ORC_R_ATTN) ? bf16r(s[t]) : s[t]) / den;
                             const float* vr = vc + base + (size_t)t * Dh;
                             for (int d = 0; d < Dh; ++d) o[d] += p * vr[d];
                         }

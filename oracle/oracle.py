@@ -124,14 +124,66 @@ def sine_pe(n_pos: int, dim: int) -> np.ndarray:
     return pe
 
 
+R_KV, R_LIN, R_ATTN, R_FP8 = 1, 2, 4, 8     # gsv_oracle.c ORC_R_*
+
+
+def round_bf16(a):
+    """fp32 -> nearest-even bf16 -> fp32 (what the product's bf16 weight / cache storage holds)"""
+    a = np.ascontiguousarray(a, np.float32).copy()
+    lib().orc_round_bf16(_fp(a), ctypes.c_long(a.size))
+    return a
+
+
+def round_e4m3(a):
+    """fp32 -> OCP e4m3fn (nearest even, saturating at 448) -> fp32"""
+    a = np.ascontiguousarray(a, np.float32).copy()
+    lib().orc_round_e4m3(_fp(a), ctypes.c_long(a.size))
+    return a
+
+
+def quant_e4m3_rows(w):
+    """the product's fp8 weight format: per output channel scale = max|row| / 448, row / scale -> e4m3; returns the
+    dequantised weights (what the contraction multiplies, up to the epilogue's scale factor) and the scales"""
+    w = np.ascontiguousarray(w, np.float32)
+    amax = np.abs(w).max(axis=1, keepdims=True)
+    scale = np.where(amax > 0, amax * np.float32(1.0 / 448.0), np.float32(1.0)).astype(np.float32)
+    q = round_e4m3(w * (np.float32(1.0) / scale))
+    return q, scale[:, 0]
+
+
 class T2SOracle:
-    def __init__(self, config, weights, gpt_cache):
+    """numerics: "fp32" = the reference's CPU arithmetic (the parity target);
+    "bf16" / "fp8" = the same restatement with the product's production roundings applied at the same places
+    (weights, K/V, GEMM operands -- module header of gsv_oracle.c), so that only the summation order separates
+    it from the HIP kernels: the tight pin of the kernels the bench times.  `batched_min` mirrors the library's
+    switch to the batched decode step (gsv_t2s_batched_min)."""
+
+    def __init__(self, config, weights, gpt_cache, numerics="fp32", batched_min=12):
         m = config["model"]
         self.D, self.H, self.NL = m["hidden_dim"], m["head"], m["n_layer"]
         self.V, self.EOS = m["vocab_size"], m["EOS"]
         self.suppressed = [280, 486, self.EOS]
+        assert numerics in ("fp32", "bf16", "fp8")
+        self.numerics = numerics
+        self.batched_min = batched_min
         w = {k: _f32(v) for k, v in weights.items()}
+        self.w8 = None
+        if numerics != "fp32":
+            w = dict(w)
+            for k in list(w):
+                if k.endswith((".qkv.weight", ".out_proj.weight", ".mlp.0.weight", ".mlp.2.weight")) or \
+                        k in ("ar_predict_layer.weight", "bert_proj.weight"):
+                    w[k] = round_bf16(w[k])
         self.w = w
+        if numerics == "fp8":
+            # second pack for the batched step: qkv / mlp weights dequantised from e4m3 with the row scale folded back
+            w8 = dict(w)
+            for k in list(w8):
+                if k.endswith((".qkv.weight", ".mlp.0.weight", ".mlp.2.weight")):
+                    q, sc = quant_e4m3_rows(_f32(weights[k]))
+                    w8[k] = (q * sc[:, None]).astype(np.float32)
+            self.pack8 = np.concatenate([w8["t2s_transformer.blocks.%d.%s" % (l, k)].ravel()
+                                         for l in range(self.NL) for k in _LAYER_KEYS])
         self.pack = np.concatenate([w["t2s_transformer.blocks.%d.%s" % (l, k)].ravel()
                                     for l in range(self.NL) for k in _LAYER_KEYS])
         assert self.pack.size == lib().orc_layer_floats(self.D) * self.NL
@@ -154,6 +206,8 @@ class T2SOracle:
     def embed_text(self, x, bert):
         w = self.w
         e = w["ar_text_embedding.word_embeddings.weight"][x]
+        if self.numerics != "fp32":
+            bert = round_bf16(bert)
         e = e + (bert @ w["bert_proj.weight"].T + w["bert_proj.bias"])
         return (e * np.float32(1.0) + self.pe_text[: len(x)]).astype(np.float32)
 
@@ -191,17 +245,43 @@ class T2SOracle:
         B, L, _ = xy.shape
         if L > kc.shape[3]:
             raise ValueError("prompt longer than the largest KV bucket")
-        lib().orc_t2s_prefill(_fp(self.pack), self.NL, self.D, self.H, B, L, _fp(xy),
-                              mask.ctypes.data_as(c_u8), _fp(kc), _fp(vc), kc.shape[1], kc.shape[3], b0)
+        self._prefill_rows(xy, mask, bsz, b0)
         return xy
+
+    def _prefill_rows(self, xy, mask, bsz, b0):
+        """in place; the prompt path rounds K/V, GEMM operands and the attention's q / p in the reduced modes"""
+        kc, vc = self.cache[bsz]
+        lib().orc_set_rounding(0 if self.numerics == "fp32" else (R_KV | R_LIN | R_ATTN))
+        try:
+            lib().orc_t2s_prefill(_fp(self.pack), self.NL, self.D, self.H, xy.shape[0], xy.shape[1], _fp(xy),
+                                  mask.ctypes.data_as(c_u8), _fp(kc), _fp(vc), kc.shape[1], kc.shape[3], int(b0))
+        finally:
+            lib().orc_set_rounding(0)
 
     def decode(self, x, bsz, kv_len):
         kc, vc = self.cache[bsz]
         x = np.ascontiguousarray(x, np.float32).copy()
         kv = np.ascontiguousarray(kv_len, np.int64)
-        lib().orc_t2s_decode(_fp(self.pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),
-                             kc.shape[1], kc.shape[3], 0, kv.ctypes.data_as(c_i64))
+        pack, flags = self.pack, 0
+        if self.numerics != "fp32":
+            flags = R_KV                                   # per-sequence kernels: fp32 activations x bf16 weights
+            if bsz >= self.batched_min:                    # batched chain: bf16 (fp8) MFMA operands
+                flags |= R_LIN
+                if self.numerics == "fp8":
+                    flags |= R_FP8
+                    pack = self.pack8
+        lib().orc_set_rounding(flags)
+        try:
+            lib().orc_t2s_decode(_fp(pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),
+                                 kc.shape[1], kc.shape[3], 0, kv.ctypes.data_as(c_i64))
+        finally:
+            lib().orc_set_rounding(0)
         return x
+
+    @staticmethod
+    def _gap(logits_row):
+        t = np.sort(logits_row[np.isfinite(logits_row)])
+        return float(t[-1] - t[-2])
 
     def _margin(self, logits_row):
         """decision margin: top-1 minus top-2 of the logits the argmax actually saw."""
@@ -345,6 +425,8 @@ class T2SOracle:
         kv[:actual] = xy_lens
         view = lg[:, :-1].copy()
         samples = sample(view, None, q=q(view.shape), **kw)
+        # decision margins per request (top-1 minus top-2 of the logits each of its samples saw); entry 0 = prefill sample
+        self.req_margins = {b: [self._gap(view[b])] for b in range(actual)}
         xin = np.zeros((bsz, self.D), np.float32)
         xin[:actual] = self.next_input(samples[:, 0], kv[:actual] - x_lens)
         x_lens = np.concatenate([x_lens, np.zeros(bsz - actual, np.int64)])
@@ -363,6 +445,8 @@ class T2SOracle:
                 kv += 1
                 lg = self.logits(h)
                 samples = sample(lg, None, q=q(lg.shape), **kw)
+                for i in np.nonzero(~ignore)[0]:
+                    self.req_margins[int(slot_orig[i])].append(self._gap(lg[i]))
                 pre[rows, kv] = samples[:, 0]
                 if idx % check_interval == 0:
                     reached = kv + check_interval >= bks[min(bi, len(bks) - 1)]
@@ -399,17 +483,15 @@ class T2SOracle:
                                     sx = np.asarray(xs[cur], np.int64); sy = np.asarray(ys[cur], np.int64)
                                     one = np.concatenate([self.embed_text(sx, _f32(berts[cur])),
                                                           self.embed_audio(sy)])[None]
-                                    kc, vc = self.cache[bsz]
                                     xyd = np.ascontiguousarray(one, np.float32)
                                     m1 = self.single_mask(len(sx), len(sy))[None]
-                                    lib().orc_t2s_prefill(_fp(self.pack), self.NL, self.D, self.H, 1,
-                                                          xyd.shape[1], _fp(xyd), m1.ctypes.data_as(c_u8),
-                                                          _fp(kc), _fp(vc), kc.shape[1], kc.shape[3], int(i))
+                                    self._prefill_rows(xyd, m1, bsz, int(i))
                                     l1 = self.logits(xyd[:, -1])
                                     x_lens[i] = len(sx)
                                     kv[i] = len(sx) + len(sy)
                                     v1 = l1[:, :-1].copy()
                                     samples[i: i + 1] = sample(v1, None, q=q(v1.shape), **kw)
+                                    self.req_margins[cur] = [self._gap(v1[0])]
                                     slot_orig[i] = cur
                                     cur += 1
                             if stop:

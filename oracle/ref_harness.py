@@ -55,3 +55,28 @@ def reference_functions(relpath, names, namespace=None):
     if missing:
         raise RuntimeError("not found in %s: %s" % (relpath, sorted(missing)))
     return {n: ns[n] for n in names}
+
+
+def reference_statements(relpath, func_name, first_startswith, last_startswith):
+    """Compile a RUN OF STATEMENTS out of the body of `func_name` in a reference file -- for arithmetic the reference
+    keeps inline (TTS.infer_batched's sort / interleave and its split loop are not functions).  The run starts at the
+    first statement (searched depth-first) whose source begins with `first_startswith` and ends with the first later
+    sibling that begins with `last_startswith` (inclusive).  Returns a code object to `exec` in a namespace that
+    provides the variables those statements read; nothing of the source is stored."""
+    import ast
+    path = os.path.join(REF_ROOT, relpath)
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == func_name)
+    for node in ast.walk(fn):
+        for field in ("body", "orelse", "finalbody"):
+            body = getattr(node, field, None)
+            if not isinstance(body, list):
+                continue
+            for i, st in enumerate(body):
+                if isinstance(st, ast.stmt) and ast.unparse(st).startswith(first_startswith):
+                    for j in range(i, len(body)):
+                        if ast.unparse(body[j]).startswith(last_startswith):
+                            mod = ast.Module(body=body[i:j + 1], type_ignores=[])
+                            return compile(mod, path, "exec")
+    raise RuntimeError("statement run %r .. %r not found in %s:%s" % (first_startswith, last_startswith, relpath, func_name))
