@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path's headline measurement on MI355X (contract in the round prompt).
 
-Workload (BASELINE.json configs[1]): "V2Pro bs=1 greedy AR decode + vocoder,
+--workload single (default; BASELINE.json configs[1]): "V2Pro bs=1 greedy AR decode + vocoder,
 hipGraph on, bf16".  One STEP = one synthetic utterance through the hot path on each GPU:
-  GPT:  100 phonemes (40 prompt + 60 target, zero BERT features) + 100 prompt semantic tokens,
-        prefill then greedy decode of a FIXED 250 tokens (kv 200 -> 450; the reference API has
-        no max-token argument, so the length is pinned by the bucket list [(1,256),(1,450)] and
-        an EOS row of zero weight, i.e. EOS never wins);
-  SoVITS: flow + Generator for those 250 tokens = 500 frames = 10 s of 32 kHz audio
-        (z_p and ge synthetic; the text/ssl encoder enc_p is outside this timed hot path).
-Weights are seeded random tensors of the real architecture (no checkpoints exist offline).
+  GPT:  100 phonemes (40 prompt + 60 target, zero BERT features) + 100 prompt semantic tokens, prefill then greedy
+        decode of a FIXED 250 tokens (kv 200 -> 450; buckets [(1,512),(1,1024)] as SURVEY 8(d), the length pinned by
+        infer(max_new_tokens=250) and an EOS row of zero weight, i.e. EOS never wins);
+  SoVITS: flow + Generator for those 250 tokens = 500 frames = 10 s of 32 kHz audio (z_p and ge synthetic; the
+        text/ssl encoder enc_p is outside this timed hot path).
+--workload cb (configs[2] with --version v2ProPlus on one GPU, configs[3] = v2Pro on 8): continuous batching through the
+multi-GPU engine (gsv_tts_lite_amd/engine.py): 256 mixed-length requests PER GPU through 32 slots per GPU, requests
+dealt on demand from one shared cursor, then the flow + Generator over every finished utterance, time-concatenated in
+batches of 10 as TTS.infer_batched feeds it.  One STEP = one pass over the whole queue.  --dtype fp8 --slots 64 is
+configs[4] (e4m3 QKV / FFN operands in the batched decode step).
 
-value = semantic tokens/s of the whole job end to end (AR + vocoder), all ranks; extra keys give
-the AR-only rate, the vocoder audio-s/s, p50 TTFT, per-kernel rooflines and the CPU baseline
+Weights are seeded random tensors of the real architecture (no checkpoints exist offline).
+value = semantic tokens/s of the whole job end to end (AR + vocoder), all ranks; extra keys give the AR-only rate,
+the vocoder audio-s/s, p50 TTFT, per-kernel and step-level rooflines, the fp32 parity-mode rates and the CPU baseline
 (the oracle = a C/OpenMP restatement of the reference's CPU path, timed on this box's cores).
 
-N>1: one process per GPU (torch.distributed, backend nccl == RCCL), utterances are independent
-(weak scaling: every rank runs its own utterance per step); the only collective is the broadcast
-of the reference-speaker embedding `ge` from rank 0 at the start of each step.
+N>1: one process per GPU (torch.distributed, backend nccl == RCCL).  Utterances are independent; the only collective
+is the ONE broadcast of the reference-speaker embedding `ge` from rank 0 when the speaker is first seen (setup, not
+per step); `cb` additionally shares the request cursor through the process group's store.
 """
 import argparse
 import ctypes
@@ -39,8 +43,11 @@ MFMA_BF16_TFLOPS = 2500.0  # dense bf16 peak
 MFMA_F32_TFLOPS = 157.3
 
 N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, N_NEW = 40, 60, 100, 250
-GPT_CACHE = [(1, 256), (1, 450)]
+GPT_CACHE = [(1, 512), (1, 1024)]
 FRAMES = 2 * N_NEW
+GPT_PARAMS = 76.02e6 + 0.16e6              # block linears + predict layer, + biases / LayerNorm
+KV_BYTES_PER_POS = 2 * 24 * 512            # x dtype bytes: K and V rows of 24 layers
+CB_REQUESTS_PER_GPU, CB_SLOTS = 256, 32
 
 
 def log(msg):
@@ -56,13 +63,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="single", choices=["single", "cb"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--version", default="v2Pro", choices=["v2", "v2Pro", "v2ProPlus"])
+    ap.add_argument("--slots", type=int, default=CB_SLOTS, help="cb: slots per GPU")
+    ap.add_argument("--requests", type=int, default=CB_REQUESTS_PER_GPU, help="cb: requests per GPU per step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the sampling / time-to-first-audio extras")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sampling / time-to-first-audio / fp32 extras")
     ap.add_argument("--ttft-runs", type=int, default=50)
-    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CI on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     return ap.parse_args()
@@ -89,23 +99,9 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline_worker(version):
-    """Runs in a child process (so a pathological host cannot hang the bench): the oracle (kind
-    "port") on this box's host cores.  Thread count = the fastest of a short calibration sweep
-    (a 1-row GEMV step does not scale to hundreds of threads), reported as `cores`."""
-    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-    from gsv_tts_lite_amd import synth
-    from oracle import oracle as orc
-    cfg = synth.gpt_config()
-    gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)
-    hps = synth.sovits_hps(version)
-    sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
-    gin = hps["model"]["gin_channels"]
-    x, y, bert, _ = synth.synth_request(0, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)
-    ge = synth.synth_ge(0, gin, 1234)
-    z = synth.hashed_uniform("bench.z", (1, 192, FRAMES), 1234) * np.float32(1.2)
+def _calibrate_threads(o, orc):
+    """fastest OpenMP team for a 1-row decode step (a GEMV does not scale to hundreds of threads)"""
     avail = _usable_cores()
-    o = orc.T2SOracle(cfg, gw, GPT_CACHE)
     xin = np.zeros((1, 512), np.float32)
     best, best_t = 1, 1e9
     for nt in [c for c in (4, 8, 16, 32, 64, 128, 256) if c <= avail] or [avail]:
@@ -118,27 +114,70 @@ def cpu_baseline_worker(version):
         if dt < best_t:
             best, best_t = nt, dt
     orc.set_num_threads(best)
-    t0 = time.perf_counter()
-    tok = o.infer(x, y, bert, top_k=1)
-    t_ar = time.perf_counter() - t0
+    return best, avail
+
+
+def cpu_baseline_worker(kind, version):
+    """Runs in a child process (so a pathological host cannot hang the bench): the oracle (kind "port") on this box's
+    host cores, on a bounded sample of the same workload."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    from gsv_tts_lite_amd import synth
+    from oracle import oracle as orc
+    cfg = synth.gpt_config()
+    hps = synth.sovits_hps(version)
+    sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
+    gin = hps["model"]["gin_channels"]
+    ge = synth.synth_ge(0, gin, 1234)
     vo = orc.VocoderOracle(hps, sw)
-    fs = 100
-    t0 = time.perf_counter()
-    vo.flow_dec(z[0, :, :fs], np.ones(fs, np.float32), ge[0])
-    t_v = (time.perf_counter() - t0) * (FRAMES / fs)
-    n = len(tok)
-    print(json.dumps({
-        "value": n / (t_ar + t_v), "unit": "semantic_tokens/s", "cores": best, "kind": "port",
-        "sample": "oracle C/OpenMP fp32 on %d of %d usable host threads (best of a calibration sweep): full AR phase "
-                  "(prefill + %d greedy tokens) once; flow+Generator on %d of %d frames scaled x%g"
-                  % (best, avail, n, fs, FRAMES, FRAMES / fs),
-        "ar_tokens_per_s": n / t_ar, "vocoder_audio_s_per_s": (FRAMES / 50.0) / t_v}))
+    if kind == "single":
+        gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)
+        x, y, bert, _ = synth.synth_request(0, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)
+        z = synth.hashed_uniform("bench.z", (1, 192, FRAMES), 1234) * np.float32(1.2)
+        o = orc.T2SOracle(cfg, gw, [(1, 256), (1, 450)])       # 250 tokens: the cache fills at kv 450
+        best, avail = _calibrate_threads(o, orc)
+        t0 = time.perf_counter()
+        tok = o.infer(x, y, bert, top_k=1)
+        t_ar = time.perf_counter() - t0
+        orc.set_num_threads(min(avail, max(best, 16)))
+        t0 = time.perf_counter()
+        vo.flow_dec(z[0], np.ones(FRAMES, np.float32), ge[0])
+        t_v = time.perf_counter() - t0
+        n = len(tok)
+        print(json.dumps({
+            "value": n / (t_ar + t_v), "unit": "semantic_tokens/s", "cores": best, "kind": "port",
+            "sample": "oracle C/OpenMP fp32, %d of %d usable host threads for the AR phase (best of a calibration sweep), "
+                      "%d for the vocoder: one whole utterance = prefill + %d greedy tokens + flow/Generator on all %d frames"
+                      % (best, avail, min(avail, max(best, 16)), n, FRAMES),
+            "ar_tokens_per_s": n / t_ar, "vocoder_audio_s_per_s": (FRAMES / 50.0) / t_v}))
+    else:
+        gw = synth.gpt_weights(cfg, seed=1234, eos_gain=4.0)
+        nreq, slots = 12, 8
+        lens = synth.mixed_lengths(nreq)
+        reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
+        o = orc.T2SOracle(cfg, gw, [(slots, 256), (slots, 512)])
+        avail = _usable_cores()
+        orc.set_num_threads(min(avail, 32))
+        t0 = time.perf_counter()
+        pred, _ = o.infer_batched([r[0] for r in reqs], [r[1] for r in reqs], [r[2] for r in reqs], top_k=1)
+        t_ar = time.perf_counter() - t0
+        ntok = int(sum(len(p) for p in pred))
+        fs = min(2 * len(pred[0]), 200)
+        z = synth.hashed_uniform("bench.z", (1, 192, fs), 1234) * np.float32(1.2)
+        t0 = time.perf_counter()
+        vo.flow_dec(z[0], np.ones(fs, np.float32), ge[0])
+        t_v = (time.perf_counter() - t0) * (2 * ntok / fs)
+        print(json.dumps({
+            "value": ntok / (t_ar + t_v), "unit": "semantic_tokens/s", "cores": min(avail, 32), "kind": "port",
+            "sample": "oracle C/OpenMP fp32 on %d host threads: continuous batching of %d mixed-length requests through %d "
+                      "slots (%d tokens); vocoder = flow/Generator timed on %d frames, scaled to the %d frames generated"
+                      % (min(avail, 32), nreq, slots, ntok, fs, 2 * ntok),
+            "ar_tokens_per_s": ntok / t_ar, "vocoder_audio_s_per_s": (2 * ntok / 50.0) / t_v}))
 
 
-def cpu_baseline(version, timeout_s=240):
+def cpu_baseline(kind, version, timeout_s=300):
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--version", version],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", kind, "--version", version],
                            capture_output=True, text=True, timeout=timeout_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if line:
@@ -150,16 +189,33 @@ def cpu_baseline(version, timeout_s=240):
                 "sample": "cpu baseline worker exceeded %ds" % timeout_s}
 
 
-def main():
-    a = parse()
-    if a.cpu_baseline_worker:
-        cpu_baseline_worker(a.version)
+def _torch_dtype(name):
+    return {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}[name]
+
+
+def _profile_traffic(out, a):
+    """HBM traffic per launch from the committed PMC passes (profiles/traffic.json): counters cannot be read in-process"""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
         return
+    try:
+        tr = json.load(open(tfile))
+        for k in out.get("roofline_kernels", []):
+            if k["kernel"] in tr:
+                k["traffic"] = tr[k["kernel"]]
+        if "kernel" in out["roofline"]:
+            out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"])
+        if a.version == "v2Pro" and a.dtype == "bf16" and "roofline_vocoder" in out:
+            out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
+    except Exception:
+        pass
+
+
+def setup_dist(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.share_gpu:
-        local = 0
+    local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,18 +224,41 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
-    else:
-        dist = None
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    return world, rank, dev, dist
 
-    from gsv_tts_lite_amd import synth, _native as N
+
+def timed_region(steps, warmup, step_fn, dev, dist):
+    from gsv_tts_lite_amd import scheduler
+    for i in range(warmup):
+        step_fn(i, None)
+    log("warmup done")
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(warmup + i, i)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    return scheduler.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+
+# ================================================================================================ configs[1]
+def run_single(a):
+    world, rank, dev, dist = setup_dist(a)
+    from gsv_tts_lite_amd import synth, _native as N, engine
     from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
     from gsv_tts_lite_amd.sovits import _VocoderNative
-    from gsv_tts_lite_amd import scheduler
 
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.dtype == "fp8":
+        raise SystemExit("fp8 operands exist in the batched decode step only: use --workload cb --dtype fp8")
+    dtype = _torch_dtype(a.dtype)
     sbytes = 2 if a.dtype == "bf16" else 4
     cfg = synth.gpt_config()
     gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)
@@ -193,14 +272,14 @@ def main():
     t2s.use_graph = not a.no_graph
     voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, dtype, dev)
 
-    # every rank owns a different utterance stream (weak scaling); the speaker embedding comes from rank 0
+    # every rank owns a different utterance stream (weak scaling); the speaker embedding exists on rank 0 and is
+    # broadcast ONCE, when the speaker is first seen (engine.SpeakerBook), not per utterance
     def request(i):
         x, y, bert, _ = synth.synth_request(rank * 100003 + i, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)
-        return (torch.from_numpy(x)[None].to(dev), torch.from_numpy(y)[None].to(dev),
-                torch.from_numpy(bert)[None].to(dev))
+        return (torch.from_numpy(x)[None].to(dev), torch.from_numpy(y)[None].to(dev), torch.from_numpy(bert)[None].to(dev))
     reqs = [request(i) for i in range(max(1, min(8, a.steps + a.warmup)))]
-    ge_src = torch.from_numpy(synth.synth_ge(0, gin, 1234)).to(dev)
-    ge = ge_src.clone() if rank == 0 else torch.zeros_like(ge_src)
+    book = engine.SpeakerBook(dev)
+    ge = book.sync("speaker-0", [torch.from_numpy(synth.synth_ge(0, gin, 1234))] if rank == 0 else None)[0]
     z_np = synth.hashed_uniform("bench.z", (1, 192, FRAMES), 1234) * np.float32(1.2)
     z_p = torch.from_numpy(z_np).to(dev)
     mask = torch.ones(1, 1, FRAMES, device=dev)
@@ -208,12 +287,11 @@ def main():
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
     n_tok = [0]
 
-    def step(i, timed_idx=None):
-        scheduler.broadcast_speaker([ge], src=0)
+    def step(i, timed_idx):
         x, y, bert = reqs[i % len(reqs)]
         if timed_idx is not None:
             ev[timed_idx][0].record()
-        tok = t2s.infer(x, y, bert, top_k=1)
+        tok = t2s.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
         if timed_idx is not None:
             ev[timed_idx][1].record()
         audio = voc.flow_dec(z_p, mask, ge)
@@ -223,22 +301,7 @@ def main():
         return tok, audio
 
     log("models ready")
-    for i in range(a.warmup):
-        step(i)
-    log("warmup done")
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i, i)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = scheduler.max_over_ranks(time.perf_counter() - t0, device=dev)
-
+    elapsed = timed_region(a.steps, a.warmup, step, dev, dist)
     log("timed region done: %.3f s" % elapsed)
     tokens_per_step = n_tok[0]
     assert tokens_per_step == N_NEW, "expected %d tokens per utterance, got %d" % (N_NEW, tokens_per_step)
@@ -255,7 +318,8 @@ def main():
         "config": {"workload": "configs[1]: %s bs=1 greedy AR decode (%d tokens, kv 200->450) + flow/Generator vocoder "
                                "(%d frames = %.0f s audio) per GPU per step, hipGraph %s" %
                                (a.version, N_NEW, FRAMES, audio_s, "off" if a.no_graph else "on"),
-                   "utterances_per_step": world, "gpt_cache": GPT_CACHE, "parallelism": "replicas x%d, ge broadcast" % world},
+                   "utterances_per_step": world, "gpt_cache": GPT_CACHE, "max_new_tokens": N_NEW,
+                   "parallelism": "replicas x%d, ge broadcast once per speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
         "audio_s_per_s_end_to_end": world * a.steps * audio_s / elapsed,
         "ar_tokens_per_s_per_gpu": tokens_per_step / t_ar,
         "vocoder_audio_s_per_s_per_gpu": audio_s / t_voc,
@@ -264,9 +328,9 @@ def main():
     }
 
     if rank == 0:
-        # ---- p50 TTFT: prefill + first sample available on the host (ref-audio caches warm)
         x, y, bert = reqs[0]
         rt = t2s._rt[1]
+        # ---- p50 TTFT: prefill + first sample available on the host (ref-audio caches warm)
         tt = []
         for _ in range(a.ttft_runs):
             torch.cuda.synchronize(dev)
@@ -279,19 +343,64 @@ def main():
         out["ttft_ms_p50"] = float(np.median(tt))
         log("ttft done")
 
-        # ---- extras (not part of `value`): default-parameter sampling, and time to first audio
-        # (first 25-token chunk + 50-frame vocoder pass)
+        # ---- step-level roofline of the timed AR phase: algorithmic bytes per token = weights + the K/V rows read
+        kv_avg = N_PROMPT_PH + N_TEXT_PH + N_PROMPT_TOK + (N_NEW - 1) / 2.0
+        step_bytes = GPT_PARAMS * sbytes + KV_BYTES_PER_POS * sbytes * kv_avg
+        ar_decode_s = t_ar - out["ttft_ms_p50"] * 1e-3 if t_ar > out["ttft_ms_p50"] * 1e-3 else t_ar
+        gbs = step_bytes / (ar_decode_s / tokens_per_step) / 1e9
+        out["roofline_step"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "traffic": None, "bytes_per_token": step_bytes, "ms_per_token": ar_decode_s / tokens_per_step * 1e3,
+                                "note": "whole decode step (50 launches replayed from one hipGraph): (76.2 M weights + K/V rows at the run's "
+                                        "mean kv) x dtype bytes / measured time per token (AR phase minus the p50 prefill)"}
+
+        # ---- roofline of the decode-step kernels: each class's 24 launches replayed from a hipGraph between two
+        # hipEvents on the launch stream (no host launch cost; the dependent-launch gap of a real step is included)
+        ms = (ctypes.c_float * 4)()
+        N.check(N.lib().gsv_t2s_time_kernels(t2s._h, 1, 20, ms, N.current_stream_ptr(dev)))
+        log("kernel timing done")
+        kv = int(rt["kv_len"][0].item())
+        w_attn = (1536 * 512 + 512 * 512) * sbytes
+        b_attn = w_attn + 2 * kv * 512 * sbytes + 2 * 512 * sbytes
+        b_ffn = 2 * 2048 * 512 * sbytes
+        b_log = 1025 * 512 * sbytes
+        kern = []
+        for name, t_ms, byts, per_tok in (("t2s_attn_kernel", ms[0], b_attn, 24), ("t2s_ffn_kernel", ms[1], b_ffn, 24),
+                                          ("t2s_logits_kernel", ms[2], b_log, 1), ("t2s_token_kernel", ms[3], 4096, 1)):
+            g = byts / (t_ms * 1e-3) / 1e9
+            kern.append({"kernel": name, "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": g / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_ms * 1e3,
+                         "algorithmic_bytes_per_launch": byts, "launches_per_token": per_tok, "us_per_token": t_ms * 1e3 * per_tok,
+                         "kv_at_measurement": kv})
+        dom = max(kern[:2], key=lambda k: k["us_per_token"])
+        out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        out["roofline"]["kernel"] = dom["kernel"]
+        out["roofline"]["avg_launch_us"] = dom["avg_launch_us"]
+        out["roofline"]["note"] = ("dominant kernel of the timed region (24 launches/token); algorithmic bytes = its weights (+ K/V rows "
+                                   "at the live kv for attn) per launch, SURVEY.md 8(d); time = hipGraph replay of the class between "
+                                   "hipEvents, which includes the dependent-launch gap (rocprofv3's per-dispatch figure in profiles/ "
+                                   "excludes it); bs=1 decode is latency-bound")
+        out["roofline_kernels"] = kern
+        vbytes, vflops = vocoder_algorithmic(a.version, sbytes)
+        g = vbytes * FRAMES / t_voc / 1e9
+        peak_tf = MFMA_BF16_TFLOPS if a.dtype == "bf16" else MFMA_F32_TFLOPS
+        out["roofline_vocoder"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                   "traffic": None, "mfma_tflops": vflops * FRAMES / t_voc / 1e12,
+                                   "mfma_frac": vflops * FRAMES / t_voc / 1e12 / peak_tf,
+                                   "note": "whole flow+Generator pass; algorithmic bytes = layer-streaming conv I/O, SURVEY.md 8(d)"}
+        _profile_traffic(out, a)
+
+        # ---- extras (not part of `value`)
         try:
             if a.no_extras:
                 raise RuntimeError("--no-extras")
-            for _ in range(2):
+            for _ in range(2):   # default-parameter sampling
                 torch.cuda.synchronize(dev); s0 = time.perf_counter()
-                tk = t2s.infer(x, y, bert, top_k=15, repetition_penalty=1.35)
+                tk = t2s.infer(x, y, bert, top_k=15, repetition_penalty=1.35, max_new_tokens=N_NEW)
                 torch.cuda.synchronize(dev); dt = time.perf_counter() - s0
             out["sampled_top_k15_ms_per_token"] = dt * 1e3 / max(1, int(tk.shape[-1]))
             z50, m50 = z_p[:, :, :50].contiguous(), mask[:, :, :50].contiguous()
             ta = []
-            for _ in range(10):
+            for _ in range(10):   # time to first audio: prefill + first 25-token chunk + 50-frame vocoder pass
                 torch.cuda.synchronize(dev); s0 = time.perf_counter()
                 xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
                 t2s.prefill(1, 0, xy, xl, yl)
@@ -300,25 +409,6 @@ def main():
                 torch.cuda.synchronize(dev)
                 ta.append((time.perf_counter() - s0) * 1e3)
             out["ttfa_ms_p50"] = float(np.median(ta))
-            # first-batch TTFT at 32 slots: one packed prefill of 32 prompts + the first sample of each,
-            # on a second decoder instance so that the timed bs=1 runtime above is not re-laid-out
-            t32 = Text2SemanticDecoder(cfg)
-            t32.load_state_dict(gw)
-            t32.initialize_runtime(dtype, dev, [(32, 512)])
-            r32 = [synth.synth_request(1000 + i, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234) for i in range(32)]
-            xs = [torch.from_numpy(r[0]).to(dev) for r in r32]
-            ys = [torch.from_numpy(r[1]).to(dev) for r in r32]
-            bs_ = [torch.from_numpy(r[2]).to(dev) for r in r32]
-            tb = []
-            for _ in range(12):
-                torch.cuda.synchronize(dev); s0 = time.perf_counter()
-                xy, xl, yl, _, _ = t32.embed_prompt(xs, ys, bs_)
-                t32.prefill(32, 0, xy, xl, yl)
-                t32._flush(32)
-                _ = t32._rt[32]["pre_tokens"][:, N_PROMPT_PH + N_TEXT_PH + N_PROMPT_TOK].cpu()
-                tb.append((time.perf_counter() - s0) * 1e3)
-            out["ttft_bs32_first_batch_ms_p50"] = float(np.median(tb[2:]))
-            del t32
             # the vocoder as TTS.infer_batched feeds it (TTS.py:728-764): 10 utterances time-concatenated, per-frame ge
             T10 = 10 * FRAMES
             z10 = z_p.repeat(1, 1, 10).contiguous()
@@ -337,55 +427,33 @@ def main():
                 "frac": vb10 * T10 / t10 / 1e9 / HBM_PEAK_GBS, "traffic": None, "ms_per_10s_audio": t10 * 1e3 / 10,
                 "mfma_tflops": vf10 * T10 / t10 / 1e12,
                 "note": "flow+Generator on 10 time-concatenated utterances (100 s of audio) in one pass, per-frame ge"}
+            # the bit-exact configuration (fp32 weights / KV / activations: the parity mode of tests/) measured as well
+            if a.dtype != "fp32":
+                del z10, m10, ge10
+                t2f = Text2SemanticDecoder(cfg)
+                t2f.load_state_dict(gw)
+                t2f.initialize_runtime(torch.float32, dev, GPT_CACHE)
+                vof = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.float32, dev)
+                t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW); vof.flow_dec(z_p, mask, ge)
+                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                for _ in range(3):
+                    t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
+                torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                for _ in range(3):
+                    vof.flow_dec(z_p, mask, ge)
+                torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                out["fp32_parity_mode"] = {
+                    "ar_tokens_per_s": 3 * N_NEW / (t1 - s0), "ar_ms_per_token": (t1 - s0) / 3 / N_NEW * 1e3,
+                    "vocoder_ms": (t2 - t1) / 3 * 1e3, "tokens_per_s_end_to_end": 3 * N_NEW / (t2 - s0),
+                    "note": "same workload with dtype fp32: the configuration whose greedy tokens are bit-exact and whose waveform "
+                            "is within 1e-3 of the fp32 CPU reference (tests/test_hip_t2s.py, test_hip_vocoder.py)"}
+                del t2f, vof
         except Exception as exc:   # extras must never cost the bench line
             log("extras skipped: %r" % (exc,))
 
-        # ---- roofline of the decode-step kernels (HIP events on the launch stream, live state: kv = 450)
-        ms = (ctypes.c_float * 4)()
-        N.check(N.lib().gsv_t2s_time_kernels(t2s._h, 1, 20, ms, N.current_stream_ptr(dev)))
-        log("kernel timing done")
-        kv = 450
-        w_attn = (1536 * 512 + 512 * 512) * sbytes
-        b_attn = w_attn + 2 * kv * 512 * sbytes + 2 * 512 * sbytes
-        b_ffn = 2 * 2048 * 512 * sbytes
-        b_log = 1025 * 512 * sbytes
-        kern = []
-        for name, t_ms, byts, per_tok in (("t2s_attn_kernel", ms[0], b_attn, 24), ("t2s_ffn_kernel", ms[1], b_ffn, 24),
-                                          ("t2s_logits_kernel", ms[2], b_log, 1), ("t2s_token_kernel", ms[3], 4096, 1)):
-            gbs = byts / (t_ms * 1e-3) / 1e9
-            kern.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_ms * 1e3,
-                         "algorithmic_bytes_per_launch": byts, "launches_per_token": per_tok,
-                         "us_per_token": t_ms * 1e3 * per_tok})
-        dom = max(kern[:2], key=lambda k: k["us_per_token"])
-        out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-        out["roofline"]["kernel"] = dom["kernel"]
-        out["roofline"]["note"] = ("dominant kernel of the timed region (24 launches/token); algorithmic bytes = its weights "
-                                   "(+ K/V rows at kv=450 for attn) per launch, SURVEY.md 8(d); bs=1 decode is latency-bound")
-        out["roofline_kernels"] = kern
-        vbytes, vflops = vocoder_algorithmic(a.version, sbytes)
-        gbs = vbytes * FRAMES / t_voc / 1e9
-        peak_tf = MFMA_BF16_TFLOPS if a.dtype == "bf16" else MFMA_F32_TFLOPS
-        out["roofline_vocoder"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                                   "mfma_tflops": vflops * FRAMES / t_voc / 1e12,
-                                   "mfma_frac": vflops * FRAMES / t_voc / 1e12 / peak_tf,
-                                   "note": "whole flow+Generator pass; algorithmic bytes = layer-streaming conv I/O, SURVEY.md 8(d)"}
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tr = json.load(open(tfile))
-                for k in out["roofline_kernels"]:
-                    if k["kernel"] in tr:
-                        k["traffic"] = tr[k["kernel"]]
-                out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"])
-                if a.version == "v2Pro" and a.dtype == "bf16":   # the PMC passes were taken on this configuration
-                    out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
-            except Exception:
-                pass
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (subprocess) ...")
-            cb = cpu_baseline(a.version)
+            cb = cpu_baseline("single", a.version)
             out["cpu_baseline"] = cb
             if cb.get("value"):
                 out["speedup_vs_cpu_baseline"] = value / cb["value"]
@@ -393,6 +461,136 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ================================================================================================ configs[2] / [3] / [4]
+def run_cb(a):
+    world, rank, dev, dist = setup_dist(a)
+    from gsv_tts_lite_amd import synth, engine
+    from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+
+    dtype = _torch_dtype(a.dtype)
+    vdtype = torch.bfloat16 if a.dtype == "fp8" else dtype       # fp8 operands exist in the GPT batched step only
+    sbytes = 4 if a.dtype == "fp32" else 2
+    cfg = synth.gpt_config()
+    gw = synth.gpt_weights(cfg, seed=1234, eos_gain=4.0)
+    hps = synth.sovits_hps(a.version)
+    sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
+    gin = hps["model"]["gin_channels"]
+    t2s = Text2SemanticDecoder(cfg)
+    t2s.load_state_dict(gw)
+    t2s.initialize_runtime(dtype, dev, [(a.slots, 512), (a.slots, 1024)])     # SURVEY.md 8(d) buckets
+    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, vdtype, dev)
+    eng = engine.ContinuousBatchingEngine(t2s, slots=a.slots, chunk=2)
+    book = engine.SpeakerBook(dev)
+    ge = book.sync("speaker-0", [torch.from_numpy(synth.synth_ge(0, gin, 1234))] if rank == 0 else None)[0]
+
+    n_req = a.requests * world
+    lens = synth.mixed_lengths(n_req)
+    reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
+    xs = [torch.from_numpy(r[0]).to(dev) for r in reqs]
+    ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
+    bs = [torch.from_numpy(r[2]).to(dev) for r in reqs]
+    acc = {"tok": 0, "frames": 0, "t_ar": 0.0, "t_voc": 0.0, "steps": 0, "kv_rows": 0, "mine": 0}
+
+    def vocode(items):
+        """flow + Generator over this rank's finished utterances, time-concatenated in batches of 10 with per-frame ge,
+        sorted short/long-interleaved as TTS.infer_batched does (TTS.py:705-764)"""
+        from gsv_tts_lite_amd.batchmath import balance_order
+        if not items:
+            return 0
+        lengths = torch.tensor([len(p) for _, p in items])
+        order = balance_order(lengths).tolist()
+        tot = 0
+        for s in range(0, len(order), 10):
+            T = int(sum(2 * int(lengths[i]) for i in order[s:s + 10]))
+            if T == 0:
+                continue
+            z = torch.randn(1, 192, T, device=dev)
+            voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge.expand(-1, -1, T).contiguous())
+            tot += T
+        return tot
+
+    def step(i, timed_idx):
+        torch.cuda.synchronize(dev); s0 = time.perf_counter()
+        pred, idx = eng.run_gpt(xs, ys, bs, top_k=1)
+        torch.cuda.synchronize(dev); s1 = time.perf_counter()
+        frames = vocode(list(zip(idx.tolist(), pred)))
+        torch.cuda.synchronize(dev); s2 = time.perf_counter()
+        if timed_idx is not None:
+            acc["tok"] += int(sum(len(p) for p in pred)); acc["frames"] += frames
+            acc["t_ar"] += s1 - s0; acc["t_voc"] += s2 - s1; acc["mine"] += len(pred)
+            acc["steps"] += t2s.last_stats["steps"]; acc["kv_rows"] += t2s.last_stats["kv_rows"]
+
+    log("models ready")
+    elapsed = timed_region(a.steps, a.warmup, step, dev, dist)
+    log("timed region done: %.3f s" % elapsed)
+    tot = torch.tensor([acc["tok"], acc["frames"], acc["mine"]], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tot)
+    tok_all, frames_all = float(tot[0]), float(tot[1])
+    assert int(tot[2]) == n_req * a.steps, "every request must have been served exactly once per step"
+    value = tok_all / elapsed
+    which = "configs[4]" if a.dtype == "fp8" else ("configs[2]" if world == 1 and a.version == "v2ProPlus" else "configs[3]")
+    out = {
+        "metric": "semantic_tokens_per_sec_end_to_end (GPT AR incl. prefill + flow/Generator vocoder); RTF^-1 = value/25",
+        "value": value, "unit": "semantic_tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic (seeded random weights of the real architecture, synthetic phoneme/token ids)",
+        "config": {"workload": "%s: %s continuous batching, %d mixed-length requests per GPU per step through %d slots per GPU "
+                               "(greedy, EOS-terminated), flow/Generator over every utterance in time-concatenated batches of 10"
+                               % (which, a.version, a.requests, a.slots),
+                   "requests_per_step": n_req, "gpt_cache": [(a.slots, 512), (a.slots, 1024)],
+                   "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "
+                                  "speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
+        "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
+        "tokens_per_step": tok_all / a.steps, "mean_tokens_per_request": tok_all / a.steps / n_req,
+        "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"], "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9),
+        "rank0_requests_served_per_step": acc["mine"] / a.steps,
+    }
+    if rank == 0:
+        # step-level roofline of the batched decode step on this rank: weights once per step + the K/V rows read
+        wbytes = GPT_PARAMS * 2
+        if a.dtype == "fp32":
+            wbytes = GPT_PARAMS * 4
+        if a.dtype == "fp8":   # QKV / W1 / W2 as e4m3 (+ fp32 scales); out-proj, predict layer bf16
+            wbytes = (24 * (3 * 512 * 512 + 2 * 2048 * 512) * 1 + 24 * 512 * 512 * 2 + 1025 * 512 * 2 + 0.16e6 * 4 + 24 * 4096 * 4)
+        by = acc["steps"] * wbytes + acc["kv_rows"] * KV_BYTES_PER_POS * sbytes
+        gbs = by / acc["t_ar"] / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "batched decode step (5 launches per layer, csrc/t2s_batch.h)",
+                           "ms_per_step_of_the_slot_loop": acc["t_ar"] / max(1, acc["steps"]) * 1e3,
+                           "note": "algorithmic bytes of the AR phase = decode steps x weight bytes + K/V rows read x row bytes (prefills and "
+                                   "refills are inside the time, not in the bytes) / AR wall time of rank 0"}
+        vbytes, vflops = vocoder_algorithmic(a.version, 4 if a.dtype == "fp32" else 2)
+        if acc["frames"]:
+            g = vbytes * acc["frames"] / acc["t_voc"] / 1e9
+            out["roofline_vocoder"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                       "traffic": None, "mfma_tflops": vflops * acc["frames"] / acc["t_voc"] / 1e12}
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (subprocess) ...")
+            cb = cpu_baseline("cb", a.version)
+            out["cpu_baseline"] = cb
+            if cb.get("value"):
+                out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_worker:
+        cpu_baseline_worker(a.cpu_baseline_worker, a.version)
+        return
+    if a.workload == "cb":
+        if a.steps == 10 and a.warmup == 2 and "--steps" not in sys.argv:
+            a.steps, a.warmup = 3, 1      # a step is a whole queue (~2 s): keep the default run within minutes
+        run_cb(a)
+    else:
+        run_single(a)
 
 
 if __name__ == "__main__":

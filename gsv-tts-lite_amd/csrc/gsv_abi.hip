@@ -3,6 +3,7 @@
 // No allocation happens inside a step; nothing here falls back to a CPU or library path.
 #include "abi_common.h"
 #include "t2s_decode.h"
+#include "t2s_decode_multi.h"
 #include "t2s_batch.h"
 
 namespace {
@@ -220,6 +221,12 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
     a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
     a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart; a.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
+    if (B > 16) {   // two sequences per block: one round of 1024-thread blocks up to 32 sequences (t2s_decode_multi.h)
+        const size_t ml = sizeof(float) * attn_multi_lds_floats<2>();
+        if (l == 0) hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 0, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
+        else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
+        return;
+    }
     if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
@@ -230,7 +237,21 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     FfnArgs<WT> f;
     f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
     f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
-    hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, s.batch), dim3(kNT), 0, st, f);
+    const int B = s.batch;
+    if (B > 16 && sizeof(WT) == 2) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B);
+    else if (B > 8) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
+    else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
+}
+
+// the R-sequences-per-block kernels use more than 64 KB of dynamic LDS
+template <typename WT>
+int t2s_multi_lds_attr() {
+    const int la = (int)(sizeof(float) * attn_multi_lds_floats<2>());
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<2>())));
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<4>())));
+    return GSV_OK;
 }
 
 // the transformer stack for one token per slot; x from `xsrc` [B][512]
@@ -272,23 +293,28 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 }
 
 // batched step (bf16, B >= kBatchedMin): the prompt GEMM chain on B rows + one attention block per (head, sequence)
-// From this many sequences on, the bf16 / fp8 step is the batched chain (t2s_batch.h: weights streamed once per step)
-// instead of the per-sequence kernels (weights re-streamed per sequence from L2).  GSV_BATCHED_MIN overrides it at
-// handle creation (bench / tuning aid).
-constexpr int kBatchedMinDefault = 12;
+// From this many sequences on, the bf16 / fp8 step is the batched chain (t2s_batch.h: weights streamed once per step,
+// five launches per layer) instead of the two-launches-per-layer kernels (t2s_decode.h up to 16 sequences,
+// t2s_decode_multi.h with 2 / 4 sequences per block up to 32).  Measured step time, bf16, kv 200-300 (ms):
+//   sequences         8      16     24     32     40     64     256
+//   2 launches/layer  0.38   0.45   0.65   0.66   1.13   --     --
+//   batched chain     --     0.67   0.75   0.83   0.85   0.89   1.51
+// GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
+constexpr int kBatchedMinDefault = 33;
 constexpr size_t kPrefillLdsMax = 160 * 1024;
 
-template <typename WT>
-int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
-    const int B = s.batch, T = s.max_kv;
-    float* qkv = h->ypart;                                   // [B][1536]
-    float* attn = qkv + (size_t)B * 3 * kD;                  // [B][512]
-    float* y1 = attn + (size_t)B * kD;                       // [B][512]  pre-LN1 rows
-    float* y2 = y1 + (size_t)B * kD;                         // [B][512]  pre-LN2 rows
-    void* hid = h->zpart;                                    // [B][2048] bf16 | e4m3
-    const size_t layer_elems = (size_t)B * kH * T * kDh;
-    const int rtiles = cdiv(B, 32);
-    const bool f8 = h->fp8;
+// The 5-launches-per-layer chain of t2s_batch.h on M rows (decode: one row per sequence; prompt pass: nrows * l_max
+// rows).  x0 [M][512] fp32 is the input of layer 0 and is overwritten with each layer's input (the residual of the
+// out-proj); on return `y2` holds the LAST layer's pre-LayerNorm2 rows.  `attn_launch(l)` runs the attention of layer l
+// from `qkv` into `attn`.
+struct ChainBufs {
+    float *qkv, *attn, *y1, *y2, *x1;   // [M][1536], [M][512] x 4
+    void* hid;                          // [M][2048] bf16 | e4m3
+};
+
+template <typename AttnFn>
+int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, AttnFn attn_launch, hipStream_t st) {
+    const int rtiles = cdiv(M, 32);
     const unsigned skip = h->dbg_skip;
     auto run = [&](auto kern, int nthreads, const BGemmArgs& ba) {
         hipLaunchKernelGGL(kern, dim3(rtiles, ba.mtiles), dim3(nthreads), 0, st, ba);
@@ -297,46 +323,69 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
         T2SLayer& L = h->layers[l];
         if (!(skip & 1)) {   // K1: [LayerNorm2 of layer l-1] -> QKV
             BGemmArgs g{};
-            g.M = B; g.ldx = kD; g.W = (const uint4*)(f8 ? L.f8_qkv : L.g_qkv.w); g.wscale = L.s_qkv; g.mtiles = 3 * kD / 32; g.cout = 3 * kD;
-            g.bias = L.g_qkv.bias; g.Y = qkv; g.ldy = 3 * kD;
+            g.M = M; g.ldx = kD; g.W = (const uint4*)(f8 ? L.f8_qkv : L.g_qkv.w); g.wscale = L.s_qkv; g.mtiles = 3 * kD / 32; g.cout = 3 * kD;
+            g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
             if (l == 0) {
-                g.X = h->xcur;
+                g.X = x0;
                 if (f8) run(bgemm_kernel<PRO_NONE, float, float, 4, true>, 256, g);
                 else run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
             } else {
-                g.X = y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = h->xbuf;
+                g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
                 if (f8) run(bgemm_kernel<PRO_LN, float, float, 4, true>, 256, g);
                 else run(bgemm_kernel<PRO_LN, float, float, 4, false>, 256, g);
             }
         }
-        BatchAttnArgs<WT> ba;
-        ba.qkv = qkv; ba.kc = (WT*)s.k_cache + (size_t)l * layer_elems; ba.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-        ba.kv_len = s.kv_len; ba.T = T; ba.out = attn;
-        if (!(skip & 2)) hipLaunchKernelGGL((t2s_batch_attn_kernel<WT>), dim3(kH, B), dim3(256), 0, st, ba);
+        if (!(skip & 2)) attn_launch(l);
         if (!(skip & 4)) {   // K3: out-proj + bias + residual -> pre-LN1
             BGemmArgs g{};
-            g.M = B; g.X = attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
-            g.res = l == 0 ? h->xcur : h->xbuf; g.ldres = kD; g.Y = y1; g.ldy = kD;
+            g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
+            g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
             run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
         }
         if (!(skip & 8)) {   // K4: [LayerNorm1] -> W1 + bias + ReLU
             BGemmArgs g{};
-            g.M = B; g.X = y1; g.ldx = kD; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = h->x1buf;
+            g.M = M; g.X = c.y1; g.ldx = kD; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = c.x1;
             g.W = (const uint4*)(f8 ? L.f8_w1 : L.g_w1.w); g.wscale = L.s_w1; g.mtiles = kF / 32; g.cout = kF; g.bias = L.b1; g.relu = 1;
-            g.Y = hid; g.ldy = kF;
+            g.Y = c.hid; g.ldy = kF;
             if (f8) run(bgemm_kernel<PRO_LN, float, fp8_t, 4, true>, 256, g);
             else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false>, 256, g);
         }
         if (!(skip & 16)) {   // K5: W2 over the full K + bias + residual -> pre-LN2
             BGemmArgs g{};
-            g.M = B; g.X = hid; g.ldx = kF; g.W = (const uint4*)(f8 ? L.f8_w2 : L.g_w2.w); g.wscale = L.s_w2; g.mtiles = kD / 32; g.cout = kD;
-            g.bias = L.b2; g.res = h->x1buf; g.ldres = kD; g.Y = y2; g.ldy = kD;
+            g.M = M; g.X = c.hid; g.ldx = kF; g.W = (const uint4*)(f8 ? L.f8_w2 : L.g_w2.w); g.wscale = L.s_w2; g.mtiles = kD / 32; g.cout = kD;
+            g.bias = L.b2; g.res = c.x1; g.ldres = kD; g.Y = c.y2; g.ldy = kD;
             if (f8) run(bgemm_kernel<PRO_NONE, fp8_t, float, 16, true>, 1024, g);
             else run(bgemm_kernel<PRO_NONE, bf16_t, float, 16, false>, 1024, g);
         }
     }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+// batched decode step: the chain on B rows + one attention block per (head, sequence); final hidden states -> h->xbuf
+template <typename WT>
+int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
+    const int B = s.batch, T = s.max_kv;
+    ChainBufs c;
+    c.qkv = h->ypart;                                        // [B][1536]
+    c.attn = c.qkv + (size_t)B * 3 * kD;                     // [B][512]
+    c.y1 = c.attn + (size_t)B * kD;
+    c.y2 = c.y1 + (size_t)B * kD;
+    c.x1 = h->x1buf;
+    c.hid = h->zpart;                                        // [B][2048] bf16 | e4m3
+    const size_t layer_elems = (size_t)B * kH * T * kDh;
+    auto attn = [&](int l) {
+        BatchAttnArgs<WT> ba;
+        ba.qkv = c.qkv; ba.kc = (WT*)s.k_cache + (size_t)l * layer_elems; ba.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
+        ba.kv_len = s.kv_len; ba.T = T; ba.out = c.attn;
+        if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn_kernel<4, false>), dim3(kH, B), dim3(256), 0, st, ba);
+        else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn_kernel<8, false>), dim3(kH, B), dim3(256), 0, st, ba);
+        else hipLaunchKernelGGL((t2s_batch_attn_kernel<16, false>), dim3(kH, B), dim3(256), 0, st, ba);
+    };
+    // x0 = xcur: the token kernel rewrites it at the start of every step, so the chain may use it as its residual buffer
+    if (int rc = t2s_gemm_chain(h, B, h->xcur, c, h->fp8, attn, st)) return rc;
     const T2SLayer& LL = h->layers.back();
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)y2, (const float*)LL.ln2g, (const float*)LL.ln2b, h->xbuf, B);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, (const float*)c.y2, (const float*)LL.ln2g, (const float*)LL.ln2b, h->xbuf, B);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }
@@ -378,37 +427,21 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         return fail(GSV_ERR_ARG, "prefill: prompt of %d positions exceeds the LDS-staged attention limit of the %s mode (%d positions)",
                     l_max, sizeof(WT) == 2 ? "bf16" : "fp32", sizeof(WT) == 2 ? 1056 : 591);
     if constexpr (sizeof(WT) == 2) {
-        // bf16 mode: latency-shaped GEMMs (rowgemm_kernel), flash attention on the matrix cores, and
-        // bias + residual + LayerNorm in the consumer of the raw (split) GEMM tiles
-        const int rtiles = cdiv(M, 32);
-        bf16_t* fb16 = (bf16_t*)fbuf;                    // FFN hidden as bf16: the GEMM's operand type anyway
-        bf16_t* xb16 = fb16 + (size_t)M * kF;            // bf16 copy of the LayerNorm output (second half of the fp32-sized fbuf)
-        float* part = qkv;                               // W2 split partials reuse qkv + attn (dead by then): [4][M][512]
-        auto gemm = [&](auto kern, const void* X, int ldx, const PackedConv& pc, const float* bias, int relu, void* Y, int ldy,
-                        int nsplit, size_t split_stride) {
-            RowGemmArgs ra;
-            ra.X = X; ra.ldx = ldx; ra.M = M; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
-            ra.bias = bias; ra.relu = relu;
-            ra.Y = Y; ra.ldy = ldy; ra.split_stride = split_stride;
-            hipLaunchKernelGGL(kern, dim3(rtiles, pc.mtiles, nsplit), dim3(256), 0, st, ra);
-        };
-        for (int l = 0; l < h->cfg.n_layer; ++l) {
-            T2SLayer& L = h->layers[l];
-            if (l == 0) gemm(rowgemm_kernel<float, float>, xy, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
-            else gemm(rowgemm_kernel<bf16_t, float>, xb16, kD, L.g_qkv, L.g_qkv.bias, 0, qkv, 3 * kD, 1, 0);
+        // bf16 mode: the same 5-launch chain as the batched decode step on M = nrows * l_max rows (LayerNorm in the
+        // consuming GEMM's prologue, full-K W2), with flash attention on the matrix cores; bf16 operands also on GSV_FP8
+        // handles (fp8 is the batched decode step's).  Workspace: qkv | attn | y1 | [y2 | x1 | hid(bf16)] in the FFN slot.
+        ChainBufs c;
+        c.qkv = qkv; c.attn = attn; c.y1 = ybuf; c.y2 = fbuf; c.x1 = fbuf + (size_t)M * kD; c.hid = fbuf + (size_t)2 * M * kD;
+        auto attn_launch = [&](int l) {
             PrefillAttnMfmaArgs pm;
             pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
             pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
             pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
-            gemm(rowgemm_kernel<float, float>, attn, kD, L.g_out, nullptr, 0, ybuf, kD, 1, 0);
-            hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)ybuf, 1, (size_t)0, (const float*)L.bo,
-                               (const float*)xy, (const float*)L.ln1g, (const float*)L.ln1b, xy, M, xb16);
-            gemm(rowgemm_kernel<bf16_t, bf16_t>, xb16, kD, L.g_w1, L.b1, 1, fb16, kF, 1, 0);
-            gemm(rowgemm_kernel<bf16_t, float>, fb16, kF, L.g_w2, nullptr, 0, part, kD, 4, (size_t)M * kD);
-            hipLaunchKernelGGL(ln_rows_sum_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)part, 4, (size_t)M * kD, (const float*)L.b2,
-                               (const float*)xy, (const float*)L.ln2g, (const float*)L.ln2b, xy, M, xb16);
-        }
+        };
+        if (int rc = t2s_gemm_chain(h, M, xy, c, false, attn_launch, st)) return rc;
+        const T2SLayer& LL = h->layers.back();
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)c.y2, (const float*)LL.ln2g, (const float*)LL.ln2b, xy, M);
         HIPCHK(hipGetLastError());
     } else {
         for (int l = 0; l < h->cfg.n_layer; ++l) {
@@ -570,8 +603,10 @@ int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
     if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
     if (h->cfg.dtype == GSV_BF16) {
         HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
+        if (int rc = t2s_multi_lds_attr<bf16_t>()) return rc;
     } else {
         HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
+        if (int rc = t2s_multi_lds_attr<float>()) return rc;
     }
     HIPCHK(hipStreamSynchronize(S(stream)));
     h->finalized = true;

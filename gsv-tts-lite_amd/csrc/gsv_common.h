@@ -118,6 +118,55 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
+// ---- cross-lane exchanges without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32: an LDS instruction
+// (>100 cycles per dependent level, and the 16 waves of a decode block share ONE LDS pipe).  gfx950 has
+// v_permlane32_swap / v_permlane16_swap (exchange lane halves / odd-even 16-lane rows between two registers) and the
+// DPP row rotations, all on the VALU.
+// all lanes: v[l] + v[l ^ 32]   and   v[l] + v[l ^ 16]
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// halving exchanges: lanes 0-31 (even rows) end with a[l] + a[partner], lanes 32-63 (odd rows) with b[l] + b[partner]
+__device__ __forceinline__ float halve32_sum(float a, float b) {
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+__device__ __forceinline__ float halve16_sum(float a, float b) {
+    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// lanes with bit 3 clear end with a[l] + a[l ^ 8], lanes with bit 3 set with b[l] + b[l ^ 8]   (row_ror:8 == xor 8 in a row)
+__device__ __forceinline__ float halve8_sum(float a, float b) {
+    const bool hi = (threadIdx.x & 8) != 0;
+    const float send = hi ? a : b, keep = hi ? b : a;
+    return keep + dpp_f32<0x128>(send);
+}
+// the partner's value v[l ^ M] for M = 1 .. 32 (float or 32-bit integer payload)
+template <int M> __device__ __forceinline__ unsigned lane_xor_u32(unsigned v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "M");
+    if constexpr (M == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+    else if constexpr (M == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+    else if constexpr (M == 4) {
+        const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);   // row_shl:4 -> v[l + 4]
+        const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4 -> v[l - 4]
+        return (threadIdx.x & 4) ? dn : up;
+    } else if constexpr (M == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+    else if constexpr (M == 16) {
+        const auto t = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // t[0] rows (0,0,2,2), t[1] rows (1,1,3,3)
+        return (threadIdx.x & 16) ? t[0] : t[1];
+    } else {
+        const auto t = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // t[0] low half twice, t[1] high half twice
+        return (threadIdx.x & 32) ? t[0] : t[1];
+    }
+}
+template <int M> __device__ __forceinline__ float lane_xor(float v) { return __uint_as_float(lane_xor_u32<M>(__float_as_uint(v))); }
+template <int M> __device__ __forceinline__ int lane_xor(int v) { return (int)lane_xor_u32<M>((unsigned)v); }
+
 // Block-wide reductions for 256-thread (4-wave) blocks; `red` is >= 8 floats of LDS.
 // Deterministic: fixed shuffle tree then waves summed in index order.
 template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {

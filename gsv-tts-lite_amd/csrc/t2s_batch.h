@@ -295,6 +295,135 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
     }
 }
 
+// ---- attention of the batched step ------------------------------------------------------------------
+// One block per (head, sequence): append the new K/V row (rounded through the cache type, t2s_model.py:87-88), then
+// softmax(q K^T / sqrt(32)) V over positions [0, kv_len[b]] (the token attends to itself).
+// Shape, each point measured on MI355X (B = 64, kv 200-300, 28 MB of K/V per launch):
+//  * four lanes per 64-byte row, 16 bytes per lane: a wave's load instruction covers 1 KiB of CONSECUTIVE bytes.  One
+//    thread per key (a lane reading its own 64-byte row) touches 64 cache lines per instruction and was bound by the
+//    texture-address path at 2 TB/s (13 us per launch) whatever else the kernel did;
+//  * the row addresses depend on nothing this kernel computes (rows past kv_len are loaded from clamped, valid
+//    addresses and masked), so kv_len, the q / k / v row and EVERY K and V chunk of the thread are in flight at kernel
+//    entry: one memory latency;
+//  * per-wave softmax statistics (no block-wide max), the wave's P.V reduced by halving exchanges on the cross-lane
+//    network (v_permlane32_swap / v_permlane16_swap / DPP), one LDS meeting of the four waves at the end.
+template <typename WT>
+struct BatchAttnArgs {
+    const float* qkv;        // [B][1536]
+    WT* kc;                  // this layer: [B][16][T][32]
+    WT* vc;
+    const int64_t* kv_len;   // [B]
+    int T;
+    float* out;              // [B][512]
+};
+
+template <int NIT, bool BLIND>   // iterations of 64 rows: T <= 64 * NIT; BLIND: load every chunk, mask after (else: kv_len first)
+__global__ __launch_bounds__(256) void t2s_batch_attn_kernel(BatchAttnArgs<bf16_t> a) {
+    __shared__ __attribute__((aligned(16))) float qs[32], kn[32], vn[32], pacc[4][32];
+    __shared__ float pm[4], pl[4];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int part = tid & 3, rsub = tid >> 2;               // 16-byte quarter of the row; row within an iteration
+    const float* row = a.qkv + (size_t)b * 1536 + h * 32;
+    bf16_t* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
+    bf16_t* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
+    // ---- everything in flight: kv_len, this head's q / k / v, the thread's K and V chunks
+    const int64_t n64 = a.kv_len[b];
+    float rq = 0.f, rk = 0.f, rv = 0.f;
+    if (tid < 32) { rq = row[tid]; rk = row[512 + tid]; rv = row[1024 + tid]; }
+    // !BLIND: rows past kv_len are loaded UNCONDITIONALLY from the last live row (a cache hit, no HBM bytes) and
+    // masked at use -- a per-load "if live" makes hipcc branch around each load and drain vmcnt(0) between them
+    int lastrow = a.T - 1;
+    if constexpr (!BLIND) lastrow = max((int)(n64 < 0 ? 0 : (n64 > a.T - 1 ? a.T - 1 : n64)) - 1, 0);
+    raw16 kr[NIT], vr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) kr[it] = ldg16(Kp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) vr[it] = ldg16(Vp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
+    asm volatile("" : "+v"(rq) : : "memory");
+    const int n = (int)(n64 < 0 ? 0 : (n64 > a.T - 1 ? a.T - 1 : n64));     // position of the new token
+    if (tid < 32) {
+        qs[tid] = rq;
+        const bf16_t kq = f32_to_bf16(rk), vq = f32_to_bf16(rv);
+        kn[tid] = bf16_to_f32(kq); vn[tid] = bf16_to_f32(vq);
+        Kp[(size_t)n * kDh + tid] = kq; Vp[(size_t)n * kDh + tid] = vq;
+    }
+    __syncthreads();
+    float q[8], knr[8], vnr[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(qs + part * 8 + 4 * c);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(kn + part * 8 + 4 * c);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(vn + part * 8 + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { q[4 * c + e] = t[e]; knr[4 * c + e] = u[e]; vnr[4 * c + e] = w[e]; }
+    }
+    const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+    float sc[NIT + 1];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float kk[8];
+        Unpack<bf16_t, 8>::run(kr[it], kk);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(q[e], kk[e], s);
+        s = quad_sum(s);
+        sc[it] = it * 64 + rsub < n ? s * scale : -INFINITY;     // rows [0, n): the cache; row n is the new token, below
+        mx = fmaxf(mx, sc[it]);
+    }
+    {   // the new token's own key / value ride with the first quad of wave 0 (from LDS, never from the row being written)
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(q[e], knr[e], s);
+        s = quad_sum(s);
+        sc[NIT] = tid < 4 ? s * scale : -INFINITY;
+        mx = fmaxf(mx, sc[NIT]);
+    }
+    mx = wave_max(mx);
+    const float mref = mx == -INFINITY ? 0.f : mx;               // a wave without live rows
+    float l = 0.f, acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const bool live = sc[it] != -INFINITY;
+        const float p = live ? __expf(sc[it] - mref) : 0.f;
+        float vv[8];
+        Unpack<bf16_t, 8>::run(vr[it], vv);
+        l += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, live ? vv[e] : 0.f, acc[e]);   // select: never multiply a stale row
+    }
+    {
+        const float p = sc[NIT] != -INFINITY ? __expf(sc[NIT] - mref) : 0.f;
+        l += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, vnr[e], acc[e]);
+    }
+    l = wave_sum(part == 0 ? l : 0.f);
+    float r4[4], r2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = halve32_sum(acc[i], acc[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r2[i] = halve16_sum(r4[i], r4[i + 2]);
+    float r1 = halve8_sum(r2[0], r2[1]);
+    r1 += lane_xor<4>(r1);
+    if ((lane & 4) == 0) pacc[wid][part * 8 + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)] = r1;
+    if (lane == 0) { pm[wid] = mx; pl[wid] = l; }
+    __syncthreads();
+    if (tid < 32) {
+        const float M = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(pm[w] - M);                   // exp(-inf) = 0 for an empty wave
+            num = fmaf(pacc[w][tid], f, num);
+            den = fmaf(pl[w], f, den);
+        }
+        a.out[(size_t)b * kD + h * 32 + tid] = num / den;
+    }
+}
+
 // ---- fp8 weight packing --------------------------------------------------------------------------
 // scale[m] = max_c |W[m][c]| / 448 (1 for an all-zero row)
 static __global__ __launch_bounds__(256) void fp8_row_scale_kernel(const float* __restrict__ W, int cin, float* __restrict__ scale, int cout) {

@@ -123,60 +123,18 @@ __device__ __forceinline__ void lane_x(const float* xs, float (&xr)[8]) {
 // Every lane returns the total of value index sumN_index<N>().
 template <int N> __device__ __forceinline__ float wave_sumN(const float (&v)[N]);
 template <> __device__ __forceinline__ float wave_sumN<8>(const float (&v)[8]) {
-    const int lane = threadIdx.x & 63;
-    float a[4], b[2], c;
-    {
-        const bool hi = lane & 32;
+    float a[4], b[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float send = hi ? v[i] : v[i + 4];
-            const float keep = hi ? v[i + 4] : v[i];
-            a[i] = keep + __shfl_xor(send, 32, 64);
-        }
-    }
-    {
-        const bool hi = lane & 16;
+    for (int i = 0; i < 4; ++i) a[i] = halve32_sum(v[i], v[i + 4]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = hi ? a[i] : a[i + 2];
-            const float keep = hi ? a[i + 2] : a[i];
-            b[i] = keep + __shfl_xor(send, 16, 64);
-        }
-    }
-    {
-        const bool hi = lane & 8;
-        const float send = hi ? b[0] : b[1];
-        const float keep = hi ? b[1] : b[0];
-        c = keep + __shfl_xor(send, 8, 64);
-    }
-    c += __shfl_xor(c, 4, 64);
-    c += __shfl_xor(c, 2, 64);
-    c += __shfl_xor(c, 1, 64);
-    return c;
+    for (int i = 0; i < 2; ++i) b[i] = halve16_sum(a[i], a[i + 2]);
+    return oct_sum(halve8_sum(b[0], b[1]));
 }
 template <> __device__ __forceinline__ float wave_sumN<4>(const float (&v)[4]) {
-    const int lane = threadIdx.x & 63;
-    float b[2], c;
-    {
-        const bool hi = lane & 32;
+    float b[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float send = hi ? v[i] : v[i + 2];
-            const float keep = hi ? v[i + 2] : v[i];
-            b[i] = keep + __shfl_xor(send, 32, 64);
-        }
-    }
-    {
-        const bool hi = lane & 16;
-        const float send = hi ? b[0] : b[1];
-        const float keep = hi ? b[1] : b[0];
-        c = keep + __shfl_xor(send, 16, 64);
-    }
-    c += __shfl_xor(c, 8, 64);
-    c += __shfl_xor(c, 4, 64);
-    c += __shfl_xor(c, 2, 64);
-    c += __shfl_xor(c, 1, 64);
-    return c;
+    for (int i = 0; i < 2; ++i) b[i] = halve32_sum(v[i], v[i + 2]);
+    return row16_sum(halve16_sum(b[0], b[1]));
 }
 template <int N> __device__ __forceinline__ int sumN_index();
 template <> __device__ __forceinline__ int sumN_index<8>() {
@@ -272,6 +230,13 @@ template <int NPART> struct PartialSum {
         return s + bias + resid;
     }
 };
+
+// one butterfly level of a (value, lowest index) arg-max on the VALU cross-lane network
+template <int M> __device__ __forceinline__ void argmax_step(float& v, int& idx) {
+    const float ov = lane_xor<M>(v);
+    const int oi = lane_xor<M>(idx);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
 
 template <int G> __device__ __forceinline__ float group_sum(float v) {  // aligned groups of G lanes, all lanes
     static_assert(G == 4 || G == 8 || G == 16, "group");
@@ -503,15 +468,25 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         }
         m_run = m_new;
     }
-#pragma unroll
-    for (int m = 32; m >= LPR; m >>= 1) {
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) acc[i] += __shfl_xor(acc[i], m, 64);
-    }
+    // the wave's un-normalised P.V: every thread holds EPL dims of its rows; sum over the rows by halving exchanges
+    // (lane halves, 16-lane rows, 8-lane groups: one value left per lane), then the last level on the DPP network
     l_run = wave_sum(l_run);
-    if (lane < LPR) {
+    if constexpr (EPL == 8) {      // bf16: 4 lanes per row; lane bits 5, 4, 3 pick the dim, bit 2 is summed last
+        float r4[4], r2[2];
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) pacc[wid * 32 + part * EPL + i] = acc[i];
+        for (int i = 0; i < 4; ++i) r4[i] = halve32_sum(acc[i], acc[i + 4]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r2[i] = halve16_sum(r4[i], r4[i + 2]);
+        float r1 = halve8_sum(r2[0], r2[1]);
+        r1 += lane_xor<4>(r1);
+        if ((lane & 4) == 0) pacc[wid * 32 + part * 8 + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)] = r1;
+    } else {                       // fp32: 8 lanes per row; lane bits 5, 4 pick the dim, bit 3 is summed last
+        float r2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r2[i] = halve32_sum(acc[i], acc[i + 2]);
+        float r1 = halve16_sum(r2[0], r2[1]);
+        r1 += lane_xor<8>(r1);
+        if ((lane & 8) == 0) pacc[wid * 32 + part * 4 + 2 * (lane >> 5) + ((lane >> 4) & 1)] = r1;
     }
     if (lane == 0) { pm[wid] = m_run; pl[wid] = l_run; }
     stamp(a.dbg, 4);
@@ -519,18 +494,13 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     if (wid == 0) {
         // merge the 16 waves: lane l (mod 16) owns wave l's (max, sum); 2x32 lanes own the 32 dims
         const float mw = pm[lane & 15], lw = pl[lane & 15];
-        float M = mw;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) M = fmaxf(M, __shfl_xor(M, m, 64));
-        const float f = expf(mw - M);            // waves with no live rows: exp(-inf) = 0
-        float den = lw * f;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) den += __shfl_xor(den, m, 64);
+        const float M = row16_max(mw);
+        const float den = row16_sum(lw * expf(mw - M));      // waves with no live rows: exp(-inf) = 0
         const int hf = lane >> 5, d = lane & 31;
         float num = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], __shfl(f, hf * 8 + w, 64), num);
-        num += __shfl_xor(num, 32, 64);
+        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], expf(pm[hf * 8 + w] - M), num);
+        num = xor32_sum(num);
         if (lane < 32) att[d] = num / den;
     }
     __syncthreads();
@@ -718,12 +688,8 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
             float l = lg[r];
             if (l > bv || (l == bv && vbase + r < bi)) { bv = l; bi = vbase + r; }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            float ov = __shfl_xor(bv, m, 64);
-            int oi2 = __shfl_xor(bi, m, 64);
-            if (ov > bv || (ov == bv && oi2 < bi)) { bv = ov; bi = oi2; }
-        }
+        argmax_step<32>(bv, bi); argmax_step<16>(bv, bi); argmax_step<8>(bv, bi);
+        argmax_step<4>(bv, bi); argmax_step<2>(bv, bi); argmax_step<1>(bv, bi);
         if (lane == 0) {
             TokPart tp; tp.v = bv; tp.idx = bi;
             a.tokpart[(size_t)b * kNP + p] = tp;
@@ -767,12 +733,8 @@ __device__ __forceinline__ float t2s_uniform(uint32_t seed_lo, uint32_t seed_hi,
 
 // block-wide (value, lowest index) argmax over 256 threads; every thread gets the winner
 __device__ __forceinline__ void t2s_block_argmax(float& v, int& idx, float* sv, int* si) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(v, m, 64);
-        const int oi = __shfl_xor(idx, m, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    argmax_step<32>(v, idx); argmax_step<16>(v, idx); argmax_step<8>(v, idx);
+    argmax_step<4>(v, idx); argmax_step<2>(v, idx); argmax_step<1>(v, idx);
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { sv[w] = v; si[w] = idx; }

@@ -443,96 +443,6 @@ static __global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __
     }
 }
 
-// ---- batched decode step (bf16, large batches): one token per sequence ---------------------------------
-// At 32+ sequences the per-sequence decode kernels re-stream every layer's weights once per sequence (from
-// L2) and run in several rounds of 1024-thread blocks; here the step is the prefill's GEMM chain on B rows
-// (rowgemm: weights streamed once per step) plus this attention, one block per (head, sequence):
-// append the new K/V row (rounded through the cache type, t2s_model.py:87-88), softmax(q K^T / sqrt(32)) V
-// over positions [0, kv_len[b]] (the token attends to itself).
-template <typename WT>
-struct BatchAttnArgs {
-    const float* qkv;        // [B][1536]
-    WT* kc;                  // this layer: [B][16][T][32]
-    WT* vc;
-    const int64_t* kv_len;   // [B]
-    int T;
-    float* out;              // [B][512]
-};
-
-// One thread per key (<= 4 keys per thread at T <= 1024), whole 64-byte rows per load.  Fusing the head's share of
-// the out-proj into this kernel (per-head [512][32] panel, 16 partial rows summed by the LayerNorm kernel, one launch
-// less per layer) was measured and rejected: step 0.98 -> 1.00 ms at 64 slots, 1.60 -> 1.84 ms at 256.  Two other shapes were
-// measured and rejected: 8 lanes per key with a 32-key pass loop (one exposed memory latency per pass: step
-// 0.93 -> 1.04 ms at B = 32) and the same with all passes preloaded (256 registers of K/V: 1.37 ms).
-template <typename WT>
-__global__ __launch_bounds__(256) void t2s_batch_attn_kernel(BatchAttnArgs<WT> a) {
-    __shared__ float qs[32], kn[32], vn[32], red[8], ored[4][32];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int64_t n64 = a.kv_len[b];
-    const int n = (int)(n64 < 0 ? 0 : (n64 > a.T - 1 ? a.T - 1 : n64));     // position of the new token
-    const float* row = a.qkv + (size_t)b * 1536 + h * 32;
-    WT* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
-    WT* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
-    if (tid < 32) {
-        qs[tid] = row[tid];
-        const WT kq = from_f32<WT>(row[512 + tid]), vq = from_f32<WT>(row[1024 + tid]);
-        kn[tid] = to_f32<WT>(kq); vn[tid] = to_f32<WT>(vq);
-        Kp[(size_t)n * kDh + tid] = kq; Vp[(size_t)n * kDh + tid] = vq;
-    }
-    __syncthreads();
-    constexpr int MAXK = 4;                                  // keys per thread: T <= 1024
-    float sc[MAXK];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-        const int t = tid + i * 256;
-        sc[i] = -INFINITY;
-        if (t <= n) {
-            float s = 0.f;
-            if (t == n) {
-#pragma unroll
-                for (int d = 0; d < 32; ++d) s = fmaf(qs[d], kn[d], s);
-            } else {
-                float kr[32];
-                Ld<WT, 32>::load(Kp + (size_t)t * kDh, kr);
-#pragma unroll
-                for (int d = 0; d < 32; ++d) s = fmaf(qs[d], kr[d], s);
-            }
-            sc[i] = s * 0.17677669529663687f;
-            mx = fmaxf(mx, sc[i]);
-        }
-    }
-    mx = block_max<4>(mx, red);
-    float sum = 0.f, o[32];
-#pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-        const int t = tid + i * 256;
-        if (t <= n) {
-            const float p = expf(sc[i] - mx);
-            sum += p;
-            if (t == n) {
-#pragma unroll
-                for (int d = 0; d < 32; ++d) o[d] = fmaf(p, vn[d], o[d]);
-            } else {
-                float vr[32];
-                Ld<WT, 32>::load(Vp + (size_t)t * kDh, vr);
-#pragma unroll
-                for (int d = 0; d < 32; ++d) o[d] = fmaf(p, vr[d], o[d]);
-            }
-        }
-    }
-    sum = block_sum<4>(sum, red);
-#pragma unroll
-    for (int d = 0; d < 32; ++d) {
-        const float w = wave_sum(o[d]);
-        if (lane == 0) ored[wid][d] = w;
-    }
-    __syncthreads();
-    if (tid < 32) a.out[(size_t)b * kD + h * 32 + tid] = ((ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid])) / sum;
-}
-
 // hlast[r] = hidden[r][x_len + y_len - 1]; and per-slot state after a (re)fill
 struct PrefillFinishArgs {
     const float* hidden;  // [nrows][l_max][512]

@@ -271,8 +271,9 @@ class Text2SemanticDecoder:
     @torch.inference_mode()
     def infer(self, x, y, bert_feature, top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
               repetition_penalty: float = 1.35, initial_suppression_steps: int = 10, check_interval: int = 5,
-              generator=None):
-        """t2s_model.py:385-464.  x int64[1,Lx], y int64[1,Ly], bert [1,Lx,1024] -> int64[1,1,N]."""
+              generator=None, max_new_tokens: int = None):
+        """t2s_model.py:385-464.  x int64[1,Lx], y int64[1,Ly], bert [1,Lx,1024] -> int64[1,1,N].
+        `max_new_tokens` (not in the reference, whose only length limit is the largest bucket) caps the loop."""
         rt = self._rt[1]
         buckets = self.cuda_graph_buckets[1]
         lx, ly = int(x.shape[1]), int(y.shape[1])
@@ -282,6 +283,8 @@ class Text2SemanticDecoder:
         n_iter = buckets[-1].max_kv_cache - Lp
         if n_iter < 1:
             raise RuntimeError("no decode iterations: prompt fills the largest bucket")
+        if max_new_tokens is not None:
+            n_iter = max(1, min(n_iter, int(max_new_tokens)))
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1   # the device loop serves greedy and device sampling alike
         rep_on = repetition_penalty != 1.0
@@ -471,11 +474,13 @@ class Text2SemanticDecoder:
             rt["tok_override"].copy_(tok)
 
         pred, orig = [], []
+        self.last_stats = {"slots": batch_size, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0}
         slot_orig = first + [-1] * (batch_size - actual)
         steps = [0] * batch_size
         ignore = [i >= actual for i in range(batch_size)]
         stop = False
         idx = 0
+        since = 0
         while not stop:
             # the reference tests after steps 1, 6, 11, ... of each 1000-iteration inner loop
             if greedy:
@@ -490,6 +495,8 @@ class Text2SemanticDecoder:
                 self._decode(batch_size, 1)
             for b in range(batch_size):
                 steps[b] += n
+            self.last_stats["steps"] += n
+            since += n
             idx += n
             last = idx - 1
             if idx >= 1000:
@@ -503,6 +510,8 @@ class Text2SemanticDecoder:
             kv = rt["kv_len"].clone()
             samples = rt["pre_tokens"][rows, kv.clamp(max=rt["T"])]
             kv_h, smp = torch.stack([kv, samples.to(kv.dtype)]).tolist()   # one device->host copy per window
+            self.last_stats["kv_rows"] += sum(kv_h) * since       # ~ K/V rows read by the steps since the previous window
+            since = 0
             cap = caps[min(bucket_i, len(caps) - 1)]
             reached = [k + check_interval >= cap for k in kv_h]
             eos = [t == self.EOS for t in smp]
@@ -555,6 +564,7 @@ class Text2SemanticDecoder:
                 req = [c for _, c in refill]
                 xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in req], [y[c] for c in req], [bert_feature[c] for c in req])
                 self.prefill_slots(batch_size, [i for i, _ in refill], xy1, xl1, yl1)
+                self.last_stats["refills"] += len(refill)
                 if not greedy:  # every refilled slot needs its own first sample, drawn in slot order (t2s_model.py:713-714)
                     for i, _ in refill:
                         rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]
