@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--version", default="v2Pro", choices=["v2", "v2Pro", "v2ProPlus"])
     ap.add_argument("--slots", type=int, default=CB_SLOTS, help="cb: slots per GPU")
     ap.add_argument("--requests", type=int, default=CB_REQUESTS_PER_GPU, help="cb: requests per GPU per step")
+    ap.add_argument("--overlap", action="store_true", help="cb: vocoder batches on a side stream while the slot loop decodes (measured "
+                    "+1 .. +4 %% end to end: the two share the chip) instead of after it in TTS.infer_batched's length-balanced order")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / time-to-first-audio / fp32 extras")
@@ -154,7 +156,7 @@ def cpu_baseline_worker(kind, version):
         nreq, slots = 12, 8
         lens = synth.mixed_lengths(nreq)
         reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
-        o = orc.T2SOracle(cfg, gw, [(slots, 256), (slots, 512)])
+        o = orc.T2SOracle(cfg, gw, [(slots, 256), (slots, 400)])   # EOS- / capacity-terminated: ~ the GPU run's token mix
         avail = _usable_cores()
         orc.set_num_threads(min(avail, 32))
         t0 = time.perf_counter()
@@ -474,7 +476,7 @@ def run_cb(a):
     vdtype = torch.bfloat16 if a.dtype == "fp8" else dtype       # fp8 operands exist in the GPT batched step only
     sbytes = 4 if a.dtype == "fp32" else 2
     cfg = synth.gpt_config()
-    gw = synth.gpt_weights(cfg, seed=1234, eos_gain=4.0)
+    gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)      # lengths come from the per-request budgets below, not from EOS
     hps = synth.sovits_hps(a.version)
     sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
     gin = hps["model"]["gin_channels"]
@@ -487,7 +489,8 @@ def run_cb(a):
     ge = book.sync("speaker-0", [torch.from_numpy(synth.synth_ge(0, gin, 1234))] if rank == 0 else None)[0]
 
     n_req = a.requests * world
-    lens = synth.mixed_lengths(n_req)
+    lens = synth.mixed_lengths(n_req)                         # Lx2 ~ U[20,120], Ly ~ U[75,150]   
+    new_tok = synth.mixed_new_tokens(n_req)                   # N ~ U[50,400]
     reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
     xs = [torch.from_numpy(r[0]).to(dev) for r in reqs]
     ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
@@ -512,11 +515,24 @@ def run_cb(a):
             tot += T
         return tot
 
+    def vocode_batch(items):
+        """one time-concatenated vocoder batch (completion order): the overlapped engine calls this on its side stream"""
+        T = int(sum(2 * len(p) for _, p in items))
+        if T:
+            z = torch.randn(1, 192, T, device=dev)
+            voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge.expand(-1, -1, T).contiguous())
+        return {i: 2 * len(p) for i, p in items}
+
     def step(i, timed_idx):
         torch.cuda.synchronize(dev); s0 = time.perf_counter()
-        pred, idx = eng.run_gpt(xs, ys, bs, top_k=1)
-        torch.cuda.synchronize(dev); s1 = time.perf_counter()
-        frames = vocode(list(zip(idx.tolist(), pred)))
+        if (not a.overlap):
+            pred, idx = eng.run_gpt(xs, ys, bs, top_k=1, max_new_tokens=new_tok)
+            torch.cuda.synchronize(dev); s1 = time.perf_counter()
+            frames = vocode(list(zip(idx.tolist(), pred)))
+        else:
+            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, top_k=1, max_new_tokens=new_tok)
+            s1 = time.perf_counter()
+            frames = int(sum(res.values()))
         torch.cuda.synchronize(dev); s2 = time.perf_counter()
         if timed_idx is not None:
             acc["tok"] += int(sum(len(p) for p in pred)); acc["frames"] += frames
@@ -539,14 +555,17 @@ def run_cb(a):
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic (seeded random weights of the real architecture, synthetic phoneme/token ids)",
         "config": {"workload": "%s: %s continuous batching, %d mixed-length requests per GPU per step through %d slots per GPU "
-                               "(greedy, EOS-terminated), flow/Generator over every utterance in time-concatenated batches of 10"
+                               "(greedy, 50..400 new tokens per request), flow/Generator over every utterance in time-concatenated batches of 10"
                                % (which, a.version, a.requests, a.slots),
                    "requests_per_step": n_req, "gpt_cache": [(a.slots, 512), (a.slots, 1024)],
+                   "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
+                              "overlapped with the slot loop on a side stream, batches of 10 in completion order",
                    "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "
                                   "speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
         "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
         "tokens_per_step": tok_all / a.steps, "mean_tokens_per_request": tok_all / a.steps / n_req,
-        "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"], "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9),
+        "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"],
+        "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
         "rank0_requests_served_per_step": acc["mine"] / a.steps,
     }
     if rank == 0:
@@ -559,12 +578,15 @@ def run_cb(a):
         by = acc["steps"] * wbytes + acc["kv_rows"] * KV_BYTES_PER_POS * sbytes
         gbs = by / acc["t_ar"] / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "batched decode step (5 launches per layer, csrc/t2s_batch.h)",
+                           "traffic": None,
+                           "kernel": ("batched decode step (5 launches per layer, csrc/t2s_batch.h)" if a.slots >= t2s.batched_min else
+                                      "decode step, 2 launches per layer with 2 / 4 sequences per block (csrc/t2s_decode_multi.h)" if a.slots > 16
+                                      else "decode step, 2 launches per layer (csrc/t2s_decode.h)"),
                            "ms_per_step_of_the_slot_loop": acc["t_ar"] / max(1, acc["steps"]) * 1e3,
                            "note": "algorithmic bytes of the AR phase = decode steps x weight bytes + K/V rows read x row bytes (prefills and "
                                    "refills are inside the time, not in the bytes) / AR wall time of rank 0"}
         vbytes, vflops = vocoder_algorithmic(a.version, 4 if a.dtype == "fp32" else 2)
-        if acc["frames"]:
+        if acc["frames"] and (not a.overlap):
             g = vbytes * acc["frames"] / acc["t_voc"] / 1e9
             out["roofline_vocoder"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                                        "traffic": None, "mfma_tflops": vflops * acc["frames"] / acc["t_voc"] / 1e12}

@@ -1,5 +1,7 @@
 // C ABI of the MI355X GPT-SoVITS hot path (include/gsv_tts_hip.h), SoVITS part: flow + Generator (tapgemm / wconv /
 // wups / flowfuse) and enc_p.  Workspaces come from the caller; nothing is allocated inside a pass.
+#include <tuple>
+
 #include "abi_common.h"
 #include "flowfuse.h"
 #include "encp.h"
@@ -52,6 +54,15 @@ struct gsv_voc {
     std::vector<VocStage> stages;
     int total_up = 1;
     int max_stage_elems_per_frame = 0;  // max over stages of ld(C) * time multiplier
+    // one captured flow + Generator pass per (static buffers, T): the reference's per-bucket CUDA graphs (models.py:322-369)
+    struct GraphKey {
+        const void *z, *m, *g, *o, *w; int T, Tg;
+        bool operator<(const GraphKey& r) const {
+            return std::tie(z, m, g, o, w, T, Tg) < std::tie(r.z, r.m, r.g, r.o, r.w, r.T, r.Tg);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
 };
 
 namespace {
@@ -731,6 +742,8 @@ int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out) {
 int gsv_voc_destroy(gsv_voc* v) {
     if (!v) return GSV_OK;
     (void)hipDeviceSynchronize();
+    for (auto& kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     voc_free(v);
     delete v;
     return GSV_OK;
@@ -784,6 +797,54 @@ int gsv_voc_flow_dec(gsv_voc* v, const float* z_p, const float* y_mask, const fl
     if (!v || !z_p || !y_mask || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
     return v->cfg.dtype == GSV_BF16 ? voc_run<bf16_t>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream))
                                     : voc_run<float>(v, 3, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, S(stream));
+}
+
+int gsv_voc_flow_dec_graph(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !z_p || !y_mask || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    const gsv_voc::GraphKey key{z_p, y_mask, ge, out, workspace, T, Tg};
+    auto it = v->graphs.find(key);
+    if (it == v->graphs.end()) {
+        if (v->graphs.size() >= 64) return fail(GSV_ERR_STATE, "too many captured vocoder passes (64): reuse the static buffers of a bucket");
+        if (!v->cap_stream && hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(GSV_ERR_HIP, "hipStreamCreate failed");
+        // an eager pass first: it sets every kernel's dynamic-LDS attribute outside the capture and validates the arguments
+        if (int rc = gsv_voc_flow_dec(v, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, stream)) return rc;
+        HIPCHK(hipStreamSynchronize(S(stream)));
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(v->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = gsv_voc_flow_dec(v, z_p, y_mask, ge, T, Tg, out, workspace, workspace_bytes, v->cap_stream);
+        hipError_t e = hipStreamEndCapture(v->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        it = v->graphs.emplace(key, exec).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, S(stream)));
+    return GSV_OK;
+}
+
+// y[c][j] = linear resampling of x[c][:] to T_out points, torch's F.interpolate(mode="linear", align_corners=False):
+// src = (j + 0.5) * T_in / T_out - 0.5 clamped at 0, weights (1 - frac, frac), right neighbour clamped to T_in - 1
+static __global__ __launch_bounds__(256) void resample_linear_kernel(const float* __restrict__ x, int C, int T_in, float* __restrict__ y, int T_out) {
+    const int j = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (j >= T_out) return;
+    const float scale = (float)T_in / (float)T_out;
+    float src = ((float)j + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+    const int i0 = min((int)src, T_in - 1), i1 = min(i0 + 1, T_in - 1);
+    const float f = src - (float)i0;
+    y[(size_t)c * T_out + j] = (1.0f - f) * x[(size_t)c * T_in + i0] + f * x[(size_t)c * T_in + i1];
+}
+
+int gsv_voc_resample_linear(const float* x, int C, int T_in, float* y, int T_out, void* stream) {
+    if (!x || !y || C < 1 || T_in < 1 || T_out < 1) return fail(GSV_ERR_ARG, "resample: bad arguments");
+    hipLaunchKernelGGL(resample_linear_kernel, dim3(cdiv(T_out, 256), C), dim3(256), 0, S(stream), x, C, T_in, y, T_out);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
 }
 
 int gsv_voc_flow(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* z_out,

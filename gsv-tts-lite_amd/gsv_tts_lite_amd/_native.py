@@ -21,7 +21,7 @@ EXPORTS = [
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_prefill_slots", "gsv_t2s_decode_hidden",
     "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
-    "gsv_voc_flow_dec", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
+    "gsv_voc_flow_dec", "gsv_voc_flow_dec_graph", "gsv_voc_resample_linear", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
     "gsv_align_workspace", "gsv_align_viterbi",
     "gsv_ref_create", "gsv_ref_destroy", "gsv_ref_load_tensor", "gsv_ref_finalize", "gsv_ref_workspace",
     "gsv_ref_spectrogram", "gsv_ref_get_ge", "gsv_ref_extract_latent",
@@ -87,6 +87,8 @@ def lib():
         "gsv_voc_load_tensor": [vp, ctypes.c_char_p, vp, i64, vp],
         "gsv_voc_finalize": [vp, vp],
         "gsv_voc_flow_dec": [vp, vp, vp, vp, i, i, vp, vp, sz, vp],
+        "gsv_voc_flow_dec_graph": [vp, vp, vp, vp, i, i, vp, vp, sz, vp],
+        "gsv_voc_resample_linear": [vp, i, i, vp, i, vp],
         "gsv_voc_flow": [vp, vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_dec": [vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_has_enc_p": [vp],

@@ -148,6 +148,43 @@ class ContinuousBatchingEngine:
         self.last_taken = list(src.taken)
         return pred, idx
 
+    def run_overlapped(self, xs, ys, berts, vocode_batch: Callable, batch: int = 10, costs=None, **sampling):
+        """GPT on this rank's share with the vocoder OVERLAPPED: every `batch` finished utterances (the reference's
+        sovits_batch_size, TTS.py:728) go to `vocode_batch(list of (index, tokens)) -> dict` on a side stream while the
+        slot loop keeps decoding -- the loop is latency-bound on a few CUs per kernel, so the vocoder's wide kernels
+        fill the rest of the chip.  (Batches form in completion order here; TTS.infer_batched's length-balanced order,
+        TTS.py:705-720, needs all lengths first and is what the non-overlapped path keeps.)
+        -> (this rank's results dict index -> payload, pred, idx)"""
+        dev = self.decoder.device
+        side = torch.cuda.Stream(device=dev)
+        pending: List = []
+        results: Dict[int, object] = {}
+
+        def flush():
+            if not pending:
+                return
+            items = pending[:]
+            pending.clear()
+            ev = torch.cuda.Event()
+            ev.record()                      # the token tensors were produced on the current stream
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                results.update(vocode_batch(items))
+
+        def on_finish(i, tok):
+            pending.append((int(i), tok))
+            if len(pending) >= batch:
+                flush()
+
+        if costs is None:
+            costs = [int(x.shape[0]) for x in xs]
+        src = self._source(costs)
+        pred, idx = self.decoder.infer_batched(xs, ys, berts, source=src, slots=self.slots, on_finish=on_finish, **sampling)
+        self.last_taken = list(src.taken)
+        flush()
+        side.synchronize()
+        return results, pred, idx
+
     def gather(self, local: Dict[int, object], n_total: int, dst: Optional[int] = None) -> Optional[List[object]]:
         """index -> payload of this rank  =>  the full list in global index order (on `dst`, or on every rank)"""
         if self.world == 1:

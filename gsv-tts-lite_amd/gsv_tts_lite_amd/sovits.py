@@ -85,6 +85,39 @@ class _VocoderNative:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def flow_dec_bucket(self, z_p, y_mask, ge):
+        """flow_dec replayed from the hipGraph of this length's bucket (gsv_voc_flow_dec_graph): static buffers are
+        allocated once per (T, Tg), the chunk is copied in, the captured pass replayed, the result cloned out -- the
+        protocol of the reference's graph path (SoVITS/models.py:406-423)."""
+        z, ge, T, Tg = self._prep(z_p, ge)
+        key = (T, Tg)
+        if not hasattr(self, "_buckets"):
+            self._buckets = {}
+        b = self._buckets.get(key)
+        if b is None:
+            need = N.lib().gsv_voc_workspace(self._h, T)
+            b = {"z": torch.zeros(1, self.inter, T, dtype=torch.float32, device=self.device),
+                 "m": torch.zeros(T, dtype=torch.float32, device=self.device),
+                 "g": torch.zeros(1, self.gin, Tg, dtype=torch.float32, device=self.device),
+                 "o": torch.zeros(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device),
+                 "w": torch.empty(need, dtype=torch.uint8, device=self.device)}
+            self._buckets[key] = b
+        b["z"].copy_(z)
+        b["m"].copy_(y_mask.to(device=self.device, dtype=torch.float32).reshape(-1))
+        b["g"].copy_(ge)
+        N.check(N.lib().gsv_voc_flow_dec_graph(self._h, b["z"].data_ptr(), b["m"].data_ptr(), b["g"].data_ptr(), T, Tg,
+                                               b["o"].data_ptr(), b["w"].data_ptr(), b["w"].numel(),
+                                               N.current_stream_ptr(self.device)))
+        return b["o"].clone()
+
+    def resample_linear(self, x, T_out):
+        """[1, C, T] fp32 -> [1, C, T_out], F.interpolate(mode="linear") on the device (gsv_voc_resample_linear)"""
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        y = torch.empty(1, x.shape[1], T_out, dtype=torch.float32, device=self.device)
+        N.check(N.lib().gsv_voc_resample_linear(x.data_ptr(), x.shape[1], x.shape[2], y.data_ptr(), T_out,
+                                                N.current_stream_ptr(self.device)))
+        return y
+
     def _prep(self, z, ge):
         z = z.to(device=self.device, dtype=torch.float32).contiguous()
         ge = ge.to(device=self.device, dtype=torch.float32).contiguous()
@@ -168,7 +201,7 @@ class SynthesizerTrn:
         self._voc = None
         self.enc_p = None
         self._ref = None
-        self.native_enc_p = True   # bf16: run enc_p on device when its tensors are loaded (fp32 keeps the torch path)
+        self.native_enc_p = True   # bf16: run enc_p on device when its tensors are loaded, incl. speed != 1 and streaming (fp32 keeps the torch path)
 
     def load_state_dict(self, sd, strict=False):
         self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
@@ -179,9 +212,11 @@ class SynthesizerTrn:
 
     @torch.inference_mode()
     def initialize_runtime(self, dtype, device, sovits_caches):
-        """models.py:322-369.  The reference captures one CUDA graph per cache length; here the
-        native path has no per-length state (it allocates nothing per call), so `sovits_caches`
-        only records the bucket list for API compatibility."""
+        """models.py:322-369.  The reference captures one CUDA graph per cache length.  Here a pass whose length EQUALS a
+        bucket (the streaming chunk sizes, default [50, 55]) replays a hipGraph of the whole flow + Generator pass
+        (gsv_voc_flow_dec_graph, captured on first use); other lengths run eagerly -- the reference pads them to the
+        next bucket, which lets the padded frames' conditioning leak into the last real frames, so
+        the eager pass is the faithful one for them."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("the MI355X hot path needs a GPU device; there is no CPU fallback")
@@ -235,7 +270,7 @@ class SynthesizerTrn:
         if ge.shape[-1] != 1:
             ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
         ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
-        if self.native_enc_p and self._voc.has_enc_p and speed == 1 and codes.shape[0] == 1 and codes.shape[1] == 1:
+        if self.native_enc_p and self._voc.has_enc_p and codes.shape[0] == 1 and codes.shape[1] == 1:
             # enc_p on device (csrc/encp.h): quantizer lookup, x2 upsampling, the three encoders and MRTE
             m_p, logs_p, attn = self._voc.enc_p(codes[0, 0], text[0], ge_in, slice_indices)
             if stream_mode:
@@ -248,6 +283,13 @@ class SynthesizerTrn:
                 if self.enc_p.y_overlap is not None:
                     stats[:, :, :overlap_len] = self.enc_p.y_overlap * (1 - alpha) + stats[:, :, :overlap_len] * alpha
                 self.enc_p.y_overlap = stats[:, :, -overlap_len:].clone()
+                m_p, logs_p = torch.split(stats, self.inter_channels, dim=1)
+                m_p, logs_p = m_p.contiguous(), logs_p.contiguous()
+            if speed != 1:
+                # models.py:217-219 resamples the encoder features linearly to int(T / speed) + 1 frames before `proj`;
+                # proj is 1x1 affine, so the same resampling of its output is the same function (mask: all ones)
+                stats = torch.cat([m_p, logs_p], dim=1)
+                stats = self._voc.resample_linear(stats, int(stats.shape[-1] / speed) + 1)
                 m_p, logs_p = torch.split(stats, self.inter_channels, dim=1)
                 m_p, logs_p = m_p.contiguous(), logs_p.contiguous()
             y_mask = torch.ones(1, 1, m_p.shape[-1], dtype=torch.float32, device=self.device)
@@ -264,6 +306,9 @@ class SynthesizerTrn:
             z_p = m_p + noise * torch.exp(logs_p) * noise_scale
         else:
             z_p = m_p
-        o = self.flow_dec(z_p, y_mask, ge)
+        if cuda_graph and z_p.shape[-1] in self.cuda_graph_buckets and ge.shape[-1] == 1:
+            o = self._voc.flow_dec_bucket(z_p, y_mask, ge)
+        else:
+            o = self.flow_dec(z_p, y_mask, ge)
         attn = self.enc_p.mrte.cross_attention.attn
         return o, attn[0, ...]

@@ -341,6 +341,11 @@ def mixed_lengths(n: int, seed: int = 1234):
     return [(int(p), int(q)) for p, q in zip(a, b)]
 
 
+def mixed_new_tokens(n: int, seed: int = 1234):
+    """generated-length targets of the mixed-length request set: N ~ U[50, 400]"""
+    return [int(v) for v in hashed_ints("mixed.new", n, 50, 401, seed)]
+
+
 def synth_attn(seed: int, heads: int, frames: int, phonemes: int, lead: int = 0, tail: int = 0,
                noise: float = 0.2) -> np.ndarray:
     """Synthetic MRTE cross-attention [heads, frames, phonemes] for the subtitle-alignment tests: a monotone

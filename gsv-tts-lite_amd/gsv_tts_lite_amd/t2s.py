@@ -411,13 +411,16 @@ class Text2SemanticDecoder:
     def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
                       top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
                       repetition_penalty: float = 1.35, check_interval: int = 5, generator=None,
-                      source=None, slots: int = None):
+                      source=None, slots: int = None, on_finish=None, max_new_tokens=None):
         """t2s_model.py:555-734: continuous batching over the slots of one batch-size family.
 
         `source` (engine.RequestSource) replaces "the next request is x[cur]" (:696-700) by "the next request is
         whatever the shared queue hands this rank": x / y / bert_feature are then the GLOBAL lists, the returned
         indices are global, and `slots` names the batch-size family to run (default: as the reference, the
-        smallest family that holds len(x))."""
+        smallest family that holds len(x)).  `on_finish(index, tokens)` is called as each request completes (the
+        engine starts that utterance's vocoder work on a side stream while the slots keep decoding).
+        `max_new_tokens` (a list indexed like x; not in the reference, which stops at EOS or a full cache only) ends
+        request i once it has produced that many tokens -- tested at the same 5-step cadence as EOS, cut exactly."""
         B = len(x)
         sizes = sorted(self.cuda_graph_buckets)
         if slots is not None:
@@ -515,6 +518,8 @@ class Text2SemanticDecoder:
             cap = caps[min(bucket_i, len(caps) - 1)]
             reached = [k + check_interval >= cap for k in kv_h]
             eos = [t == self.EOS for t in smp]
+            if max_new_tokens is not None:   # a token budget ends a request like an EOS would
+                eos = [e or (slot_orig[b] >= 0 and steps[b] - 1 >= max_new_tokens[slot_orig[b]]) for b, e in enumerate(eos)]
             fin = [(not ignore[b]) and (eos[b] or reached[b]) for b in range(batch_size)]
             if not any(fin):
                 continue
@@ -532,9 +537,13 @@ class Text2SemanticDecoder:
                 a0, b0 = kv_h[i] - steps[i] + 1, kv_h[i]
                 hit = np.nonzero(fin_rows[j, a0:b0] == self.EOS)[0]   # cut at the first EOS (t2s_model.py:675-678)
                 n_keep = int(hit[0]) if hit.size else max(0, b0 - a0)
+                if max_new_tokens is not None:
+                    n_keep = min(n_keep, int(max_new_tokens[slot_orig[i]]))
                 seg = rt["pre_tokens"][i, a0: a0 + n_keep]
                 pred.append(seg.clone())
                 orig.append(slot_orig[i])
+                if on_finish is not None:
+                    on_finish(slot_orig[i], pred[-1])
                 steps[i] = 0
                 kv_h[i] = 0
                 rt["kv_len"][i] = 0

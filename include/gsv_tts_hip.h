@@ -186,6 +186,16 @@ int gsv_voc_finalize(gsv_voc* h, void* stream);
 size_t gsv_voc_workspace(gsv_voc* h, int T);
 int gsv_voc_flow_dec(gsv_voc* h, const float* z_p, const float* y_mask, const float* ge, int T, int Tg,
                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same pass replayed from a hipGraph captured on first use for this (z_p, y_mask, ge, out, workspace, T, Tg) --
+ * the reference's per-bucket CUDA graphs of SynthesizerTrn.initialize_runtime / decode (models.py:322-369, 406-423): the
+ * caller owns STATIC buffers per bucket length, copies the chunk in (zero mask beyond the real length), replays, slices.
+ * A 50-frame streaming chunk is ~60 launch-bound kernels; replay removes their host launch cost. */
+int gsv_voc_flow_dec_graph(gsv_voc* h, const float* z_p, const float* y_mask, const float* ge, int T, int Tg,
+                           float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* x fp32 [C][T_in] -> y fp32 [C][T_out], linear resampling as F.interpolate(mode="linear", align_corners=False): the
+ * `speed != 1` resampling of TextEncoder.infer (models.py:217-219), applied to the projected statistics (proj is 1x1
+ * affine, so resampling its output equals resampling its input). */
+int gsv_voc_resample_linear(const float* x, int C, int T_in, float* y, int T_out, void* stream);
 /* parity seams: the flow alone (ResidualCouplingBlock.forward reverse, models.py:58-65) and the
  * Generator alone (models.py:113-132); same layouts. */
 int gsv_voc_flow(gsv_voc* h, const float* z_p, const float* y_mask, const float* ge, int T, int Tg,

@@ -57,11 +57,15 @@ ORC_API void orc_set_num_threads(int n) {
  *   ORC_R_LIN     the input rows of every linear rounded to bf16 (MFMA operand type of the prompt / batched GEMMs)
  *   ORC_R_ATTN    prompt attention: q and the un-normalised probabilities rounded to bf16 (MFMA flash attention)
  *   ORC_R_FP8     qkv / mlp.0 / mlp.2 inputs rounded to e4m3 at unit scale, saturating (batched fp8 step)
+ *   ORC_R_VOC     flow + Generator: every stored activation rounded to bf16 where the bf16 HIP path stores bf16
+ *                 (conv outputs after bias / conditioning / residual; the leaky-ReLU'd conv operands; the branch mean;
+ *                 the flow's h, gate output, skip operand and updated half), fp32 accumulation inside each op
  * 0 = the fp32 reference arithmetic. */
 #define ORC_R_KV 1
 #define ORC_R_LIN 2
 #define ORC_R_ATTN 4
 #define ORC_R_FP8 8
+#define ORC_R_VOC 16
 static int g_round = 0;
 ORC_API void orc_set_rounding(int flags) { g_round = flags; }
 ORC_API int orc_get_rounding(void) { return g_round; }
@@ -93,6 +97,11 @@ static inline float e4m3r(float f) {
     return copysignf(a, f);
 }
 ORC_API void orc_round_bf16(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = bf16r(x[i]); }
+static void voc_round(float* x, size_t n) {
+    if (!(g_round & ORC_R_VOC)) return;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; ++i) x[i] = bf16r(x[i]);
+}
 ORC_API void orc_round_e4m3(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = e4m3r(x[i]); }
 
 /* ------------------------------------------------------------------ basic ops */
@@ -337,7 +346,8 @@ ORC_API void orc_conv1d(const float* x, int Cin, int T, const float* w, const fl
         for (int c = 0; c < Cin; ++c)
             for (int t = 0; t < T; ++t) {
                 float v = x[(size_t)c * T + t];
-                act[(size_t)c * T + t] = v >= 0.f ? v : v * in_slope;
+                v = v >= 0.f ? v : v * in_slope;
+                act[(size_t)c * T + t] = (g_round & ORC_R_VOC) ? bf16r(v) : v;   /* the MFMA operand is bf16(lrelu(x)) */
             }
         xin = act;
     }
@@ -396,7 +406,7 @@ ORC_API void orc_conv_transpose1d(const float* x, int Cin, int T, const float* w
             const float* wr = w + ((size_t)ci * Cout + co) * k;
             for (int i = 0; i < T; ++i) {
                 float xv = xr[i];
-                if (in_slope != 1.0f && xv < 0.f) xv *= in_slope;
+                if (in_slope != 1.0f && xv < 0.f) { xv *= in_slope; if (g_round & ORC_R_VOC) xv = bf16r(xv); }
                 int n0 = i * u - pad;
                 for (int kk = 0; kk < k; ++kk) {
                     int n = n0 + kk;
@@ -425,6 +435,12 @@ ORC_API void orc_generator(const float* pack, int Cz, int C0, int gin, int n_up,
     const float* cond_w = p; p += (size_t)C0 * gin;
     const float* cond_b = p; p += C0;
     float* x = (float*)malloc(sizeof(float) * (size_t)C0 * T);
+    float* zr = NULL;
+    float* gr = NULL;
+    if (g_round & ORC_R_VOC) {   /* the ABI converts z and ge to the activation type */
+        zr = (float*)malloc(sizeof(float) * (size_t)Cz * T); memcpy(zr, z, sizeof(float) * (size_t)Cz * T); voc_round(zr, (size_t)Cz * T); z = zr;
+        gr = (float*)malloc(sizeof(float) * (size_t)gin * Tg); memcpy(gr, g, sizeof(float) * (size_t)gin * Tg); voc_round(gr, (size_t)gin * Tg); g = gr;
+    }
     orc_conv1d(z, Cz, T, pre_w, pre_b, C0, 7, 1, 3, 1.0f, x);
     {
         float* c = (float*)malloc(sizeof(float) * (size_t)C0 * Tg);
@@ -433,6 +449,8 @@ ORC_API void orc_generator(const float* pack, int Cz, int C0, int gin, int n_up,
             for (int t = 0; t < T; ++t) x[(size_t)co * T + t] += c[(size_t)co * Tg + (Tg == 1 ? 0 : t)];
         free(c);
     }
+    voc_round(x, (size_t)C0 * T);
+    free(zr); free(gr);
     int C = C0, Tc = T;
     for (int i = 0; i < n_up; ++i) {
         int u = up_rates[i], k = up_kernels[i], Co = C / 2;
@@ -444,6 +462,7 @@ ORC_API void orc_generator(const float* pack, int Cz, int C0, int gin, int n_up,
         free(x);
         C = Co; Tc = Tn;
         size_t n = (size_t)C * Tc;
+        voc_round(y, n);
         float* xs = (float*)calloc(n, sizeof(float));
         float* xr = (float*)malloc(sizeof(float) * n);
         float* t1 = (float*)malloc(sizeof(float) * n);
@@ -456,12 +475,21 @@ ORC_API void orc_generator(const float* pack, int Cz, int C0, int gin, int n_up,
             memcpy(xr, y, sizeof(float) * n);
             for (int d = 0; d < 3; ++d) {
                 orc_conv1d(xr, C, Tc, w1[d], b1[d], C, kk, rdil[d], rdil[d] * (kk - 1) / 2, 0.1f, t1);
+                /* bf16 path: the first conv stores lrelu(t1) (one rounding), which orc_conv1d's own lrelu + rounding of
+                 * the un-rounded t1 reproduces */
                 orc_conv1d(t1, C, Tc, w2[d], b2[d], C, kk, 1, (kk - 1) / 2, 0.1f, t2);
                 for (size_t e = 0; e < n; ++e) xr[e] = t2[e] + xr[e];
+                voc_round(xr, n);
             }
-            for (size_t e = 0; e < n; ++e) xs[e] += xr[e];
+            if (g_round & ORC_R_VOC) {   /* the branch mean is ((a + b) + c) / 3 in fp32 from the stored tensors */
+                if (j == 0) memcpy(xs, xr, sizeof(float) * n);
+                else for (size_t e = 0; e < n; ++e) xs[e] = xs[e] + xr[e];
+            } else {
+                for (size_t e = 0; e < n; ++e) xs[e] += xr[e];
+            }
         }
         for (size_t e = 0; e < n; ++e) xs[e] = xs[e] / (float)n_rk;
+        voc_round(xs, n);
         free(xr); free(t1); free(t2); free(y);
         x = xs;
     }
@@ -501,6 +529,11 @@ ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, i
     float* gc = (float*)malloc(sizeof(float) * (size_t)8 * H * Tg);
     float* m = (float*)malloc(sizeof(float) * (size_t)half * T);
     float* tmp = (float*)malloc(sizeof(float) * (size_t)C * T);
+    float* gq = NULL;
+    if (g_round & ORC_R_VOC) {
+        voc_round(x, (size_t)C * T);
+        gq = (float*)malloc(sizeof(float) * (size_t)gin * Tg); memcpy(gq, g, sizeof(float) * (size_t)gin * Tg); voc_round(gq, (size_t)gin * Tg); g = gq;
+    }
     for (int f = n_flows - 1; f >= 0; --f) {
         /* Flip: reverse channel order (modules.py:504-511) */
         for (int c = 0; c < C; ++c) memcpy(tmp + (size_t)c * T, x + (size_t)(C - 1 - c) * T, sizeof(float) * T);
@@ -514,6 +547,7 @@ ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, i
         orc_conv1d(x, half, T, pre_w, pre_b, H, 1, 1, 0, 1.0f, h);
         for (int c = 0; c < H; ++c)
             for (int t = 0; t < T; ++t) h[(size_t)c * T + t] *= mask[t];
+        voc_round(h, HT);
         orc_conv1d(g, gin, Tg, cond_w, cond_b, 8 * H, 1, 1, 0, 1.0f, gc);
         memset(outp, 0, sizeof(float) * HT);
         for (int l = 0; l < 4; ++l) {
@@ -530,11 +564,13 @@ ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, i
                     float sa = a[(size_t)(H + c) * T + t] + gc[(size_t)(l * 2 * H + H + c) * Tg + tg];
                     acts[(size_t)c * T + t] = tanhf(ta) * (1.0f / (1.0f + expf(-sa)));
                 }
+            voc_round(acts, HT);
             orc_conv1d(acts, H, T, rs_w, rs_b, R, 1, 1, 0, 1.0f, rs);
             if (l < 3) {
                 for (int c = 0; c < H; ++c)
                     for (int t = 0; t < T; ++t) {
                         h[(size_t)c * T + t] = (h[(size_t)c * T + t] + rs[(size_t)c * T + t]) * mask[t];
+                        if (g_round & ORC_R_VOC) h[(size_t)c * T + t] = bf16r(h[(size_t)c * T + t]);
                         outp[(size_t)c * T + t] += rs[(size_t)(H + c) * T + t];
                     }
             } else {
@@ -543,6 +579,7 @@ ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, i
         }
         for (int c = 0; c < H; ++c)
             for (int t = 0; t < T; ++t) outp[(size_t)c * T + t] *= mask[t];
+        voc_round(outp, HT);
         const float* post_w = p; p += (size_t)half * H;
         const float* post_b = p; p += half;
         orc_conv1d(outp, H, T, post_w, post_b, half, 1, 1, 0, 1.0f, m);
@@ -552,7 +589,9 @@ ORC_API void orc_flow_reverse(const float* pack, int n_flows, int half, int H, i
                 float mm = m[(size_t)c * T + t] * mask[t];
                 float* x1 = x + (size_t)(half + c) * T + t;
                 *x1 = (*x1 - mm) * mask[t];
+                if (g_round & ORC_R_VOC) *x1 = bf16r(*x1);
             }
     }
+    free(gq);
     free(h); free(outp); free(a); free(acts); free(rs); free(gc); free(m); free(tmp);
 }

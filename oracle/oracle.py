@@ -124,7 +124,7 @@ def sine_pe(n_pos: int, dim: int) -> np.ndarray:
     return pe
 
 
-R_KV, R_LIN, R_ATTN, R_FP8 = 1, 2, 4, 8     # gsv_oracle.c ORC_R_*
+R_KV, R_LIN, R_ATTN, R_FP8, R_VOC = 1, 2, 4, 8, 16     # gsv_oracle.c ORC_R_*
 
 
 def round_bf16(a):
@@ -512,7 +512,12 @@ def fold_weight_norm(g, v):
 
 
 class VocoderOracle:
-    def __init__(self, hps, weights):
+    """numerics "bf16": conv weights (flow: after the weight-norm fold) rounded to bf16 and every stored activation
+    rounded where the bf16 HIP path stores bf16 (ORC_R_VOC); conv_post keeps fp32 weights, as the product does."""
+
+    def __init__(self, hps, weights, numerics="fp32"):
+        assert numerics in ("fp32", "bf16")
+        self.numerics = numerics
         m = hps["model"]
         self.H = m["hidden_channels"]; self.inter = m["inter_channels"]; self.gin = m["gin_channels"]
         self.C0 = m["upsample_initial_channel"]
@@ -530,6 +535,8 @@ class VocoderOracle:
                 for c in ("convs1", "convs2"):
                     for d in range(3):
                         parts += [w["%s%s.%d.weight" % (r, c, d)], w["%s%s.%d.bias" % (r, c, d)]]
+        if numerics == "bf16":
+            parts = [p if p.ndim == 1 else round_bf16(p) for p in parts]      # weights, not biases
         parts.append(w["dec.conv_post.weight"])
         self.gen_pack = np.concatenate([p.ravel() for p in parts])
         fparts = []
@@ -544,6 +551,8 @@ class VocoderOracle:
                            fold_weight_norm(w["%senc.res_skip_layers.%d.weight_g" % (p, l)], w["%senc.res_skip_layers.%d.weight_v" % (p, l)]),
                            w["%senc.res_skip_layers.%d.bias" % (p, l)]]
             fparts += [w[p + "post.weight"], w[p + "post.bias"]]
+        if numerics == "bf16":
+            fparts = [p if p.ndim == 1 else round_bf16(p) for p in fparts]
         self.flow_pack = np.concatenate([p.ravel() for p in fparts])
         assert self.flow_pack.size == 4 * lib().orc_flow_layer_floats(self.inter // 2, self.H, self.gin)
 
@@ -552,8 +561,12 @@ class VocoderOracle:
         x = _f32(z_p).copy()
         m = _f32(y_mask).ravel()
         g = _f32(ge).reshape(self.gin, -1)
-        lib().orc_flow_reverse(_fp(self.flow_pack), 4, self.inter // 2, self.H, self.gin, _fp(x), x.shape[1],
-                               _fp(m), _fp(g), g.shape[1])
+        lib().orc_set_rounding(R_VOC if self.numerics == "bf16" else 0)
+        try:
+            lib().orc_flow_reverse(_fp(self.flow_pack), 4, self.inter // 2, self.H, self.gin, _fp(x), x.shape[1],
+                                   _fp(m), _fp(g), g.shape[1])
+        finally:
+            lib().orc_set_rounding(0)
         return x
 
     def dec(self, z, ge):
@@ -561,10 +574,14 @@ class VocoderOracle:
         g = _f32(ge).reshape(self.gin, -1)
         T = z.shape[1]
         out = np.zeros(T * self.samples_per_frame, np.float32)
-        lib().orc_generator(_fp(self.gen_pack), self.inter, self.C0, self.gin, len(self.up_rates),
-                            self.up_rates.ctypes.data_as(c_i), self.up_kernels.ctypes.data_as(c_i),
-                            len(self.rk), self.rk.ctypes.data_as(c_i), self.rdil.ctypes.data_as(c_i),
-                            _fp(z), T, _fp(g), g.shape[1], _fp(out))
+        lib().orc_set_rounding(R_VOC if self.numerics == "bf16" else 0)
+        try:
+            lib().orc_generator(_fp(self.gen_pack), self.inter, self.C0, self.gin, len(self.up_rates),
+                                self.up_rates.ctypes.data_as(c_i), self.up_kernels.ctypes.data_as(c_i),
+                                len(self.rk), self.rk.ctypes.data_as(c_i), self.rdil.ctypes.data_as(c_i),
+                                _fp(z), T, _fp(g), g.shape[1], _fp(out))
+        finally:
+            lib().orc_set_rounding(0)
         return out
 
     def flow_dec(self, z_p, y_mask, ge):

@@ -169,7 +169,7 @@ def test_continuous_batching_40_requests_32_slots(dev, dtype, numerics):
     assert exact >= 30, exact
 
 
-@pytest.mark.parametrize("B,n_layer", [(16, 1), (64, 1), (64, 24)])
+@pytest.mark.parametrize("B,n_layer", [(40, 1), (64, 1), (64, 24)])
 def test_batched_step_hidden_vs_oracle_bf16_and_fp8(dev, B, n_layer):
     """one decode step of the batched chain (5 launches per layer) on B sequences with ragged cache lengths: final
     hidden states against the oracle in the matching numerics mode.  ONE layer is the arithmetic check (fragment

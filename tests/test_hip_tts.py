@@ -253,3 +253,50 @@ def test_tts_vc_async_and_cache_management(dev):
     tts.del_spk_audio("spk.wav", "missing.wav")
     tts.del_prompt_audio("prompt.wav")
     assert tts.get_spk_audio_list() == [] and tts.get_prompt_audio_list() == []
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vocoder_graph_bucket_equals_eager(dev, dtype):
+    """a pass whose length equals a sovits_cache bucket replays a hipGraph of the whole flow + Generator
+    (gsv_voc_flow_dec_graph, the reference's per-bucket graphs, SoVITS/models.py:322-369): same kernels, same buffers
+    layout -> bit-identical to the eager pass, also on the second replay with new contents"""
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps("v2Pro")
+    w = synth.sovits_weights(hps, seed=3, hot_path_only=True)
+    v = _VocoderNative(hps["model"], {k: torch.from_numpy(a) for k, a in w.items()}, dtype, dev)
+    ge = _T(synth.synth_ge(1, 1024, 3), dev)
+    for rep in range(3):
+        z = _T(synth.hashed_uniform("gb.z%d" % rep, (1, 192, 50), 3) * np.float32(1.3), dev)
+        mask = torch.ones(1, 1, 50, device=dev)
+        eager = v.flow_dec(z, mask, ge)
+        graph = v.flow_dec_bucket(z, mask, ge)
+        assert torch.equal(eager, graph), rep
+    assert len(v._buckets) == 1
+
+
+def test_decode_speed_on_device_matches_torch_encoder(dev):
+    """speed != 1 (TextEncoder.infer resamples the features linearly before proj, SoVITS/models.py:217-219): the device
+    path resamples the projected statistics (gsv_voc_resample_linear) and must agree with the torch restatement of
+    the reference order; also the resampling kernel itself against F.interpolate"""
+    import torch.nn.functional as F
+    from gsv_tts_lite_amd.sovits import SynthesizerTrn
+    hps = synth.sovits_hps("v2Pro")
+    vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    vq.load_state_dict(synth.sovits_weights(hps, seed=11))
+    vq.initialize_runtime(torch.bfloat16, dev, [50, 55])
+    x = torch.randn(1, 7, 83, device=dev)
+    for T_out in (64, 83, 120, 167):
+        got = vq._voc.resample_linear(x, T_out)
+        want = F.interpolate(x, size=T_out, mode="linear")
+        assert torch.allclose(got, want, atol=1e-6), T_out
+    codes = torch.randint(0, 1024, (1, 1, 40), device=dev)
+    text = torch.randint(1, 700, (1, 30), device=dev)
+    ge = _T(synth.synth_ge(0, 1024, 11), dev)
+    for speed in (1.25, 0.8):
+        vq.native_enc_p = True
+        o1, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=speed)
+        vq.native_enc_p = False
+        o2, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=speed)
+        assert o1.shape == o2.shape == (1, 1, (int(80 / speed) + 1) * 640)
+        err = (o1 - o2).abs()
+        assert err.max() < 0.15 and err.mean() < 0.02, (speed, float(err.max()), float(err.mean()))   # bf16 enc_p vs fp32 torch enc_p

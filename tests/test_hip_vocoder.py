@@ -149,3 +149,38 @@ def test_generator_bf16_wconv_odd_lengths_vs_oracle(dev, ver):
         assert out.shape == ref.shape and np.isfinite(out).all()
         err = np.abs(out - ref)
         assert err.max() < 8e-2 and err.mean() < 8e-3, (T, err.max(), err.mean())
+
+
+def test_bench_shape_bf16_flow_and_generator_vs_bf16_oracle(dev):
+    """The kernels bench.py times (v2Pro, bf16, T = 500 frames = 10 s of audio) against the oracle in ITS bf16 mode:
+    bf16 weights and every stored activation rounded where the HIP path stores bf16 (oracle/gsv_oracle.c ORC_R_VOC),
+    so only fp32 summation order -- and the one-ulp operand flips it causes, which ~100 conv layers then spread --
+    separates the two.  Measured on MI355X: flow max 1.6e-2 / mean 2.0e-3 (vs the fp32 oracle 2.2e-2 / 3.0e-3);
+    Generator max 2.5e-2 / mean 3.2e-3 on a waveform of rms 0.5 -- and NOT closer to the rounding-matched oracle than to
+    the fp32 one (2.6e-2 / 3.2e-3): after a hundred layers the flips have decorrelated the two bf16 computations as far
+    as bf16 is from fp32.  So what this test pins is the bench-size run itself (T = 500; the older bf16 check stopped at
+    T = 131 with max < 8e-2), with bounds = measured distance + headroom."""
+    from oracle import oracle as orc
+    T = 500
+    v, hps, w = _voc("v2Pro", 1234, torch.bfloat16, dev)
+    o16 = orc.VocoderOracle(hps, w, numerics="bf16")
+    o32 = orc.VocoderOracle(hps, w)
+    z = synth.hashed_uniform("bench.z", (1, 192, T), 1234) * np.float32(1.2)
+    ge = synth.synth_ge(0, 1024, 1234)
+    mask = np.ones(T, np.float32)
+    zf = v.flow(_T(z, dev), torch.ones(1, 1, T, device=dev), _T(ge, dev))[0].cpu().numpy()
+    f16, f32 = o16.flow(z[0], mask, ge[0]), o32.flow(z[0], mask, ge[0])
+    e16, e32 = np.abs(zf - f16), np.abs(zf - f32)
+    print("flow T=500 bf16: vs bf16 oracle max %.2e mean %.2e | vs fp32 oracle max %.2e mean %.2e" % (e16.max(), e16.mean(), e32.max(), e32.mean()))
+    assert e16.max() < 3e-2 and e16.mean() < 4e-3, (e16.max(), e16.mean())
+    # Generator alone on the oracle's own flow output (identical inputs), then the whole pass
+    out = v.dec(_T(f16[None], dev), _T(ge, dev))[0, 0].cpu().numpy()
+    d16, d32 = o16.dec(f16, ge[0]), o32.dec(f16, ge[0])
+    e16, e32 = np.abs(out - d16), np.abs(out - d32)
+    print("Generator T=500 bf16: vs bf16 oracle max %.2e mean %.2e | vs fp32 oracle max %.2e mean %.2e" % (e16.max(), e16.mean(), e32.max(), e32.mean()))
+    assert out.shape == (T * 640,) and np.isfinite(out).all()
+    assert e16.max() < 5e-2 and e16.mean() < 5e-3, (e16.max(), e16.mean())
+    full = v.flow_dec(_T(z, dev), torch.ones(1, 1, T, device=dev), _T(ge, dev))[0, 0].cpu().numpy()
+    ef = np.abs(full - o16.flow_dec(z[0], mask, ge[0]))
+    print("flow_dec T=500 bf16 vs bf16 oracle: max %.2e mean %.2e" % (ef.max(), ef.mean()))
+    assert ef.max() < 8e-2 and ef.mean() < 8e-3, (ef.max(), ef.mean())
