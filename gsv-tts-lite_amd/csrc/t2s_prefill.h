@@ -300,8 +300,9 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
 // K = 2048 GEMM: 19 us).  Here nothing is staged: a block owns one 32x32 output tile of one K split, each
 // of its 4 waves takes 8 k-steps (128 channels) and has ALL of its operands in flight at once -- weight
 // fragments (packed as for tapgemm) and the X rows straight from global in B-fragment layout -- so a
-// block costs one memory latency, 8 MFMAs, an LDS reduction and a store.  Splits write raw partial
-// tiles; bias / residual / LayerNorm happen in ln_rows_sum_kernel, which reads them back.
+// block costs one memory latency, 8 MFMAs, an LDS reduction and a store.  Splits write raw partial tiles.
+// (The GPT prompt pass and batched step moved to bgemm_kernel, t2s_batch.h; this kernel serves the SoVITS side:
+// conditioning GEMVs and enc_p's dense layers, gsv_voc.hip.)
 struct RowGemmArgs {
     const void* X;        // [M][ldx], float or bf16
     int ldx, M;
@@ -400,46 +401,6 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(yp + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-    }
-}
-
-// y[row] = LayerNorm(sum_s P[s][row] + bias + res[row]) over 512 (post-LN block, t2s_model.py:55-63): the
-// consumer of rowgemm's raw (split) tiles; partials are added in split order, then bias, then the residual
-static __global__ __launch_bounds__(256) void ln_rows_sum_kernel(const float* __restrict__ P, int nsplit, size_t split_stride,
-                                                          const float* __restrict__ bias, const float* res,
-                                                          const float* __restrict__ g, const float* __restrict__ bta,
-                                                          float* y, int rows, bf16_t* yb = nullptr) {   // y may alias res (row-wise in place)
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    float v[8], t[8];
-    Ld<float, 8>::load(P + (size_t)row * kD + lane * 8, v);
-    for (int s = 1; s < nsplit; ++s) {
-        Ld<float, 8>::load(P + (size_t)s * split_stride + (size_t)row * kD + lane * 8, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += t[i];
-    }
-    Ld<float, 8>::load(bias + lane * 8, t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += t[i];
-    Ld<float, 8>::load(res + (size_t)row * kD + lane * 8, t);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += t[i];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.0f / kD);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { v[i] -= mean; q += v[i] * v[i]; }
-    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / kD) + kEps);
-    float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = v[i] * rs * g[lane * 8 + i] + bta[lane * 8 + i];
-    *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8) = f32x4{o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<f32x4*>(y + (size_t)row * kD + lane * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
-    if (yb) {   // the next GEMM's operand type: same values it would round on load, half the bytes
-        u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-        *reinterpret_cast<u32x4*>(yb + (size_t)row * kD + lane * 8) = pk;
     }
 }
 

@@ -480,3 +480,48 @@ def test_prefill_into_scattered_slots_equals_one_by_one(dev, dtype):
     assert a["kv_len"].tolist() == b["kv_len"].tolist() and a["kv_len"][5] == 6 + 11 + 14 and a["kv_len"][1] == 0
     for key in a:
         assert torch.equal(a[key], b[key]), key
+
+
+def test_bf16_long_prompt_uses_the_mfma_attention_limit(dev):
+    """the bf16 prompt pass is gated by ITS kernel's LDS footprint (prompts up to 1056 positions), not by
+    the fp32 parity kernel's (591): a 900-position prompt -- inside the reference's default 1024 bucket -- must run
+    in bf16 and still be refused, with a message naming the mode, in fp32."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=2)
+    w = synth.gpt_weights(cfg, seed=21, eos_gain=0.0)
+    x, y, bert, _ = synth.synth_request(9, 300, 400, 200, seed=21)      # 700 phonemes + 200 prompt tokens = 900 positions
+    cache = [(1, 1024)]
+    m = _model(cfg, w, cache, torch.bfloat16, dev)
+    tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1, max_new_tokens=12)[0, 0].cpu().numpy()
+    assert len(tok) == 12
+    o = orc.T2SOracle(cfg, w, [(1, 912)], numerics="bf16")
+    ref = o.infer(x, y, bert, top_k=1)
+    first = next((i for i in range(12) if tok[i] != ref[i]), None)
+    assert first is None or o.margins[first + 1] < 2e-2, (first, tok, ref[:12])
+    m32 = _model(cfg, w, cache, torch.float32, dev)
+    with pytest.raises(RuntimeError, match="fp32 mode"):
+        m32.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1, max_new_tokens=2)
+
+
+def test_first_sample_is_suppressed_even_without_suppression_steps(dev):
+    """infer() / infer_stream() never let the PREFILL's sample be 280 / 486 / EOS (t2s_model.py:415-416),
+    whatever initial_suppression_steps is; the loop's samples are only suppressed while idx < that (:444-445).  A
+    predict layer whose row 280 dominates makes the difference observable; the oracle restates the reference."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=2)
+    w = synth.gpt_weights(cfg, seed=33, eos_gain=0.0)
+    pw = np.array(w["ar_predict_layer.weight"], copy=True)
+    pw[280] = pw[280] * 0 + 0.05 * np.sign(np.random.default_rng(0).normal(size=512)).astype(np.float32)
+    w["ar_predict_layer.weight"] = pw
+    x, y, bert, _ = synth.synth_request(2, 6, 9, 11, seed=33)
+    cache = [(1, 64)]
+    m = _model(cfg, w, cache, torch.float32, dev)
+    o = orc.T2SOracle(cfg, w, cache)
+    for steps in (0, 10):
+        ref = o.infer(x, y, bert, top_k=1, initial_suppression_steps=steps)
+        tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1, initial_suppression_steps=steps)[0, 0].cpu().numpy()
+        assert np.array_equal(tok, ref), (steps, tok[:8], ref[:8])
+    # the prefill sample itself (kept at kv position Lp): never a suppressed id, also with steps = 0
+    m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1, initial_suppression_steps=0, max_new_tokens=2)
+    s0 = int(m._rt[1]["pre_tokens"][0, len(x) + len(y)].item())
+    assert s0 not in (280, 486, 1024)

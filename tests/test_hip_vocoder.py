@@ -10,7 +10,7 @@ import torch
 from gsv_tts_lite_amd import synth
 
 pytestmark = pytest.mark.gpu
-CASES = [("v2Pro", 50, "c"), ("v2Pro", 55, "pf"), ("v2ProPlus", 50, "c"), ("v2", 23, "c")]
+CASES = [("v2Pro", 50, "c"), ("v2Pro", 55, "pf"), ("v2ProPlus", 50, "c"), ("v2", 23, "c"), ("v2Pro", 200, "c"), ("v2ProPlus", 55, "pf")]
 
 
 @pytest.fixture(scope="module")
@@ -40,11 +40,14 @@ def test_flow_dec_fp32_matches_reference_golden(golden_dir, dev, ver, T, tag):
     zf = v.flow(z, mask, ge)
     np.testing.assert_allclose(zf.cpu().numpy(), g[name + "_flow"], atol=1e-4)
     od = v.dec(_T(g[name + "_flow"], dev), ge)
-    np.testing.assert_allclose(od.cpu().numpy()[0, 0], g[name + "_o"], atol=1e-4)
+    sub = name + "_o" not in g            # long cases store every 5th sample
+    want = g[name + "_o_sub"] if sub else g[name + "_o"]
+    pick = (lambda a: a[::5]) if sub else (lambda a: a)
+    np.testing.assert_allclose(pick(od.cpu().numpy()[0, 0]), want, atol=1e-4)
     o = v.flow_dec(z, mask, ge)
     assert o.shape == (1, 1, T * 640)
-    np.testing.assert_allclose(o.cpu().numpy()[0, 0], g[name + "_o"], atol=1e-3)   # north_star bound
-    assert np.abs(o.cpu().numpy()[0, 0] - g[name + "_o"]).max() < 1e-4             # what we actually hold
+    np.testing.assert_allclose(pick(o.cpu().numpy()[0, 0]), want, atol=1e-3)       # north_star bound
+    assert np.abs(pick(o.cpu().numpy()[0, 0]) - want).max() < 1e-4                 # what we actually hold
 
 
 def test_flow_dec_fp32_vs_oracle_odd_lengths_and_mask(dev):

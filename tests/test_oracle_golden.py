@@ -104,7 +104,8 @@ def test_greedy_infer_batched_matches_reference(golden_dir, name):
 
 def test_vocoder_flow_and_generator_match_reference(golden_dir):
     g = _load(golden_dir, "vocoder.npz")
-    for ver, T, tag in [("v2Pro", 50, "c"), ("v2Pro", 55, "pf"), ("v2ProPlus", 50, "c"), ("v2", 23, "c")]:
+    for ver, T, tag in [("v2Pro", 50, "c"), ("v2Pro", 55, "pf"), ("v2ProPlus", 50, "c"), ("v2", 23, "c"),
+                        ("v2Pro", 200, "c"), ("v2ProPlus", 55, "pf")]:
         hps = synth.sovits_hps(ver)
         v = orc.VocoderOracle(hps, synth.sovits_weights(hps, seed=int(g["seed"])))
         name = "%s_T%d_%s" % (ver, T, tag)
@@ -114,7 +115,11 @@ def test_vocoder_flow_and_generator_match_reference(golden_dir):
         np.testing.assert_allclose(zf, g[name + "_flow"][0], atol=ATOL)
         o = v.flow_dec(z, mask, ge)
         assert o.shape == (T * 640,)
-        np.testing.assert_allclose(o, g[name + "_o"], atol=5e-5)
+        if name + "_o" in g:
+            np.testing.assert_allclose(o, g[name + "_o"], atol=5e-5)
+        else:   # long cases store every 5th sample and the fp64 sum
+            np.testing.assert_allclose(o[::5], g[name + "_o_sub"], atol=5e-5)
+            assert abs(float(o.astype(np.float64).sum()) - float(g[name + "_o_sum"])) < 0.5
 
 
 def test_synth_generator_is_stable():
