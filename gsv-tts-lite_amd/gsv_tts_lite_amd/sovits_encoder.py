@@ -15,6 +15,11 @@ the reference:
 The relative-position terms are computed directly on the 2w+1 band (gather / scatter on the
 offset j - i) instead of the reference's pad-and-reshape skewing; the result is the same
 attention (embeddings outside the window are zero in both formulations).
+
+`round_fn` (tests only; default: identity = the fp32 arithmetic of the reference): applied to the conv / linear
+weights and to every tensor the bf16 device path (csrc/encp.h, gsv_voc.hip encp_run) stores as bf16 -- gathered
+embeddings, conv outputs, attention probabilities and outputs, LayerNorm outputs, the FFN hidden -- so that
+tests/test_hip_encp.py can hold the device enc_p to a rounding-matched mirror instead of the fp32 one.
 """
 from __future__ import annotations
 
@@ -26,6 +31,10 @@ import torch.nn.functional as F
 
 def _dev(weights, name, device):
     return weights[name].detach().to(device=device, dtype=torch.float32)
+
+
+def _ident(x):
+    return x
 
 
 def codebook_decode(weights, codes):
@@ -46,12 +55,13 @@ def channel_layer_norm(x, gamma, beta, eps=1e-5):
 class _Attention:
     """multi-head attention over channels-first tensors; optional windowed relative positions"""
 
-    def __init__(self, w, prefix, device, n_heads, window=None):
+    def __init__(self, w, prefix, device, n_heads, window=None, rnd=_ident):
         g = lambda n: _dev(w, prefix + n, device)
-        self.wq, self.bq = g("conv_q.weight"), g("conv_q.bias")
-        self.wk, self.bk = g("conv_k.weight"), g("conv_k.bias")
-        self.wv, self.bv = g("conv_v.weight"), g("conv_v.bias")
-        self.wo, self.bo = g("conv_o.weight"), g("conv_o.bias")
+        self.rnd = rnd
+        self.wq, self.bq = rnd(g("conv_q.weight")), g("conv_q.bias")
+        self.wk, self.bk = rnd(g("conv_k.weight")), g("conv_k.bias")
+        self.wv, self.bv = rnd(g("conv_v.weight")), g("conv_v.bias")
+        self.wo, self.bo = rnd(g("conv_o.weight")), g("conv_o.bias")
         self.n_heads = n_heads
         self.window = window
         if window is not None:
@@ -59,9 +69,10 @@ class _Attention:
         self.attn = None
 
     def __call__(self, x, c, mask):
-        q = F.conv1d(x, self.wq, self.bq)
-        k = F.conv1d(c, self.wk, self.bk)
-        v = F.conv1d(c, self.wv, self.bv)
+        rnd = self.rnd
+        q = rnd(F.conv1d(x, self.wq, self.bq))
+        k = rnd(F.conv1d(c, self.wk, self.bk))
+        v = rnd(F.conv1d(c, self.wv, self.bv))
         b, d, tt = q.shape
         ts = k.shape[2]
         h, dk = self.n_heads, d // self.n_heads
@@ -80,27 +91,28 @@ class _Attention:
         if mask is not None:
             scores = scores.masked_fill(mask == 0, -1e4)
         p = torch.softmax(scores, dim=-1)
-        out = p @ v
+        out = rnd(p) @ v
         if self.window is not None:
             rel_w = torch.zeros(b, h, tt, 2 * w + 1, device=x.device, dtype=p.dtype)
             rel_w.scatter_add_(-1, bin_, p * band)
             out = out + rel_w @ self.rel_v
         self.attn = p
-        out = out.transpose(2, 3).contiguous().view(b, d, tt)
+        out = rnd(out.transpose(2, 3).contiguous().view(b, d, tt))
         return F.conv1d(out, self.wo, self.bo)
 
 
 class _Encoder:
-    def __init__(self, w, prefix, device, n_heads, n_layers, kernel_size, window=4):
+    def __init__(self, w, prefix, device, n_heads, n_layers, kernel_size, window=4, rnd=_ident):
         self.layers = []
+        self.rnd = rnd
         for i in range(n_layers):
             g = lambda n: _dev(w, prefix + n, device)
             self.layers.append(dict(
-                attn=_Attention(w, "%sattn_layers.%d." % (prefix, i), device, n_heads, window),
+                attn=_Attention(w, "%sattn_layers.%d." % (prefix, i), device, n_heads, window, rnd),
                 n1=(g("norm_layers_1.%d.gamma" % i), g("norm_layers_1.%d.beta" % i)),
                 n2=(g("norm_layers_2.%d.gamma" % i), g("norm_layers_2.%d.beta" % i)),
-                c1=(g("ffn_layers.%d.conv_1.weight" % i), g("ffn_layers.%d.conv_1.bias" % i)),
-                c2=(g("ffn_layers.%d.conv_2.weight" % i), g("ffn_layers.%d.conv_2.bias" % i)),
+                c1=(rnd(g("ffn_layers.%d.conv_1.weight" % i)), g("ffn_layers.%d.conv_1.bias" % i)),
+                c2=(rnd(g("ffn_layers.%d.conv_2.weight" % i)), g("ffn_layers.%d.conv_2.bias" % i)),
             ))
         self.k = kernel_size
 
@@ -108,23 +120,25 @@ class _Encoder:
         attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
         x = x * x_mask
         pl, pr = (self.k - 1) // 2, self.k // 2
+        rnd = self.rnd
         for L in self.layers:
             y = L["attn"](x, x, attn_mask)
-            x = channel_layer_norm(x + y, *L["n1"])
+            x = rnd(channel_layer_norm(x + y, *L["n1"]))
             y = F.conv1d(F.pad(x * x_mask, (pl, pr)), *L["c1"])
-            y = torch.relu(y)
+            y = rnd(torch.relu(y))
             y = F.conv1d(F.pad(y * x_mask, (pl, pr)), *L["c2"]) * x_mask
-            x = channel_layer_norm(x + y, *L["n2"])
+            x = rnd(channel_layer_norm(x + y, *L["n2"]))
         return x * x_mask
 
 
 class _MRTE:
-    def __init__(self, w, device):
+    def __init__(self, w, device, rnd=_ident):
         g = lambda n: _dev(w, "enc_p.mrte." + n, device)
-        self.cross_attention = _Attention(w, "enc_p.mrte.cross_attention.", device, 4, None)
-        self.c_pre = (g("c_pre.weight"), g("c_pre.bias"))
-        self.text_pre = (g("text_pre.weight"), g("text_pre.bias"))
-        self.c_post = (g("c_post.weight"), g("c_post.bias"))
+        self.rnd = rnd
+        self.cross_attention = _Attention(w, "enc_p.mrte.cross_attention.", device, 4, None, rnd)
+        self.c_pre = (rnd(g("c_pre.weight")), g("c_pre.bias"))
+        self.text_pre = (rnd(g("text_pre.weight")), g("text_pre.bias"))
+        self.c_post = (rnd(g("c_post.weight")), g("c_post.bias"))
 
     def __call__(self, ssl_enc, ssl_mask, text, text_mask, ge, slice_indices=None):
         if ge is None:
@@ -136,26 +150,28 @@ class _MRTE:
             attn_mask = (rng >= slice_indices[:, 0:1]) & (rng < slice_indices[:, 1:2])
             attn_mask[:, -1] = True
             attn_mask = attn_mask.unsqueeze(0).unsqueeze(0)
-        ssl_enc = F.conv1d(ssl_enc * ssl_mask, *self.c_pre)
-        text_enc = F.conv1d(text * text_mask, *self.text_pre)
-        x = self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, attn_mask) + ssl_enc + ge
-        return F.conv1d(x * ssl_mask, *self.c_post)
+        rnd = self.rnd
+        ssl_enc = rnd(F.conv1d(ssl_enc * ssl_mask, *self.c_pre))
+        text_enc = rnd(F.conv1d(text * text_mask, *self.text_pre))
+        x = rnd(rnd(self.cross_attention(ssl_enc * ssl_mask, text_enc * text_mask, attn_mask)) + ssl_enc + ge)
+        return rnd(F.conv1d(x * ssl_mask, *self.c_post))
 
 
 class TextEncoder:
-    def __init__(self, hps_model, weights, device):
+    def __init__(self, hps_model, weights, device, round_fn=None):
         m = hps_model
         self.device = device
+        rnd = self.rnd = round_fn if round_fn is not None else _ident
         g = lambda n: _dev(weights, "enc_p." + n, device)
         self.out_channels = m["inter_channels"]
-        self.ssl_proj = (g("ssl_proj.weight"), g("ssl_proj.bias"))
+        self.ssl_proj = (rnd(g("ssl_proj.weight")), g("ssl_proj.bias"))
         nh, nl, k = m["n_heads"], m["n_layers"], m["kernel_size"]
-        self.encoder_ssl = _Encoder(weights, "enc_p.encoder_ssl.", device, nh, nl // 2, k)
-        self.encoder_text = _Encoder(weights, "enc_p.encoder_text.", device, nh, nl, k)
+        self.encoder_ssl = _Encoder(weights, "enc_p.encoder_ssl.", device, nh, nl // 2, k, rnd=rnd)
+        self.encoder_text = _Encoder(weights, "enc_p.encoder_text.", device, nh, nl, k, rnd=rnd)
         self.text_embedding = g("text_embedding.weight")
-        self.mrte = _MRTE(weights, device)
-        self.encoder2 = _Encoder(weights, "enc_p.encoder2.", device, nh, nl // 2, k)
-        self.proj = (g("proj.weight"), g("proj.bias"))
+        self.mrte = _MRTE(weights, device, rnd)
+        self.encoder2 = _Encoder(weights, "enc_p.encoder2.", device, nh, nl // 2, k, rnd=rnd)
+        self.proj = (rnd(g("proj.weight")), g("proj.bias"))
         self.y_overlap = None
         if m["version"] in ("v2Pro", "v2ProPlus"):
             self._ge512 = (_dev(weights, "ge_to512.weight", device), _dev(weights, "ge_to512.bias", device))
@@ -165,12 +181,13 @@ class TextEncoder:
         return F.linear(ge.transpose(2, 1), *self._ge512).transpose(2, 1)
 
     def infer(self, y, text, ge, speed, stream_mode=False, valid_start_idx=None, overlap_len=None, slice_indices=None):
-        y = y.to(torch.float32)
+        rnd = self.rnd
+        y = rnd(y.to(torch.float32))
         y_mask = torch.ones((1, 1, y.size(2)), dtype=y.dtype, device=y.device)
-        y = F.conv1d(y * y_mask, *self.ssl_proj) * y_mask
+        y = rnd(F.conv1d(y * y_mask, *self.ssl_proj) * y_mask)
         y = self.encoder_ssl(y * y_mask, y_mask)
         text_mask = torch.ones((1, 1, text.size(1)), dtype=y.dtype, device=y.device)
-        t = F.embedding(text, self.text_embedding).transpose(1, 2)
+        t = rnd(F.embedding(text, self.text_embedding).transpose(1, 2))
         t = self.encoder_text(t * text_mask, text_mask)
         y = self.mrte(y, y_mask, t, text_mask, ge, slice_indices)
         y = self.encoder2(y * y_mask, y_mask)
