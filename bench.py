@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--version", default="v2Pro", choices=["v2", "v2Pro", "v2ProPlus"])
     ap.add_argument("--slots", type=int, default=CB_SLOTS, help="cb: slots per GPU")
     ap.add_argument("--requests", type=int, default=CB_REQUESTS_PER_GPU, help="cb: requests per GPU per step")
+    ap.add_argument("--sync-refill", action="store_true", help="cb: refill finished slots as the reference does, every slot waiting for "
+                    "the prompt pass (default: the prompt pass runs on a side stream and the slot joins when it is done)")
     ap.add_argument("--overlap", action="store_true", help="cb: vocoder batches on a side stream while the slot loop decodes (measured "
                     "+1 .. +4 %% end to end: the two share the chip) instead of after it in TTS.infer_batched's length-balanced order")
     ap.add_argument("--no-graph", action="store_true")
@@ -526,11 +528,11 @@ def run_cb(a):
     def step(i, timed_idx):
         torch.cuda.synchronize(dev); s0 = time.perf_counter()
         if (not a.overlap):
-            pred, idx = eng.run_gpt(xs, ys, bs, top_k=1, max_new_tokens=new_tok)
+            pred, idx = eng.run_gpt(xs, ys, bs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             torch.cuda.synchronize(dev); s1 = time.perf_counter()
             frames = vocode(list(zip(idx.tolist(), pred)))
         else:
-            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, top_k=1, max_new_tokens=new_tok)
+            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             s1 = time.perf_counter()
             frames = int(sum(res.values()))
         torch.cuda.synchronize(dev); s2 = time.perf_counter()
@@ -558,6 +560,8 @@ def run_cb(a):
                                "(greedy, 50..400 new tokens per request), flow/Generator over every utterance in time-concatenated batches of 10"
                                % (which, a.version, a.requests, a.slots),
                    "requests_per_step": n_req, "gpt_cache": [(a.slots, 512), (a.slots, 1024)],
+                   "refill": "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)" if a.sync_refill else
+                             "staged: the prompt pass of a finished slot runs on a side stream, the slot joins at the next window after it",
                    "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
                               "overlapped with the slot loop on a side stream, batches of 10 in completion order",
                    "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "

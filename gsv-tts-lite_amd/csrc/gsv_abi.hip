@@ -36,7 +36,20 @@ struct T2SLayer {
 struct T2SBound {
     gsv_t2s_state st;
     hipGraphExec_t graph = nullptr;       // the captured decode step
+    // staging of a refill that runs on ANOTHER stream while the decode step keeps replaying on the caller's
+    // (gsv_t2s_prefill_slots_staged / gsv_t2s_commit_slots): per-slot state the step also writes must not be
+    // touched by the prompt pass; it lands here and the commit, ordered on the step's stream, moves it over
+    int64_t *sg_kv = nullptr, *sg_x = nullptr;
+    int32_t *sg_step = nullptr, *sg_eos = nullptr;
+    float *sg_logits = nullptr, *sg_hidden = nullptr;
+    TokPart* sg_tok = nullptr;
 };
+
+void t2s_free_staging(T2SBound& b) {
+    for (void* p : {(void*)b.sg_kv, (void*)b.sg_x, (void*)b.sg_step, (void*)b.sg_eos, (void*)b.sg_logits, (void*)b.sg_hidden, (void*)b.sg_tok})
+        if (p) (void)hipFree(p);
+    b.sg_kv = b.sg_x = nullptr; b.sg_step = b.sg_eos = nullptr; b.sg_logits = b.sg_hidden = nullptr; b.sg_tok = nullptr;
+}
 
 struct gsv_t2s {
     gsv_t2s_config cfg;
@@ -267,13 +280,14 @@ int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_
 
 template <typename WT>
 int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirect, int slot0, int nrows, int vlimit,
-               int bump, hipStream_t st, const int32_t* slots = nullptr) {
+               int bump, hipStream_t st, const int32_t* slots = nullptr, const T2SBound* staged = nullptr) {
     const T2SLayer& L = h->layers.back();
     LogitsArgs<WT> a;
     a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
     a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0; a.slots = slots;
     a.step = s.step; a.ctl = s.ctl; a.fctl = s.fctl; a.seen = s.seen; a.logits = s.logits; a.hidden = s.hidden;
     a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;
+    if (staged) { a.step = staged->sg_step; a.logits = staged->sg_logits; a.hidden = staged->sg_hidden; a.tokpart = staged->sg_tok; a.kv_len = staged->sg_kv; }
     if (mode == 0) hipLaunchKernelGGL((t2s_logits_kernel<WT, 0>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
     else hipLaunchKernelGGL((t2s_logits_kernel<WT, 1>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
     HIPCHK(hipGetLastError());
@@ -405,7 +419,7 @@ int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
 
 template <typename WT>
 int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, float* xy, const int64_t* x_lens,
-                     const int64_t* y_lens, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* slots = nullptr) {
+                     const int64_t* y_lens, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* slots = nullptr, bool staged = false) {
     const gsv_t2s_state& s = bd.st;
     const int M = nrows * l_max, T = s.max_kv;
     const size_t need = gsv_t2s_prefill_workspace(h, nrows, l_max);
@@ -478,10 +492,26 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     PrefillFinishArgs fa;
     fa.hidden = xy; fa.x_lens = x_lens; fa.y_lens = y_lens; fa.hlast = hlast; fa.kv_len = s.kv_len; fa.x_len = s.x_len;
     fa.step = s.step; fa.eos_at = s.eos_at; fa.slot0 = slot0; fa.slots = slots; fa.l_max = l_max;
+    if (staged) { fa.kv_len = bd.sg_kv; fa.x_len = bd.sg_x; fa.step = bd.sg_step; fa.eos_at = bd.sg_eos; }
     hipLaunchKernelGGL(t2s_prefill_finish_kernel, dim3(nrows), dim3(128), 0, st, fa);
     HIPCHK(hipGetLastError());
     // first sample: logits[:, :-1] (t2s_model.py:417,613) -> EOS column dropped
-    return t2s_logits<WT>(h, s, 0, hlast, slot0, nrows, h->cfg.vocab - 1, 0, st, slots);
+    return t2s_logits<WT>(h, s, 0, hlast, slot0, nrows, h->cfg.vocab - 1, 0, st, slots, staged ? &bd : nullptr);
+}
+
+// staging -> live state of the listed slots (gsv_t2s_commit_slots)
+struct CommitArgs {
+    const int32_t* slots;
+    const int64_t *sg_kv, *sg_x; const int32_t *sg_step, *sg_eos; const float *sg_logits, *sg_hidden; const TokPart* sg_tok;
+    int64_t *kv_len, *x_len; int32_t *step, *eos_at; float *logits, *hidden; TokPart* tokpart;
+    int V;
+};
+__global__ __launch_bounds__(256) void t2s_commit_kernel(CommitArgs a) {
+    const int s = a.slots[blockIdx.x], tid = threadIdx.x;
+    for (int v = tid; v < a.V; v += 256) a.logits[(size_t)s * a.V + v] = a.sg_logits[(size_t)s * a.V + v];
+    for (int c = tid; c < kD; c += 256) a.hidden[(size_t)s * kD + c] = a.sg_hidden[(size_t)s * kD + c];
+    if (tid < kNP) a.tokpart[(size_t)s * kNP + tid] = a.sg_tok[(size_t)s * kNP + tid];
+    if (tid == 0) { a.kv_len[s] = a.sg_kv[s]; a.x_len[s] = a.sg_x[s]; a.step[s] = a.sg_step[s]; a.eos_at[s] = a.sg_eos[s]; }
 }
 
 }  // namespace
@@ -560,6 +590,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
     (void)hipDeviceSynchronize();
     for (auto& kv : h->bound) {
         if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
+        t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
         for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
@@ -623,6 +654,13 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     T2SBound& b = h->bound[st->batch];
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
     b.st = *st;
+    t2s_free_staging(b);
+    const size_t B = (size_t)st->batch;
+    HIPCHK(hipMalloc(&b.sg_kv, 8 * B)); HIPCHK(hipMalloc(&b.sg_x, 8 * B));
+    HIPCHK(hipMalloc(&b.sg_step, 4 * B)); HIPCHK(hipMalloc(&b.sg_eos, 4 * B));
+    HIPCHK(hipMalloc(&b.sg_logits, sizeof(float) * B * h->cfg.vocab)); HIPCHK(hipMalloc(&b.sg_hidden, sizeof(float) * B * kD));
+    HIPCHK(hipMalloc(&b.sg_tok, sizeof(TokPart) * B * kNP));
+    HIPCHK(hipMemset(b.sg_step, 0, 4 * B));
     return GSV_OK;
 }
 
@@ -678,6 +716,32 @@ int gsv_t2s_prefill_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows
     return h->cfg.dtype == GSV_BF16
                ? t2s_prefill_impl<bf16_t>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots)
                : t2s_prefill_impl<float>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots);
+}
+
+int gsv_t2s_prefill_slots_staged(gsv_t2s* h, int batch, const int32_t* slots, int nrows, int l_max, float* xy, const int64_t* x_lens,
+                                 const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    if (!slots || nrows < 1 || nrows > batch) return fail(GSV_ERR_ARG, "prefill_slots_staged: need 1..batch rows and their slot list");
+    if (l_max < 1 || l_max > b->st.max_kv - 1) return fail(GSV_ERR_ARG, "prompt of %d positions does not fit beside the parking row of the KV cache (%d)", l_max, b->st.max_kv);
+    return h->cfg.dtype == GSV_BF16
+               ? t2s_prefill_impl<bf16_t>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots, true)
+               : t2s_prefill_impl<float>(h, *b, 0, nrows, l_max, xy, x_lens, y_lens, workspace, workspace_bytes, S(stream), slots, true);
+}
+
+int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    if (!slots || nrows < 1 || nrows > batch) return fail(GSV_ERR_ARG, "commit_slots: need 1..batch slots");
+    CommitArgs a;
+    a.slots = slots; a.sg_kv = b->sg_kv; a.sg_x = b->sg_x; a.sg_step = b->sg_step; a.sg_eos = b->sg_eos; a.sg_logits = b->sg_logits;
+    a.sg_hidden = b->sg_hidden; a.sg_tok = b->sg_tok; a.kv_len = b->st.kv_len; a.x_len = b->st.x_len; a.step = b->st.step; a.eos_at = b->st.eos_at;
+    a.logits = b->st.logits; a.hidden = b->st.hidden; a.tokpart = h->tokpart; a.V = h->cfg.vocab;
+    hipLaunchKernelGGL(t2s_commit_kernel, dim3(nrows), dim3(256), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
 }
 
 int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream) {

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void t2s_batch_attn_kernel(BatchAttnArgs<bf16_
         qs[tid] = rq;
         const bf16_t kq = f32_to_bf16(rk), vq = f32_to_bf16(rv);
         kn[tid] = bf16_to_f32(kq); vn[tid] = bf16_to_f32(vq);
-        Kp[(size_t)n * kDh + tid] = kq; Vp[(size_t)n * kDh + tid] = vq;
+        const int nw = n64 < 0 ? a.T - 1 : n;     // parked slot (kv_len < 0): away from the rows a staged refill writes
+        Kp[(size_t)nw * kDh + tid] = kq; Vp[(size_t)nw * kDh + tid] = vq;
     }
     __syncthreads();
     float q[8], knr[8], vnr[8];

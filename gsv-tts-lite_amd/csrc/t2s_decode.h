@@ -324,6 +324,9 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     stamp(a.dbg, 0);
 
     int n = (int)a.kv_len[b];
+    // kv_len < 0 = a PARKED slot (include/gsv_tts_hip.h, staged refill): its K/V row goes to the last row of the cache,
+    // which no prompt pass writes, and it attends over row 0 only -- it must not touch rows a concurrent refill fills
+    const int nw = n < 0 ? a.T - 1 : (n > a.T - 1 ? a.T - 1 : n);
     if (n > a.T - 1) n = a.T - 1;  // memory safety only; the host never steps a full cache
     if (n < 0) n = 0;
     WT* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
             if (row >= 32) {
                 const WT s = from_f32<WT>(val);
                 val = to_f32<WT>(s);
-                if (row < 64) Kp[(size_t)n * kDh + row - 32] = s; else Vp[(size_t)n * kDh + row - 64] = s;
+                if (row < 64) Kp[(size_t)nw * kDh + row - 32] = s; else Vp[(size_t)nw * kDh + row - 64] = s;
             }
             qkv[row] = val;
         }
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
         if (lane == 0) {
             TokPart tp; tp.v = bv; tp.idx = bi;
             a.tokpart[(size_t)b * kNP + p] = tp;
-            if (p == 0 && a.bump) a.kv_len[b] += 1;
+            if (p == 0 && a.bump) { const int64_t kn = a.kv_len[b]; if (kn >= 0) a.kv_len[b] = kn + 1; }   // parked slots stay parked
         }
     }
 }
@@ -854,7 +857,7 @@ static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
         s_tok = tok;
         const int64_t n = a.kv_len[b];
         if (n >= 0 && n <= a.T) a.pre_tokens[(size_t)b * (a.T + 1) + n] = tok;
-        if (a.ctl[2] != 0) a.seen[(size_t)b * a.V + tok] = 1;
+        if (a.ctl[2] != 0 && n >= 0) a.seen[(size_t)b * a.V + tok] = 1;   // a parked slot's `seen` belongs to its refill
         if (tok == a.eos && a.eos_at[b] < 0) a.eos_at[b] = a.step[b];
         if (a.advance) a.step[b] += 1;
     }

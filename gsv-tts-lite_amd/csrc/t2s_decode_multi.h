@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
     const bool owner = tid < kD;
     const int part = tid % LPR, rsub = tid / LPR;
 
-    int bs[R], n[R];
+    int bs[R], n[R], nw[R];
     WT* Kp[R];
     WT* Vp[R];
 #pragma unroll
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
         bs[r] = min(b0 + r, B - 1);
         int nn = (int)a.kv_len[bs[r]];
         n[r] = min(max(nn, 0), a.T - 1);
+        nw[r] = nn < 0 ? a.T - 1 : n[r];          // parked slot: see t2s_decode.h
         Kp[r] = a.kc + (((size_t)bs[r] * kH + h) * a.T) * kDh;
         Vp[r] = a.vc + (((size_t)bs[r] * kH + h) * a.T) * kDh;
     }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
                 const WT s = from_f32<WT>(val);
                 val = to_f32<WT>(s);
                 if (b0 + r < B) {
-                    if (row < 64) Kp[r][(size_t)n[r] * kDh + row - 32] = s; else Vp[r][(size_t)n[r] * kDh + row - 64] = s;
+                    if (row < 64) Kp[r][(size_t)nw[r] * kDh + row - 32] = s; else Vp[r][(size_t)nw[r] * kDh + row - 64] = s;
                 }
             }
             qkv[r * 96 + row] = val;

@@ -232,6 +232,18 @@ class Text2SemanticDecoder:
         N.check(L.gsv_t2s_prefill_slots(self._h, batch, sl.data_ptr(), n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
                                         ws.data_ptr(), ws.numel(), N.current_stream_ptr(self.device)))
 
+    def prefill_slots_staged(self, batch, sl, xy, xl, yl, stream_ptr):
+        """the packed refill on ANOTHER stream than the decode step's: K/V rows into the live cache, every per-slot state
+        the step also writes into the library's staging (gsv_t2s_prefill_slots_staged); `sl` int32 device slot list"""
+        n, lmax, _ = xy.shape
+        L = N.lib()
+        ws = self._workspace(L.gsv_t2s_prefill_workspace(self._h, n, lmax))
+        N.check(L.gsv_t2s_prefill_slots_staged(self._h, batch, sl.data_ptr(), n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), stream_ptr))
+
+    def commit_slots(self, batch, sl):
+        N.check(N.lib().gsv_t2s_commit_slots(self._h, batch, sl.data_ptr(), int(sl.numel()), N.current_stream_ptr(self.device)))
+
     def decode_hidden(self, batch, x):
         """T2STransformer.decode_next_token for an explicit x [B, D] (t2s_model.py:129-143)."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
@@ -408,10 +420,176 @@ class Text2SemanticDecoder:
         yield final[None, None], True
 
     @torch.inference_mode()
+    def _infer_batched_staged(self, x, y, bert_feature, B, first, nxt, exhausted, first_len, check_interval, on_finish,
+                              max_new_tokens):
+        """The slot loop of t2s_model.py:555-734 with nothing on the decode steps' critical path but the steps:
+
+          * a finished slot is PARKED (kv_len = -1: the step leaves its rows and state alone and attends over one row),
+            its prompt pass runs on a side stream into the live K/V rows and the library's staging, and it joins at the
+            first window boundary after the pass has completed (gsv_t2s_prefill_slots_staged / gsv_t2s_commit_slots);
+          * the host never waits for the window it has just issued: the per-window read-back (kv_len, eos_at) is an
+            asynchronous copy examined one window later, while the next window runs.  Ends the host can predict --
+            a token budget, a full cache -- park the slot with no lag; an EOS is seen one window (<= 5 garbage steps
+            of that slot) late.  Tokens are cut at the first EOS from the device's `eos_at`, so the lag never shows.
+
+        Which request a slot gets is decided when the slot is parked, rows are independent through every kernel, so every
+        request's tokens equal the reference-order loop's (tests/test_hip_t2s.py); completion ORDER and the window a
+        request joins at depend on timing.  A request that fills the cache is cut at the largest bucket's limit
+        (kv + check_interval >= max_kv at a window boundary), as in the reference's last bucket.
+        The prefill of `first` into slots 0.. has already run on the current stream."""
+        rt = self._rt[B]
+        dev = self.device
+        cap = max(b.max_kv_cache for b in self.cuda_graph_buckets[B])
+        if getattr(self, "_refill_stream", None) is None:
+            self._refill_stream = torch.cuda.Stream(device=dev)
+        side = self._refill_stream
+        main = torch.cuda.current_stream(dev)
+        LIVE, PARKED, IDLE = 0, 1, 2
+        actual = len(first)
+        state = [LIVE] * actual + [IDLE] * (B - actual)
+        req = list(first) + [-1] * (B - actual)
+        start = list(first_len) + [0] * (B - actual)       # kv_len the slot joined with (its prompt length)
+        steps = [0] * B                                     # steps issued since the slot joined
+        joined = [0] * B                                    # first window whose read-back shows the slot's current request
+        if actual < B:
+            rt["kv_len"][actual:] = -1
+        pred, orig = [], []
+        waiting: list = []      # (slot, request): parked, prompt pass not launched yet
+        inflight: list = []     # at most one staged prompt pass: (slots, device slot list, done event, keep-alive tensors)
+        to_cut: list = []       # (window, slot, request, first row, most tokens): parked, tokens not collected yet
+        snap_host = torch.empty((2, 2, B), dtype=torch.int64).pin_memory()
+        snaps: list = []        # (window, buffer, event)
+        self.last_stats = {"slots": B, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0}
+
+        def park(i):
+            """slot i has finished (or has nothing to do): park it, and give it the next request if there is one"""
+            nonlocal exhausted
+            rt["kv_len"][i] = -1
+            cur = None if exhausted else nxt()
+            if cur is None:
+                exhausted = True
+                state[i] = IDLE
+                return
+            n_new = int(x[cur].shape[0]) + int(y[cur].shape[0])
+            if n_new > cap - 1:
+                raise ValueError("prompt longer than the largest KV bucket")
+            state[i], req[i] = PARKED, cur
+            waiting.append((i, cur, n_new))
+
+        def collect(i, r, a0, n_keep):
+            seg = rt["pre_tokens"][i, a0: a0 + max(0, n_keep)].clone()
+            pred.append(seg)
+            orig.append(r)
+            if on_finish is not None:
+                on_finish(r, seg)
+
+        def launch_refill():
+            if inflight or not waiting:
+                return
+            group = waiting[:]
+            waiting.clear()
+            ev = torch.cuda.Event()
+            ev.record(main)         # the parking writes, and every step that still wrote these slots' rows
+            rq = [c for _, c, _ in group]
+            with torch.cuda.stream(side):
+                # the embedding and its host->device copies first: they depend on nothing the steps do, and a pageable
+                # copy blocks the host until its stream gets there -- it must not sit behind the wait on the steps
+                xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in rq], [y[c] for c in rq], [bert_feature[c] for c in rq])
+                sl = torch.tensor([i for i, _, _ in group], dtype=torch.int32, device=dev)
+                side.wait_event(ev)
+                self.prefill_slots_staged(B, sl, xy1, xl1, yl1, side.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(side)
+            inflight.append((group, sl, done, (xy1, xl1, yl1), window))
+            self.last_stats["refills"] += len(group)
+            self.last_stats["prefill_rows"] += len(group)
+
+        def join(window, block):
+            """a completed prompt pass joins: staging -> live state on the steps' stream"""
+            if not inflight:
+                return
+            group, sl, done, _keep, launched = inflight[0]
+            if block:
+                done.synchronize()
+            elif not done.query():
+                return
+            # the old occupants' tokens first: the pass started after the read-back of the window it was launched in, so
+            # those read-backs are on the host (no wait here), and the new request's steps will overwrite the rows
+            while snaps and snaps[0][0] <= launched:
+                examine(*snaps.pop(0))
+            assert not any(i == c[1] for c in to_cut for i, _, _ in group), "a slot joined before its tokens were collected"
+            main.wait_event(done)
+            self.commit_slots(B, sl)
+            sl.record_stream(main)      # allocated on the side stream's pool, read here by the steps' stream
+            for i, _, n_new in group:
+                state[i], steps[i], start[i], joined[i] = LIVE, 0, n_new, window
+            inflight.clear()
+
+        def examine(window, buf, ev):
+            """read-back of `window` (taken after its steps): collect what was parked at that boundary, find EOS ends"""
+            ev.synchronize()
+            kv_s, eos_s = snap_host[buf].tolist()
+            for rec in [c for c in to_cut if c[0] == window]:
+                _, i, r, a0, n_max = rec
+                e = eos_s[i]                               # index of the first EOS among the slot's samples, or -1
+                collect(i, r, a0, n_max if e < 1 else min(n_max, e - 1))
+                to_cut.remove(rec)
+            for i in range(B):
+                if state[i] == LIVE and joined[i] <= window and eos_s[i] >= 0:
+                    collect(i, req[i], start[i] + 1, eos_s[i] - 1)
+                    park(i)
+
+        window, idx = 0, 0
+        while True:
+            if not any(st == LIVE for st in state):
+                while snaps:                        # nothing is running that the read-backs could hide behind
+                    examine(*snaps.pop(0))
+            join(window, block=not any(st == LIVE for st in state))
+            if not any(st == LIVE for st in state):
+                if waiting and not inflight:        # nothing left to overlap the prompt pass with
+                    launch_refill()
+                    continue
+                if inflight:
+                    continue
+                break
+            n = 1 if idx == 0 else min(check_interval, 1000 - idx)     # the reference's cadence: tests after steps 1, 6, 11, ...
+            self._decode(B, n)
+            self._flush(B)
+            idx = 0 if idx + n >= 1000 else idx + n
+            buf = window & 1
+            snap_host[buf].copy_(torch.stack([rt["kv_len"], rt["eos_at"].to(torch.int64)]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.last_stats["steps"] += n
+            for i in range(B):
+                if state[i] == LIVE:
+                    steps[i] += n
+                    self.last_stats["kv_rows"] += (start[i] + steps[i]) * n
+            # ends the host can tell without the device: park now (no garbage window), cut the tokens when this window's read-back is in
+            for i in range(B):
+                if state[i] != LIVE:
+                    continue
+                budget = None if max_new_tokens is None else int(max_new_tokens[req[i]])
+                full = start[i] + steps[i] + check_interval >= cap
+                if full or (budget is not None and steps[i] - 1 >= budget):
+                    n_max = steps[i] - 1 if budget is None else min(steps[i] - 1, budget)
+                    to_cut.append((window, i, req[i], start[i] + 1, n_max))
+                    park(i)
+            snaps.append((window, buf, ev))
+            launch_refill()                          # host work of a prompt pass: behind the steps the GPU is busy with
+            while len(snaps) > 1:                    # the PREVIOUS window's read-back: on the host by now
+                examine(*snaps.pop(0))
+            window += 1
+        for sn in snaps:
+            examine(*sn)
+        assert not to_cut and not waiting and not inflight
+        return pred, torch.tensor(orig, device=dev)
+
+    @torch.inference_mode()
     def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
                       top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
                       repetition_penalty: float = 1.35, check_interval: int = 5, generator=None,
-                      source=None, slots: int = None, on_finish=None, max_new_tokens=None):
+                      source=None, slots: int = None, on_finish=None, max_new_tokens=None, async_refill: bool = False):
         """t2s_model.py:555-734: continuous batching over the slots of one batch-size family.
 
         `source` (engine.RequestSource) replaces "the next request is x[cur]" (:696-700) by "the next request is
@@ -420,7 +598,9 @@ class Text2SemanticDecoder:
         smallest family that holds len(x)).  `on_finish(index, tokens)` is called as each request completes (the
         engine starts that utterance's vocoder work on a side stream while the slots keep decoding).
         `max_new_tokens` (a list indexed like x; not in the reference, which stops at EOS or a full cache only) ends
-        request i once it has produced that many tokens -- tested at the same 5-step cadence as EOS, cut exactly."""
+        request i once it has produced that many tokens -- tested at the same 5-step cadence as EOS, cut exactly.
+        `async_refill` (not in the reference, whose slots all wait while a refill's prompt pass runs, :696-722) runs the
+        slot loop of `_infer_batched_staged` instead: same requests, same tokens per request, no stall."""
         B = len(x)
         sizes = sorted(self.cuda_graph_buckets)
         if slots is not None:
@@ -469,6 +649,10 @@ class Text2SemanticDecoder:
             raise ValueError("prompt longer than the largest KV bucket")
         self.prefill(batch_size, 0, xy, xl, yl)
         rows = torch.arange(batch_size, device=dev)
+        if async_refill and mode != 1:      # host-sampled tokens need every refill's logits at once: reference order
+            return self._infer_batched_staged(x, y, bert_feature, batch_size, first, nxt, exhausted,
+                                              [int(a) + int(b) for a, b in zip(x_lens_h, y_lens_h)], check_interval,
+                                              on_finish, max_new_tokens)
 
         have_tok = False
 
@@ -557,6 +741,7 @@ class Text2SemanticDecoder:
                 if cur is None:
                     exhausted = True
                     ignore[i] = True
+                    rt["kv_len"][i] = -1       # parked (gsv_tts_hip.h): an idle slot's steps attend over one row, not a growing cache
                     if all(ignore):
                         stop = True
                         break

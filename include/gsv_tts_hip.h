@@ -123,6 +123,21 @@ int gsv_t2s_prefill(gsv_t2s* h, int batch, int slot0, int nrows, int l_max, floa
 int gsv_t2s_prefill_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, int l_max, float* xy, const int64_t* x_lens,
                           const int64_t* y_lens, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The refill as an ASYNCHRONOUS pair, for continuous batching that does not stall its decode steps on a prompt pass:
+ *   gsv_t2s_prefill_slots_staged  the same prompt pass, callable on ANOTHER stream than the one the decode step
+ *       replays on.  It writes the K/V rows [0, x_len + y_len) of the listed slots and puts everything else the
+ *       step also writes (kv_len, x_len, step, eos_at, the first logits / hidden / pending token) into the library's
+ *       staging of that batch size.  Contract: before calling, PARK each listed slot by setting kv_len[slot] = -1
+ *       on the step's stream and treat it as idle: the decode step keeps a parked slot parked, sends its K/V row to the
+ *       last row of the cache (which no prompt of <= max_kv - 1 positions uses), lets it attend over row 0 only and
+ *       leaves its `seen` set alone.
+ *   gsv_t2s_commit_slots  on the step's stream, once the staged pass has completed (event): staging -> live state of
+ *       the listed slots; the next step decodes them.  Rows are independent, so tokens per request are unchanged. */
+int gsv_t2s_prefill_slots_staged(gsv_t2s* h, int batch, const int32_t* slots, int nrows, int l_max, float* xy,
+                                 const int64_t* x_lens, const int64_t* y_lens, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, void* stream);
+
 /* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
  * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
  * final hidden state to state.hidden and bumps kv_len.  No sampling.  Takes the path gsv_t2s_decode would take for

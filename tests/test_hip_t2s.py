@@ -525,3 +525,43 @@ def test_first_sample_is_suppressed_even_without_suppression_steps(dev):
     m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1, initial_suppression_steps=0, max_new_tokens=2)
     s0 = int(m._rt[1]["pre_tokens"][0, len(x) + len(y)].item())
     assert s0 not in (280, 486, 1024)
+
+
+@pytest.mark.parametrize("dtype,slots,n_layer", [(torch.float32, 4, 5), (torch.bfloat16, 4, 5), (torch.bfloat16, 40, 4)])
+def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_layer):
+    """async_refill: a finished slot is parked (kv_len = -1), its prompt pass runs on a side stream into the live K/V
+    rows and the library's staging while the other slots keep stepping, and gsv_t2s_commit_slots joins it later.  Which
+    window it joins at depends on timing; the tokens of every request must not: they equal the reference-order run's
+    (fp32: also the oracle's), request by request, on the per-sequence kernels (4 slots) and the batched chain (40)."""
+    cfg = synth.gpt_config(n_layer=n_layer)
+    w = synth.gpt_weights(cfg, seed=29, eos_gain=2.5)
+    cache = [(slots, 160)]
+    rng = np.random.default_rng(29)
+    n_req = 6 * slots + 3
+    shapes = [(int(rng.integers(2, 9)), int(rng.integers(3, 30)), int(rng.integers(4, 40))) for _ in range(n_req)]
+    rs = [synth.synth_request(300 + i, p, t, n, seed=29, bert="random") for i, (p, t, n) in enumerate(shapes)]
+    # fp32: requests end at their EOS, as in the oracle; bf16: a token budget per request as well (bench.py's workload)
+    budget = None if dtype == torch.float32 else [int(rng.integers(3, 60)) for _ in range(n_req)]
+    m = _model(cfg, w, cache, dtype, dev)
+    X, Y, Bt = [_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs]
+
+    def run(**kw):
+        pred, idx = m.infer_batched(X, Y, Bt, top_k=1, max_new_tokens=budget, **kw)
+        assert sorted(idx.tolist()) == list(range(n_req))
+        return {int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)}, dict(m.last_stats)
+
+    ref, st0 = run()
+    for rep in range(2):        # twice: the staging / parked state of one run must not leak into the next
+        got, st1 = run(async_refill=True)
+        assert st1["refills"] == st0["refills"] == n_req - slots
+        for i in range(n_req):
+            assert np.array_equal(got[i], ref[i]), (rep, i)
+    again, _ = run()
+    for i in range(n_req):
+        assert np.array_equal(again[i], ref[i])
+    if dtype == torch.float32:
+        from oracle import oracle as orc
+        o = orc.T2SOracle(cfg, w, cache)
+        op, oi = o.infer_batched([r[0] for r in rs], [r[1] for r in rs], [r[2] for r in rs], top_k=1)
+        for i, p in zip(oi.tolist(), op):
+            assert np.array_equal(ref[int(i)], p)
