@@ -1,8 +1,8 @@
 // enc_p (TextEncoder.infer, reference SoVITS/models.py:196-224; attentions.py:58-220; mrte_model.py:20-38)
 // on gfx950: the dense layers run on tapgemm (channels-last activations), this file holds what is left --
 // the attention with windowed relative positions, the channel LayerNorm and the two gathers.  bf16
-// activations / operands, fp32 softmax statistics and accumulation (production mode; the fp32 parity
-// mode keeps the torch restatement in sovits_encoder.py).
+// activations / operands, fp32 softmax statistics and accumulation (production mode).  The fp32 parity mode runs the
+// same layer sequence on fp32 tapgemm with the plain fp32 kernels at the end of this file.
 #pragma once
 #include "tapgemm.h"
 
@@ -306,6 +306,107 @@ __global__ __launch_bounds__(256) void encp_attn_kernel(EncAttnArgs a) {
             pk.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(a.O + (size_t)i * a.ldo + h * D + d0) = pk;
         }
+    }
+}
+
+// ---- fp32 parity mode -------------------------------------------------------------------------------------------
+static __global__ void encp_gather_f32_kernel(const int64_t* __restrict__ idx, int n_rows_table, const float* __restrict__ table, int C,
+                                              int rep, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    int id = (int)idx[r / rep];
+    id = min(max(id, 0), n_rows_table - 1);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[(size_t)r * C + c] = table[(size_t)id * C + c];
+}
+
+// y[t] = LN(x[t]) * gamma + beta in place, one wave per row, two-pass like F.layer_norm
+static __global__ __launch_bounds__(256) void encp_ln_f32_kernel(float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8];
+    int n = 0;
+    for (int c = lane; c < C; c += 64) v[n++] = x[(size_t)row * C + c];
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += v[i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+    n = 0;
+    for (int c = lane; c < C; c += 64) { x[(size_t)row * C + c] = v[n] * rs * gamma[c] + beta[c]; ++n; }
+}
+
+static __global__ void encp_add3_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g, int ldg,
+                                            float* __restrict__ y, int rows, int C) {
+    const size_t n = (size_t)rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        y[i] = a[i] + b[i] + g[(ldg ? r * (size_t)ldg : (size_t)0) + c];
+    }
+}
+
+struct EncAttnF32Args {
+    const float *Q, *K, *V;        // [T][ld], head h at column off + h*D
+    int ldq, ldk, ldv, qoff, koff, voff;
+    float* O; int ldo;
+    int Tq, Tk, D;
+    float rsqrt_d;                 // the reference divides q by sqrt(D) before both products (attentions.py:152)
+    const float *relk, *relv;      // [2w+1][D] or null
+    int window;
+    const int64_t* slice;          // as EncAttnArgs
+    float* P;                      // [H][Tq][Tk] or null
+};
+
+// one wave per (head, query): scores over the keys (a lane per key), softmax, then a lane per output channel.
+// The masked score is -1e4, not -inf (attentions.py:163).  Dynamic LDS: 4 waves x (Tk + D) floats.
+static __global__ __launch_bounds__(256) void encp_attn_f32_kernel(EncAttnF32Args a) {
+    extern __shared__ float encp_f32_lds[];
+    const int h = blockIdx.x, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.y * 4 + wid;
+    if (i >= a.Tq) return;
+    float* sc = encp_f32_lds + (size_t)wid * (a.Tk + a.D);
+    float* qs = sc + a.Tk;
+    const float sq = sqrtf((float)a.D);
+    for (int d = lane; d < a.D; d += 64) qs[d] = a.Q[(size_t)i * a.ldq + a.qoff + h * a.D + d] / sq;
+    __builtin_amdgcn_wave_barrier();
+    int lo = 0, hi = a.Tk;
+    if (a.slice) { lo = (int)a.slice[2 * i]; hi = (int)a.slice[2 * i + 1]; }
+    float mx = -INFINITY;
+    for (int j = lane; j < a.Tk; j += 64) {
+        const float* kr = a.K + (size_t)j * a.ldk + a.koff + h * a.D;
+        float s = 0.f;
+        for (int d = 0; d < a.D; ++d) s += qs[d] * kr[d];
+        if (a.relk && abs(j - i) <= a.window) {
+            const float* rk = a.relk + (size_t)(j - i + a.window) * a.D;
+            float r = 0.f;
+            for (int d = 0; d < a.D; ++d) r += qs[d] * rk[d];
+            s += r;
+        }
+        if (a.slice && !((j >= lo && j < hi) || j == a.Tk - 1)) s = -1e4f;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float l = 0.f;
+    for (int j = lane; j < a.Tk; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; l += e; }
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    for (int j = lane; j < a.Tk; j += 64) {
+        const float pj = sc[j] * inv;
+        sc[j] = pj;
+        if (a.P) a.P[((size_t)h * a.Tq + i) * a.Tk + j] = pj;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < a.D; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < a.Tk; ++j) o += sc[j] * a.V[(size_t)j * a.ldv + a.voff + h * a.D + d];
+        if (a.relv) {
+            float r = 0.f;
+            for (int j = max(0, i - a.window); j <= min(a.Tk - 1, i + a.window); ++j) r += sc[j] * a.relv[(size_t)(j - i + a.window) * a.D + d];
+            o += r;
+        }
+        a.O[(size_t)i * a.ldo + h * a.D + d] = o;
     }
 }
 

@@ -290,7 +290,8 @@ int voc_run(gsv_voc* v, int what, const float* z, const float* mask, const float
     return voc_dec_impl<AT>(v, w, T, Tg, out, st);
 }
 
-// ---- enc_p (bf16): weights -------------------------------------------------------------------
+// ---- enc_p: weights (packed as bf16 fragments, or fp32 ones for the parity mode) --------------
+template <typename CT>
 int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
     EncP& E = v->enc;
     auto get = [&](const std::string& n, int64_t numel, const float** out) -> int {
@@ -314,7 +315,7 @@ int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
         const float *w, *b;
         if (int rc = get(base + ".weight", (int64_t)cout * cin * k, &w)) return rc;
         if (int rc = get(base + ".bias", cout, &b)) return rc;
-        return pack_conv<bf16_t>(pc, w, cout, cin, k, (int64_t)cin * k, k, 1, 1, (k - 1) / 2, 0, b, 1.f, st);
+        return pack_conv<CT>(pc, w, cout, cin, k, (int64_t)cin * k, k, 1, 1, (k - 1) / 2, 0, b, 1.f, st);
     };
     // several 1x1 convs of one input stacked along the output channels (q|k|v)
     auto stacked = [&](PackedConv& pc, const std::vector<std::string>& bases, int cout_each, int cin) -> int {
@@ -330,7 +331,7 @@ int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
             HIPCHK(hipMemcpyAsync(w + (size_t)i * cout_each * cin, ws, sizeof(float) * (size_t)cout_each * cin, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(b + (size_t)i * cout_each, bs, sizeof(float) * cout_each, hipMemcpyDeviceToDevice, st));
         }
-        return pack_conv<bf16_t>(pc, w, n * cout_each, cin, 1, cin, 1, 0, 1, 0, 0, b, 1.f, st);
+        return pack_conv<CT>(pc, w, n * cout_each, cin, 1, cin, 1, 0, 1, 0, 0, b, 1.f, st);
     };
     const int Hc = v->cfg.hidden_channels;                   // 192
     const int Fc = 4 * Hc;                                   // filter channels (768)
@@ -496,6 +497,85 @@ int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text,
     if (int rc = enc_gemm(E.c_post, w.xsum, 512, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
     if (int rc = encp_encoder(v, E.enc2, w.y, T, w, st)) return rc;
     if (int rc = enc_gemm(E.proj, w.y, Hc, T, true, 0, w.stats, 2 * C, true, 1, 0, st)) return rc;
+    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats, m_p, C, T, 2 * C);
+    hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats + C, logs_p, C, T, 2 * C);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+// ---- enc_p, fp32 parity mode: the same layer sequence on fp32 tapgemm + the plain fp32 kernels of encp.h --------
+struct EncWsF {
+    float *y768, *y, *t, *qkv, *att, *tmp, *ffn, *ssl512, *text512, *xq, *xkv, *xatt, *xo, *xsum, *stats;
+    size_t bytes;
+};
+EncWsF encp_layout_f32(const gsv_voc* v, int T, int P, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? (float*)(base + off) : nullptr; off += align_up(4 * n, 256); return p; };
+    const int Hc = v->cfg.hidden_channels, R = std::max(T, P);
+    EncWsF w;
+    w.y768 = take((size_t)T * 768); w.y = take((size_t)T * Hc); w.t = take((size_t)P * Hc); w.qkv = take((size_t)R * 3 * Hc);
+    w.att = take((size_t)R * Hc); w.tmp = take((size_t)R * Hc); w.ffn = take((size_t)R * 4 * Hc);
+    w.ssl512 = take((size_t)T * 512); w.text512 = take((size_t)P * 512); w.xq = take((size_t)T * 512); w.xkv = take((size_t)P * 1024);
+    w.xatt = take((size_t)T * 512); w.xo = take((size_t)T * 512); w.xsum = take((size_t)T * 512);
+    w.stats = take((size_t)T * 2 * v->cfg.inter_channels);
+    w.bytes = off;
+    return w;
+}
+
+int encp_dense_f32(const PackedConv& pc, const float* X, int ldx, int rows, float* Y, int ldy, int act, const float* res, hipStream_t st) {
+    Epi e; e.act = act; e.res = res; e.ld_res = res ? ldy : 0;
+    return run_conv<float, float, float>(pc, X, ldx, rows, Y, ldy, rows, e, st);
+}
+
+int encp_attn_f32(const float* Q, int ldq, int qoff, const float* K, const float* V, int ldkv, int koff, int voff, float* O, int ldo, int Tq, int Tk,
+                  int H, int D, const float* relk, const float* relv, const int64_t* slice, float* P, hipStream_t st) {
+    EncAttnF32Args a;
+    a.Q = Q; a.K = K; a.V = V; a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.qoff = qoff; a.koff = koff; a.voff = voff; a.O = O; a.ldo = ldo;
+    a.Tq = Tq; a.Tk = Tk; a.D = D; a.rsqrt_d = 0.f; a.relk = relk; a.relv = relv; a.window = 4; a.slice = slice; a.P = P;
+    const size_t lds = sizeof(float) * 4 * (size_t)(Tk + D);
+    if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "enc_p (fp32): %d keys exceed the attention kernel's LDS rows", Tk);
+    HIPCHK(hipFuncSetAttribute((const void*)encp_attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(encp_attn_f32_kernel, dim3(H, cdiv(Tq, 4)), dim3(256), lds, st, a);
+    return GSV_OK;
+}
+
+int encp_encoder_f32(gsv_voc* v, std::vector<EncLayer>& Ls, float* x, int R, EncWsF& w, hipStream_t st) {
+    const int Hc = v->cfg.hidden_channels;
+    for (EncLayer& L : Ls) {
+        if (int rc = encp_dense_f32(L.qkv, x, Hc, R, w.qkv, 3 * Hc, ACT_NONE, nullptr, st)) return rc;
+        if (int rc = encp_attn_f32(w.qkv, 3 * Hc, 0, w.qkv, w.qkv, 3 * Hc, Hc, 2 * Hc, w.att, Hc, R, R, 2, Hc / 2, L.relk, L.relv, nullptr, nullptr, st)) return rc;
+        if (int rc = encp_dense_f32(L.o, w.att, Hc, R, w.tmp, Hc, ACT_NONE, x, st)) return rc;      // x + attn_out
+        hipLaunchKernelGGL(encp_ln_f32_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, w.tmp, (const float*)L.g1, (const float*)L.b1, R, Hc);
+        if (int rc = encp_dense_f32(L.c1, w.tmp, Hc, R, w.ffn, 4 * Hc, ACT_RELU, nullptr, st)) return rc;
+        if (int rc = encp_dense_f32(L.c2, w.ffn, 4 * Hc, R, x, Hc, ACT_NONE, w.tmp, st)) return rc;  // x + ffn_out
+        hipLaunchKernelGGL(encp_ln_f32_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, x, (const float*)L.g2, (const float*)L.b2, R, Hc);
+    }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int encp_run_f32(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg,
+                 const int64_t* slice, float* m_p, float* logs_p, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
+    EncP& E = v->enc;
+    const int Hc = v->cfg.hidden_channels, C = v->cfg.inter_channels, T = 2 * n_codes;
+    EncWsF w = encp_layout_f32(v, T, P, (char*)ws);
+    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "enc_p workspace %zu < %zu", ws_bytes, w.bytes);
+    hipLaunchKernelGGL(encp_gather_f32_kernel, dim3(T), dim3(256), 0, st, codes, E.n_code, (const float*)E.codebook, 768, 2, w.y768);
+    hipLaunchKernelGGL(encp_gather_f32_kernel, dim3(P), dim3(64), 0, st, text, E.n_text, (const float*)E.text_emb, Hc, 1, w.t);
+    if (int rc = encp_dense_f32(E.ssl_proj, w.y768, 768, T, w.y, Hc, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_encoder_f32(v, E.ssl, w.y, T, w, st)) return rc;
+    if (int rc = encp_encoder_f32(v, E.text, w.t, P, w, st)) return rc;
+    if (int rc = encp_dense_f32(E.c_pre, w.y, Hc, T, w.ssl512, 512, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_dense_f32(E.text_pre, w.t, Hc, P, w.text512, 512, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_dense_f32(E.xq, w.ssl512, 512, T, w.xq, 512, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_dense_f32(E.xkv, w.text512, 512, P, w.xkv, 1024, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_attn_f32(w.xq, 512, 0, w.xkv, w.xkv, 1024, 0, 512, w.xatt, 512, T, P, 4, 128, nullptr, nullptr, slice, attn, st)) return rc;
+    if (int rc = encp_dense_f32(E.xo, w.xatt, 512, T, w.xo, 512, ACT_NONE, nullptr, st)) return rc;
+    hipLaunchKernelGGL(encp_add3_f32_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const float*)w.xo, (const float*)w.ssl512, ge512,
+                       Tg == 1 ? 0 : 512, w.xsum, T, 512);
+    if (int rc = encp_dense_f32(E.c_post, w.xsum, 512, T, w.y, Hc, ACT_NONE, nullptr, st)) return rc;
+    if (int rc = encp_encoder_f32(v, E.enc2, w.y, T, w, st)) return rc;
+    if (int rc = encp_dense_f32(E.proj, w.y, Hc, T, w.stats, 2 * C, ACT_NONE, nullptr, st)) return rc;
     hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats, m_p, C, T, 2 * C);
     hipLaunchKernelGGL((cl_to_cf_kernel<float>), dim3(cdiv(T, 32), cdiv(C, 32)), dim3(256), 0, st, (const float*)w.stats + C, logs_p, C, T, 2 * C);
     HIPCHK(hipGetLastError());
@@ -686,7 +766,7 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
             v->post_c = ch;
         }
     }
-    if (!rc && sizeof(CT) == 2 && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize(v, temps, st);
+    if (!rc && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize<CT>(v, temps, st);
     (void)hipStreamSynchronize(st);
     for (float* t : temps) (void)hipFree(t);
     if (rc) return rc;
@@ -774,16 +854,18 @@ int gsv_voc_has_enc_p(gsv_voc* v) { return v && v->finalized && v->enc.ready ? 1
 
 size_t gsv_voc_enc_workspace(gsv_voc* v, int n_codes, int n_text) {
     if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1) return 0;
-    return encp_layout(v, 2 * n_codes, n_text, nullptr).bytes;
+    return v->cfg.dtype == GSV_BF16 ? encp_layout(v, 2 * n_codes, n_text, nullptr).bytes : encp_layout_f32(v, 2 * n_codes, n_text, nullptr).bytes;
 }
 
 int gsv_voc_enc_p(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge512, int Tg,
                   const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
                   void* stream) {
     if (!v || !v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
-    if (!v->enc.ready) return fail(GSV_ERR_STATE, "enc_p tensors were not loaded (or the handle is not bf16)");
+    if (!v->enc.ready) return fail(GSV_ERR_STATE, "enc_p tensors were not loaded");
     if (!codes || !text || !ge512 || !m_p || !logs_p || !workspace) return fail(GSV_ERR_ARG, "null argument");
     if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != 2 * n_codes)) return fail(GSV_ERR_ARG, "enc_p: bad lengths");
+    if (v->cfg.dtype != GSV_BF16)
+        return encp_run_f32(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
     return encp_run(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
 }
 

@@ -7,8 +7,9 @@ TTS reads (`samples_per_frame`, `enc_p.y_overlap`, `enc_p.mrte.cross_attention.a
 
 flow + Generator (models.py:58-65, 113-132 -- the >90% of vocoder time)
 run as hand-written HIP behind `gsv_voc_flow_dec`.  The text/ssl encoder `enc_p` (SURVEY.md 8(f)
-rank 1) runs on device too in bf16 mode (`gsv_voc_enc_p`, csrc/encp.h); its torch restatement in
-sovits_encoder.py serves the fp32 parity mode, speed != 1 and streaming calls.
+rank 1) runs on device too (`gsv_voc_enc_p`, csrc/encp.h: bf16 MFMA kernels, and plain fp32 ones for the
+parity mode); its torch restatement in sovits_encoder.py is what the tests compare it with (and what serves
+batched `codes`, which the reference never passes).
 """
 from __future__ import annotations
 
@@ -60,7 +61,7 @@ class _VocoderNative:
         stream = N.current_stream_ptr(self.device)
         for name, t in weights.items():
             enc = name.startswith("enc_p.") or name == "quantizer.vq.layers.0._codebook.embed"
-            if not (name.startswith("dec.") or name.startswith("flow.") or (enc and dtype == torch.bfloat16)):
+            if not (name.startswith("dec.") or name.startswith("flow.") or enc):
                 continue
             d = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
             N.check(L.gsv_voc_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
@@ -201,7 +202,7 @@ class SynthesizerTrn:
         self._voc = None
         self.enc_p = None
         self._ref = None
-        self.native_enc_p = True   # bf16: run enc_p on device when its tensors are loaded, incl. speed != 1 and streaming (fp32 keeps the torch path)
+        self.native_enc_p = True   # run enc_p on device when its tensors are loaded (bf16 and the fp32 parity mode), incl. speed != 1 and streaming
 
     def load_state_dict(self, sd, strict=False):
         self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)

@@ -16,13 +16,50 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _vq(ver, seed, dev):
+def _vq(ver, seed, dev, dtype=torch.bfloat16):
     from gsv_tts_lite_amd.sovits import SynthesizerTrn
     hps = synth.sovits_hps(ver)
     vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
     vq.load_state_dict(synth.sovits_weights(hps, seed=seed))
-    vq.initialize_runtime(torch.bfloat16, dev, [64])
+    vq.initialize_runtime(dtype, dev, [64])
     return vq
+
+
+@pytest.mark.parametrize("ver", ["v2Pro", "v2"])
+def test_enc_p_fp32_parity_mode_on_device(dev, ver):
+    """fp32 handle: enc_p runs on device too (fp32 tapgemm + the plain fp32 attention / LayerNorm kernels of csrc/encp.h)
+    and must agree with the torch restatement -- which decode.npz pins to the reference -- to fp32 summation-order
+    accuracy: measured max 4e-6 on m_p / logs_p (values of ~0.8) and 4e-7 on the softmax probabilities; gates 2e-5 / 2e-6.
+    Same cases as the bf16 test."""
+    vq = _vq(ver, 7, dev, torch.float32)
+    assert vq._voc.has_enc_p
+    rng = np.random.default_rng(3)
+    gin = 1024 if ver == "v2Pro" else 512
+    for n_codes, P, mode in [(25, 30, "c"), (70, 41, "pf"), (3, 5, "c"), (150, 100, "slice")]:
+        T = 2 * n_codes
+        codes = torch.from_numpy(rng.integers(0, 1024, (1, 1, n_codes))).to(dev)
+        text = torch.from_numpy(rng.integers(1, 700, (1, P))).to(dev)
+        ge = torch.from_numpy(synth.synth_ge(1, gin, 7)).to(dev)
+        sl = None
+        if mode != "c":
+            ge = torch.cat([ge.expand(-1, -1, T // 2), torch.from_numpy(synth.synth_ge(2, gin, 7)).to(dev).expand(-1, -1, T - T // 2)], 2)
+        if mode == "slice":
+            cut_t, cut_p = T // 2, P // 2
+            sl = torch.tensor([[0, cut_p]] * cut_t + [[cut_p, P]] * (T - cut_t), device=dev)
+        ge_in = vq.enc_p.ge_to512(ge) if vq.is_v2pro else ge
+        with torch.inference_mode():
+            q = vq._codebook_decode(vq._weights, codes)
+            q = F.interpolate(q, size=q.shape[-1] * 2, mode="nearest")
+            m_ref, logs_ref, _ = vq.enc_p.infer(q, text, ge_in, 1, slice_indices=sl)
+            a_ref = vq.enc_p.mrte.cross_attention.attn[0].clone()
+            m, logs, attn = vq._voc.enc_p(codes[0, 0], text[0], ge_in, sl)
+        for got, ref, name in ((m, m_ref, "m_p"), (logs, logs_ref, "logs_p"), (attn, a_ref, "attn")):
+            err = (got - ref).abs().max().item()
+            print("enc_p fp32 %s %s %s: max |err| %.2e" % (ver, mode, name, err))
+            assert got.shape == ref.shape and torch.isfinite(got).all()
+            assert err < (2e-6 if name == "attn" else 2e-5), (ver, mode, name, err)
+        if sl is not None:
+            assert attn[:, :cut_t, cut_p:P - 1].max().item() < 1e-30     # masked at -1e4: exp underflows to 0
 
 
 @pytest.mark.parametrize("ver", ["v2Pro", "v2"])
