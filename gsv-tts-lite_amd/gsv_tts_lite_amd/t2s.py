@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import List
 
 import numpy as np
@@ -89,6 +90,7 @@ class Text2SemanticDecoder:
         self.EOS = m["EOS"]
         self.suppressed_tokens = [280, 486, self.EOS]
         self.cuda_graph_buckets = {}
+        self.refill_group = int(os.environ.get("GSV_REFILL_GROUP", "2"))   # staged refill: requests a prompt pass waits for (at most one window)
         self.use_graph = True
         self._eos_pipe = None
         self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
@@ -455,6 +457,8 @@ class Text2SemanticDecoder:
             rt["kv_len"][actual:] = -1
         pred, orig = [], []
         waiting: list = []      # (slot, request): parked, prompt pass not launched yet
+        waiting_since = [0]     # window at which the oldest of them was parked
+        window = 0
         inflight: list = []     # at most one staged prompt pass: (slots, device slot list, done event, keep-alive tensors)
         to_cut: list = []       # (window, slot, request, first row, most tokens): parked, tokens not collected yet
         snap_host = torch.empty((2, 2, B), dtype=torch.int64).pin_memory()
@@ -475,6 +479,8 @@ class Text2SemanticDecoder:
                 raise ValueError("prompt longer than the largest KV bucket")
             state[i], req[i] = PARKED, cur
             waiting.append((i, cur, n_new))
+            if len(waiting) == 1:
+                waiting_since[0] = window
 
         def collect(i, r, a0, n_keep):
             seg = rt["pre_tokens"][i, a0: a0 + max(0, n_keep)].clone()
@@ -483,8 +489,12 @@ class Text2SemanticDecoder:
             if on_finish is not None:
                 on_finish(r, seg)
 
-        def launch_refill():
+        def launch_refill(force=False):
             if inflight or not waiting:
+                return
+            # a prompt pass is ~120 launches whatever its row count and takes its share of the chip from the steps: a lone
+            # request waits one window for company (costs 1/B of a window's tokens, saves most of a pass)
+            if not force and len(waiting) < self.refill_group and window - waiting_since[0] < 1:
                 return
             group = waiting[:]
             waiting.clear()
@@ -539,7 +549,7 @@ class Text2SemanticDecoder:
                     collect(i, req[i], start[i] + 1, eos_s[i] - 1)
                     park(i)
 
-        window, idx = 0, 0
+        idx = 0
         while True:
             if not any(st == LIVE for st in state):
                 while snaps:                        # nothing is running that the read-backs could hide behind
@@ -547,7 +557,7 @@ class Text2SemanticDecoder:
             join(window, block=not any(st == LIVE for st in state))
             if not any(st == LIVE for st in state):
                 if waiting and not inflight:        # nothing left to overlap the prompt pass with
-                    launch_refill()
+                    launch_refill(force=True)
                     continue
                 if inflight:
                     continue

@@ -38,7 +38,7 @@ def _model(dev, dtype=torch.float32):
     return cfg, m
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, async_refill):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -52,19 +52,21 @@ def _worker(rank, world, port, ret):
     eng = engine.ContinuousBatchingEngine(m, slots=SLOTS, chunk=1)
     book = engine.SpeakerBook(dev)
     ge = book.sync("spk", [T(synth.synth_ge(0, 1024, SEED))] if rank == 0 else None)[0]
-    out = eng.run([T(r[0]) for r in rs], [T(r[1]) for r in rs], [T(r[2]) for r in rs], top_k=1)
+    out = eng.run([T(r[0]) for r in rs], [T(r[1]) for r in rs], [T(r[2]) for r in rs], top_k=1, async_refill=async_refill)
     ret[rank] = ([t.tolist() for t in out], list(eng.last_taken), float(ge.abs().sum().item()), book.broadcasts)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_one_gpu_equal_single_process_and_oracle():
+@pytest.mark.parametrize("async_refill", [False, True])
+def test_two_ranks_sharing_one_gpu_equal_single_process_and_oracle(async_refill):
+    """async_refill=True is the slot loop bench.py's cb workload runs (parked slots, staged prompt passes on a side stream)"""
     assert torch.cuda.is_available()
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, async_refill), nprocs=world, join=True)
     out0, t0, g0, b0 = ret[0]
     out1, t1, g1, b1 = ret[1]
     assert out0 == out1 and len(out0) == N_REQ
