@@ -572,6 +572,25 @@ def run_cb(a):
         "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
         "rank0_requests_served_per_step": acc["mine"] / a.steps,
     }
+    if rank == 0 and not a.no_extras:
+        # BASELINE's "p50 TTFT ... bs=32": the first `slots` requests of the queue arrive together -> packed prompt pass of
+        # all of them + the first decode step (every request's first token exists), outside the timed region
+        try:
+            first = list(range(min(a.slots, n_req)))
+            ts = []
+            for _ in range(12):
+                torch.cuda.synchronize(dev); q0 = time.perf_counter()
+                with torch.inference_mode():
+                    xy, xl, yl, _, _ = t2s.embed_prompt([xs[c] for c in first], [ys[c] for c in first], [bs[c] for c in first])
+                    t2s.prefill(a.slots, 0, xy, xl, yl)
+                    t2s._decode(a.slots, 1)
+                torch.cuda.synchronize(dev); ts.append(time.perf_counter() - q0)
+            out["ttft_ms_p50_first_batch"] = sorted(ts[2:])[len(ts[2:]) // 2] * 1e3
+            out["ttft_first_batch_note"] = "%d prompts (%d positions in all) in one packed prompt pass + the first decode step" % (
+                len(first), int(sum(int(xs[c].shape[0]) + int(ys[c].shape[0]) for c in first)))
+        except Exception as e:  # noqa: BLE001
+            out["ttft_ms_p50_first_batch"] = None
+            log("first-batch TTFT failed: %r" % (e,))
     if rank == 0:
         # step-level roofline of the batched decode step on this rank: weights once per step + the K/V rows read
         wbytes = GPT_PARAMS * 2

@@ -734,18 +734,115 @@ __device__ __forceinline__ float t2s_uniform(uint32_t seed_lo, uint32_t seed_hi,
     return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
 }
 
-// block-wide (value, lowest index) argmax over 256 threads; every thread gets the winner
-__device__ __forceinline__ void t2s_block_argmax(float& v, int& idx, float* sv, int* si) {
-    argmax_step<32>(v, idx); argmax_step<16>(v, idx); argmax_step<8>(v, idx);
-    argmax_step<4>(v, idx); argmax_step<2>(v, idx); argmax_step<1>(v, idx);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { sv[w] = v; si[w] = idx; }
-    __syncthreads();
-    v = sv[0]; idx = si[0];
+// Device sampling (ctl[0] == 2) by ONE wave, lane l holding vocabulary entries l, l + 64, ... (V <= 64 * NPL): top-p,
+// temperature, top-k with the reference's tie rule, then the exponential race of GPT/utils.py:56-59 as a Gumbel argmax
+// (argmax p/q, q ~ Exp(1)  ==  argmax (x - log q)).  Every reduction is a cross-lane one: no block barrier, no LDS
+// (the 256-thread version paid two barriers per top-k round and per top-p bisection step: 20 / 35 us per token).
+template <int NPL>
+__device__ __forceinline__ int t2s_sample_wave(const float* __restrict__ lg, int V, float temperature, float top_p, int k, uint32_t seed_lo,
+                                               uint32_t seed_hi, uint32_t slot, uint32_t pos, uint32_t stp) {
+    const int lane = threadIdx.x & 63;
+    const float invt = 1.0f / fmaxf(temperature, 1e-5f);
+    float x[NPL];
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (sv[i] > v || (sv[i] == v && si[i] < idx)) { v = sv[i]; idx = si[i]; }
+    for (int i = 0; i < NPL; ++i) {
+        const int v = lane + 64 * i;
+        x[i] = v < V ? lg[min(v, V - 1)] * invt : -INFINITY;
+    }
+    // top-p (GPT/utils.py:29-40), on the un-tempered penalised logits: a token stays iff the probability mass of the
+    // tokens at least as likely as it is <= top_p (or it is the arg-max).  That set is {p >= tau}; tau is found by
+    // bisection over the float bit pattern (31 wave sums) instead of the reference's sort + cumsum.
+    if (top_p > 0.f && top_p < 1.0f) {
+        float lmax = -INFINITY; int li = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (x[i] > lmax) { lmax = x[i]; li = lane + 64 * i; }
+        argmax_step<32>(lmax, li); argmax_step<16>(lmax, li); argmax_step<8>(lmax, li);
+        argmax_step<4>(lmax, li); argmax_step<2>(lmax, li); argmax_step<1>(lmax, li);
+        const float lm = lmax * (1.0f / invt);           // x holds logits * invt
+        float pr[NPL], z = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            pr[i] = x[i] > -INFINITY ? expf(x[i] * (1.0f / invt) - lm) : 0.f;
+            z += pr[i];
+        }
+        const float iz = 1.0f / wave_sum(z);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) pr[i] *= iz;
+        unsigned lo = 0u, hi = 0x3f800001u;              // G(lo) > top_p >= G(hi)
+        for (int it = 0; it < 31 && hi - lo > 1u; ++it) {
+            const unsigned mid = lo + (hi - lo) / 2u;
+            const float xm = __uint_as_float(mid);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) s += pr[i] >= xm ? pr[i] : 0.f;
+            if (wave_sum(s) <= top_p) hi = mid; else lo = mid;
+        }
+        const float tau = __uint_as_float(hi);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (!(pr[i] >= tau) && lane + 64 * i != li) x[i] = -INFINITY;
+    }
+    // top-k: k rounds, each takes ONE maximum out (duplicates count, as torch.topk); the k-th one taken is the pivot and
+    // everything >= it stays (GPT/utils.py:47-50 keeps ties).  Entries are taken by slot, so -inf ones count too.
+    float pivot = -INFINITY, top = -INFINITY;
+    uint32_t removed = 0u;
+    const bool compact = k > 0 && k < V && k <= 64;      // the k entries taken are handed to lanes 0 .. k-1 as they are found
+    float cx = -INFINITY; int cv = 0x7fffffff;
+    if (k > 0 && k < V) {
+        for (int r = 0; r < k; ++r) {
+            float bv = -INFINITY; int bs = -1;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (!((removed >> i) & 1u) && lane + 64 * i < V && (bs < 0 || x[i] > bv)) { bv = x[i]; bs = i; }
+            const float m = wave_max(bs >= 0 ? bv : -INFINITY);
+            const unsigned long long cand = __builtin_amdgcn_ballot_w64(bs >= 0 && bv == m);
+            if (cand == 0ull) break;                      // fewer than k entries in all (k < V excludes it)
+            const int winner = __builtin_ctzll(cand);
+            if (lane == winner) removed |= 1u << bs;
+            const int vwin = __builtin_amdgcn_readlane(lane + 64 * bs, winner);
+            if (compact && lane == r) { cx = m; cv = vwin; }
+            if (r == 0) top = m;
+            pivot = m;
+        }
+    } else {
+        float bv = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) bv = fmaxf(bv, x[i]);
+        top = wave_max(bv);
+    }
+    // The race.  Its candidates are x >= pivot (the pivot keeps ties; logits < pivot -> -inf).  With k <= 64 the k entries
+    // taken sit one per lane already; what is left are entries EQUAL to the pivot that were not taken (rare).  ONE copy of
+    // the noise + score code, in a loop that runs once in the common case: a single wave runs this path cold, so its
+    // instruction footprint is its latency (an unrolled per-slot version measured 14 us, mostly instruction fetch).
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    uint32_t pend = 0u;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const bool in = lane + 64 * i < V && x[i] > -INFINITY && (compact ? (!((removed >> i) & 1u) && x[i] == pivot) : x[i] >= pivot);
+        pend |= in ? 1u << i : 0u;
+    }
+    bool hc = compact && cx > -INFINITY;
+    while (__builtin_amdgcn_ballot_w64(hc || pend != 0u) != 0ull) {
+        float tx = cx; int tv = cv;
+        bool act = hc;
+        if (!hc && pend != 0u) {
+#pragma unroll
+            for (int i = NPL - 1; i >= 0; --i)
+                if ((pend >> i) & 1u) { tx = x[i]; tv = lane + 64 * i; }
+            pend &= pend - 1u;                           // the lowest pending slot is the one just picked
+            act = true;
+        }
+        hc = false;
+        if (act) {
+            const float u = t2s_uniform(seed_lo, seed_hi, slot, pos, stp, (uint32_t)tv);
+            const float sc = (tx - top) - logf(-logf(u));
+            if (sc > bv || (sc == bv && tv < bi)) { bv = sc; bi = tv; }
+        }
+    }
+    argmax_step<32>(bv, bi); argmax_step<16>(bv, bi); argmax_step<8>(bv, bi);
+    argmax_step<4>(bv, bi); argmax_step<2>(bv, bi); argmax_step<1>(bv, bi);
+    return bi < V ? bi : 0;
 }
 
 static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
@@ -754,90 +851,11 @@ static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     // ---- device sampling (ctl[0] == 2): temperature, top-k with the reference's tie rule, then the
     // exponential race of GPT/utils.py:56-59 as a Gumbel argmax: argmax p/q, q ~ Exp(1)  ==  argmax (x - log q)
     int sampled = -1;
-    if (a.ctl[0] == 2) {
-        __shared__ float sv[4];
-        __shared__ int si[4];
-        constexpr int NPT = 8;                           // vocabulary entries per thread (V <= 2048)
-        const float invt = 1.0f / fmaxf(a.fctl[1], 1e-5f);
-        float x[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int v = tid + 256 * i;
-            x[i] = v < a.V ? a.logits[(size_t)b * a.V + v] * invt : -INFINITY;
-        }
-        // top-p (GPT/utils.py:29-40), on the un-tempered penalised logits: a token stays iff the probability mass of the
-        // tokens at least as likely as it is <= top_p (or it is the arg-max).  That set is {p >= tau}; tau is found by
-        // bisection over the float bit pattern (31 block sums) instead of the reference's sort + cumsum.
-        const float top_p = a.fctl[2];
-        if (top_p > 0.f && top_p < 1.0f) {
-            float lmax = -INFINITY; int li = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                if (x[i] > lmax) { lmax = x[i]; li = tid + 256 * i; }
-            t2s_block_argmax(lmax, li, sv, si);
-            const float lm = lmax * (1.0f / invt);           // x holds logits * invt
-            float pr[NPT], z = 0.f;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) {
-                const int v = tid + 256 * i;
-                pr[i] = (v < a.V && x[i] > -INFINITY) ? expf(x[i] * (1.0f / invt) - lm) : 0.f;
-                z += pr[i];
-            }
-            __shared__ float zred[8];
-            z = block_sum<4>(z, zred);
-            const float iz = 1.0f / z;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) pr[i] *= iz;
-            unsigned lo = 0u, hi = 0x3f800001u;              // G(lo) > top_p >= G(hi)
-            for (int it = 0; it < 31 && hi - lo > 1u; ++it) {
-                const unsigned mid = lo + (hi - lo) / 2u;
-                const float xm = __uint_as_float(mid);
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < NPT; ++i) s += pr[i] >= xm ? pr[i] : 0.f;
-                s = block_sum<4>(s, zred);
-                if (s <= top_p) hi = mid; else lo = mid;
-            }
-            const float tau = __uint_as_float(hi);
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                if (!(pr[i] >= tau) && tid + 256 * i != li) x[i] = -INFINITY;
-        }
-        const int k = a.ctl[4];
-        float pivot = -INFINITY, top = -INFINITY;
-        if (k > 0 && k < a.V) {
-            unsigned removed = 0u;                       // k rounds: take out one maximum per round (duplicates count)
-            for (int r = 0; r < k; ++r) {
-                float bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-                for (int i = 0; i < NPT; ++i)
-                    if (!((removed >> i) & 1u) && (x[i] > bv || (x[i] == bv && tid + 256 * i < bi))) { bv = x[i]; bi = tid + 256 * i; }
-                t2s_block_argmax(bv, bi, sv, si);
-                if (bi < 0x7fffffff && (bi & 255) == tid) removed |= 1u << (bi >> 8);
-                if (r == 0) top = bv;
-                pivot = bv;
-            }
-        } else {
-            float bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                if (x[i] > bv) { bv = x[i]; bi = tid + 256 * i; }
-            t2s_block_argmax(bv, bi, sv, si);
-            top = bv;
-        }
+    if (a.ctl[0] == 2 && tid < 64) {
+        const float* lg = a.logits + (size_t)b * a.V;
         const uint32_t pos = (uint32_t)a.kv_len[b], stp = (uint32_t)a.step[b];
-        float bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int v = tid + 256 * i;
-            if (v < a.V && x[i] >= pivot && x[i] > -INFINITY) {   // the pivot keeps ties (logits < pivot -> -inf)
-                const float u = t2s_uniform((uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp, (uint32_t)v);
-                const float sc = (x[i] - top) - logf(-logf(u));
-                if (sc > bv || (sc == bv && v < bi)) { bv = sc; bi = v; }
-            }
-        }
-        t2s_block_argmax(bv, bi, sv, si);
-        sampled = bi < a.V ? bi : 0;
+        sampled = a.V <= 64 * 17 ? t2s_sample_wave<17>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp)
+                                 : t2s_sample_wave<32>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp);
     }
     if (tid == 0) {
         int tok;
