@@ -354,7 +354,7 @@ def run_single(a):
         gbs = step_bytes / (ar_decode_s / tokens_per_step) / 1e9
         out["roofline_step"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                 "traffic": None, "bytes_per_token": step_bytes, "ms_per_token": ar_decode_s / tokens_per_step * 1e3,
-                                "note": "whole decode step (50 launches replayed from one hipGraph): (76.2 M weights + K/V rows at the run's "
+                                "note": "whole decode step (49 launches replayed from one hipGraph: the token kernel's work is in layer 0's attention kernel; t2s_token_kernel runs once per 5-step window as the flush): (76.2 M weights + K/V rows at the run's "
                                         "mean kv) x dtype bytes / measured time per token (AR phase minus the p50 prefill)"}
 
         # ---- roofline of the decode-step kernels: each class's 24 launches replayed from a hipGraph between two
@@ -369,7 +369,7 @@ def run_single(a):
         b_log = 1025 * 512 * sbytes
         kern = []
         for name, t_ms, byts, per_tok in (("t2s_attn_kernel", ms[0], b_attn, 24), ("t2s_ffn_kernel", ms[1], b_ffn, 24),
-                                          ("t2s_logits_kernel", ms[2], b_log, 1), ("t2s_token_kernel", ms[3], 4096, 1)):
+                                          ("t2s_logits_kernel", ms[2], b_log, 1), ("t2s_token_kernel", ms[3], 4096, 0.2)):
             g = byts / (t_ms * 1e-3) / 1e9
             kern.append({"kernel": name, "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": g / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": t_ms * 1e3,

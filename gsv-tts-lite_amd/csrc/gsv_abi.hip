@@ -36,6 +36,7 @@ struct T2SLayer {
 struct T2SBound {
     gsv_t2s_state st;
     hipGraphExec_t graph = nullptr;       // the captured decode step
+    hipGraphExec_t graph_ft = nullptr;    // ... with the token kernel's work in layer 0's attention kernel (GSV_STEP_FUSED_TOKEN)
     // staging of a refill that runs on ANOTHER stream while the decode step keeps replaying on the caller's
     // (gsv_t2s_prefill_slots_staged / gsv_t2s_commit_slots): per-slot state the step also writes must not be
     // touched by the prompt pass; it lands here and the commit, ordered on the step's stream, moves it over
@@ -213,11 +214,13 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     // graphs captured against the old scratch pointers are stale
     for (auto& kv : h->bound)
         if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+    for (auto& kv : h->bound)
+        if (kv.second.graph_ft) { (void)hipGraphExecDestroy(kv.second.graph_ft); kv.second.graph_ft = nullptr; }
     return GSV_OK;
 }
 
 template <typename WT>
-void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsrc, hipStream_t st) {
+void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsrc, hipStream_t st, bool fused_token = false) {
     const int B = s.batch, T = s.max_kv;
     const size_t lds = 0;  // static LDS only: scores never leave registers
     const size_t layer_elems = (size_t)B * kH * T * kDh;
@@ -240,7 +243,13 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
         else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
         return;
     }
-    if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
+    if (l == 0 && fused_token) {
+        StepTok& k = a.tk;
+        k.tokpart = h->tokpart; k.tok_override = s.tok_override; k.ctl = s.ctl; k.x_len = s.x_len; k.pre_tokens = s.pre_tokens;
+        k.seen = s.seen; k.step = s.step; k.eos_at = s.eos_at; k.emb = h->emb_audio; k.pe = h->pe_audio;
+        k.V = h->cfg.vocab; k.eos = h->cfg.eos; k.n_pos = h->cfg.n_pos;
+        hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
+    } else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
 
@@ -269,9 +278,9 @@ int t2s_multi_lds_attr() {
 
 // the transformer stack for one token per slot; x from `xsrc` [B][512]
 template <typename WT>
-int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st) {
+int t2s_layers(gsv_t2s* h, const gsv_t2s_state& s, const float* xsrc, hipStream_t st, bool fused_token = false) {
     for (int l = 0; l < h->cfg.n_layer; ++l) {
-        t2s_launch_attn<WT>(h, s, l, xsrc, st);
+        t2s_launch_attn<WT>(h, s, l, xsrc, st, fused_token);
         t2s_launch_ffn<WT>(h, s, l, st);
     }
     HIPCHK(hipGetLastError());
@@ -405,7 +414,12 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
 }
 
 template <typename WT>
-int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
+int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st, bool fused_token = false) {
+    // up to 16 sequences with greedy / host-chosen tokens: layer 0's attention kernel does the token kernel's work
+    if (fused_token && s.batch <= 16 && !(sizeof(WT) == 2 && s.batch >= h->batched_min && s.max_kv <= 1024)) {
+        if (int rc = t2s_layers<WT>(h, s, h->xcur, st, true)) return rc;
+        return t2s_logits<WT>(h, s, 1, nullptr, 0, s.batch, h->cfg.vocab, 1, st);
+    }
     if (int rc = t2s_token(h, s, 1, st)) return rc;
     if constexpr (sizeof(WT) == 2) {
         if (s.batch >= h->batched_min && s.max_kv <= 1024) {
@@ -590,6 +604,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
     (void)hipDeviceSynchronize();
     for (auto& kv : h->bound) {
         if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
+        if (kv.second.graph_ft) (void)hipGraphExecDestroy(kv.second.graph_ft);
         t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
@@ -653,6 +668,7 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     if (int rc = t2s_ensure_scratch(h, st->batch)) return rc;
     T2SBound& b = h->bound[st->batch];
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (b.graph_ft) { (void)hipGraphExecDestroy(b.graph_ft); b.graph_ft = nullptr; }
     b.st = *st;
     t2s_free_staging(b);
     const size_t B = (size_t)st->batch;
@@ -764,17 +780,17 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
     T2SBound* b = t2s_find(h, batch);
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     const bool bf = h->cfg.dtype == GSV_BF16;
-    const bool graph = (use_graph & 1) != 0;
+    const bool graph = (use_graph & 1) != 0, ft = (use_graph & GSV_STEP_FUSED_TOKEN) != 0;
     if (!graph) {
         for (int i = 0; i < n_steps; ++i)
-            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream)) : t2s_step<float>(h, b->st, S(stream))) return rc;
+            if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream), ft) : t2s_step<float>(h, b->st, S(stream), ft)) return rc;
         return GSV_OK;
     }
-    hipGraphExec_t& exec = b->graph;
+    hipGraphExec_t& exec = ft ? b->graph_ft : b->graph;
     if (!exec) {
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream) : t2s_step<float>(h, b->st, h->cap_stream);
+        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream, ft) : t2s_step<float>(h, b->st, h->cap_stream, ft);
         hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -801,6 +817,8 @@ int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
     h->dbg = (unsigned long long*)buf;
     for (auto& kv : h->bound)
         if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
+    for (auto& kv : h->bound)
+        if (kv.second.graph_ft) { (void)hipGraphExecDestroy(kv.second.graph_ft); kv.second.graph_ft = nullptr; }
     return GSV_OK;
 }
 

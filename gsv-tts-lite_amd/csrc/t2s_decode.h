@@ -279,6 +279,23 @@ template <typename WT, int K> struct Panel {
 
 // ---- attention kernel ----------------------------------------------------------------------
 
+// MODE 2 of the attention kernel (layer 0, greedy / host-chosen tokens): what t2s_token_kernel does with advance = 1 --
+// pending token -> pre_tokens / seen / eos_at / step, next input = embedding + position row -- as the kernel's prologue, so
+// the step has one launch less.  Every head block derives the token and its input row; block 0 keeps the books.
+struct StepTok {
+    const TokPart* tokpart;      // [B][kNP]
+    const int64_t* tok_override; // ctl[0] == 1
+    const int32_t* ctl;
+    const int64_t* x_len;
+    int64_t* pre_tokens;         // [B][T+1]
+    uint8_t* seen;               // [B][V]
+    int32_t* step;
+    int32_t* eos_at;
+    const float* emb;            // [V][512]
+    const float* pe;             // [n_pos][512]
+    int V, eos, n_pos;
+};
+
 template <typename WT>
 struct AttnArgs {
     // layer input: MODE 0 -> xdirect[B][512]; MODE 1 -> LN2(sum_j zpart + b2 + x1) of the previous layer
@@ -298,6 +315,7 @@ struct AttnArgs {
     int T;
     float* ypart;        // [B][16][512]
     unsigned long long* dbg;
+    StepTok tk;          // MODE 2 only
 };
 
 constexpr int kAttnLdsFloats = kD + 96 + 32 + 2 * kNW + kNW * 32 + 2 * kNW + kNW * kD;
@@ -336,14 +354,22 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // ---- issue everything whose address is known now, in consumption order
     PartialSum<kNJ> ps;
     float xd = 0.f;
+    TokPart tp; tp.v = -INFINITY; tp.idx = 0x7fffffff;
+    int ctl0 = 0, ctl2 = 0;
+    int64_t ovr = 0, xl64 = 0;
     if constexpr (MODE == 0) {
         if (owner) xd = a.xdirect[(size_t)b * kD + tid];
+    } else if constexpr (MODE == 2) {
+        tp = a.tk.tokpart[(size_t)b * kNP + min(lane, kNP - 1)];
+        ctl0 = a.tk.ctl[0]; ctl2 = a.tk.ctl[2];
+        ovr = a.tk.tok_override[b];
+        xl64 = a.tk.x_len[b];
     } else {
         ps.issue(a.zpart + (size_t)b * kNJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
     }
     // partials first: a CU serves its waves' loads in issue order and waves start staggered, so
     // without this rendezvous the last wave's partial rows queue behind the first waves' weights
-    if constexpr (MODE != 0) __builtin_amdgcn_s_barrier();
+    if constexpr (MODE == 1) __builtin_amdgcn_s_barrier();
     asm volatile("" : : : "memory");
     const WT* wp = a.wqkv + ((size_t)h * 96 + wid * RW) * kD;
     raw16 wq[RW][CPR];
@@ -364,6 +390,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // chain, so no add can be scheduled above it, while the memory clobber keeps every load above
     // it.  It only needs the FIRST-issued load to have landed.
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
+    else if constexpr (MODE == 2) asm volatile("" : "+v"(tp.v) : : "memory");
     else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
     stamp(a.dbg, 1);
 
@@ -371,6 +398,27 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     float v;
     if constexpr (MODE == 0) {
         v = xd;
+    } else if constexpr (MODE == 2) {
+        // the pending token: arg-max over the logits kernel's kNP partials (lowest index on ties), or the host's choice
+        float bv = lane < kNP ? tp.v : -INFINITY;
+        int tok = lane < kNP ? tp.idx : 0x7fffffff;
+        argmax_step<32>(bv, tok); argmax_step<16>(bv, tok); argmax_step<8>(bv, tok);
+        argmax_step<4>(bv, tok); argmax_step<2>(bv, tok); argmax_step<1>(bv, tok);
+        if (ctl0 != 0) tok = (int)ovr;
+        if (tok < 0 || tok >= a.tk.V) tok = 0;
+        const int64_t n64 = a.kv_len[b];
+        int64_t pos = n64 - xl64;
+        if (pos < 0) pos += a.tk.n_pos;  // torch negative indexing of the PE table (idle slots only)
+        if (pos < 0) pos = 0;
+        if (pos >= a.tk.n_pos) pos = a.tk.n_pos - 1;
+        v = owner ? a.tk.emb[(size_t)tok * kD + tid] * 1.0f + a.tk.pe[(size_t)pos * kD + tid] : 0.f;
+        if (h == 0 && tid == 0) {
+            if (n64 >= 0 && n64 <= a.T) a.tk.pre_tokens[(size_t)b * (a.T + 1) + n64] = tok;
+            if (ctl2 != 0 && n64 >= 0) a.tk.seen[(size_t)b * a.tk.V + tok] = 1;
+            const int stp = a.tk.step[b];
+            if (tok == a.tk.eos && a.tk.eos_at[b] < 0) a.tk.eos_at[b] = stp;
+            a.tk.step[b] = stp + 1;
+        }
     } else {
         ps.park(stage);
         __syncthreads();

@@ -92,6 +92,7 @@ class Text2SemanticDecoder:
         self.cuda_graph_buckets = {}
         self.refill_group = int(os.environ.get("GSV_REFILL_GROUP", "2"))   # staged refill: requests a prompt pass waits for (at most one window)
         self.use_graph = True
+        self.fuse_token_step = os.environ.get("GSV_FUSE_TOKEN", "1") != "0"  # greedy / host-sampled steps: layer 0's attention kernel does the token kernel's work (<= 16 sequences)
         self._eos_pipe = None
         self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
         self._weights = None
@@ -253,7 +254,9 @@ class Text2SemanticDecoder:
         return self._rt[batch]["hidden"]
 
     def _decode(self, batch, n):
-        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, 1 if self.use_graph else 0, N.current_stream_ptr(self.device)))
+        # bit 0: hipGraph replay; bit 1 (GSV_STEP_FUSED_TOKEN): the control block last written says "no device sampling"
+        flags = (1 if self.use_graph else 0) | (2 if self.fuse_token_step and self._rt[batch].get("fused_ok", False) else 0)
+        N.check(N.lib().gsv_t2s_decode(self._h, batch, n, flags, N.current_stream_ptr(self.device)))
 
     def _flush(self, batch):
         N.check(N.lib().gsv_t2s_flush(self._h, batch, N.current_stream_ptr(self.device)))
@@ -263,6 +266,7 @@ class Text2SemanticDecoder:
         """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling; suppress_first: the
         prefill's sample never takes 280 / 486 / EOS whatever suppress_steps is (infer / infer_stream, t2s_model.py:415-416)"""
         lo, hi = int(seed) & 0x7fffffff, (int(seed) >> 31) & 0x7fffffff
+        rt["fused_ok"] = int(mode) != 2
         rt["ctl"].copy_(torch.tensor([int(mode), int(suppress_steps), int(rep_enabled), 0, int(top_k or 0), lo, hi,
                                       int(bool(suppress_first))], dtype=torch.int32))
         rt["fctl"].copy_(torch.tensor([float(rep), float(temperature), float(1.0 if top_p is None else top_p), 0.0],

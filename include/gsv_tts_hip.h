@@ -148,9 +148,14 @@ int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
  * take the pending token (greedy argmax of the penalised logits, or tok_override), record it in
  * pre_tokens[b][kv_len[b]], build emb + alpha*pe[kv_len - x_len], run the layers, bump kv_len,
  * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
- * `use_graph` != 0: replay the step from a hipGraph captured on first use (one per batch size).
+ * `use_graph` is a bit set: GSV_STEP_GRAPH replays the step from a hipGraph captured on first use (one per batch size and
+ * flag combination); GSV_STEP_FUSED_TOKEN is the caller's promise that ctl[0] is 0 or 1 (greedy or tok_override, i.e. no
+ * device sampling) for these steps -- up to 16 sequences the first layer's attention kernel then does the token kernel's
+ * work itself (one launch less per step; same tokens, same state).
  * From a tuned batch size on (bf16 / fp8 handles) the step is the batched chain of csrc/t2s_batch.h: weights
  * streamed once per step through MFMA GEMMs instead of once per sequence. */
+#define GSV_STEP_GRAPH 1
+#define GSV_STEP_FUSED_TOKEN 2
 int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stream);
 /* Batch size from which gsv_t2s_decode runs the batched chain (INT_MAX on fp32 handles: never).  Tests mirror the
  * choice in the oracle, whose reduced-precision modes round the operands each path rounds. */

@@ -565,3 +565,33 @@ def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_
         op, oi = o.infer_batched([r[0] for r in rs], [r[1] for r in rs], [r[2] for r in rs], top_k=1)
         for i, p in zip(oi.tolist(), op):
             assert np.array_equal(ref[int(i)], p)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
+    """GSV_STEP_FUSED_TOKEN: with greedy / host-chosen tokens the first layer's attention kernel derives the pending token,
+    its embedding + position row and keeps the books (pre_tokens, seen, eos_at, step) itself.  Same tokens and the same
+    state as the step that starts with t2s_token_kernel: single sequence with repetition penalty and suppression
+    (infer), 4 slots with refills (infer_batched), graph replay and eager launches."""
+    cfg = synth.gpt_config(n_layer=4)
+    w = synth.gpt_weights(cfg, seed=41, eos_gain=2.0)
+    m = _model(cfg, w, [(1, 200), (4, 200)], dtype, dev)
+    rs = [synth.synth_request(500 + i, 6, 10 + 3 * i, 12 + 5 * i, seed=41, bert="random") for i in range(9)]
+    X, Y, Bt = [_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs]
+    res = {}
+    for graph in (True, False):
+        for fused in (False, True):
+            m.use_graph, m.fuse_token_step = graph, fused
+            one = m.infer(X[0][None], Y[0][None], Bt[0][None], top_k=1, repetition_penalty=1.35).cpu().numpy()
+            st = {k: m._rt[1][k].clone() for k in ("pre_tokens", "seen", "step", "eos_at", "kv_len")}
+            pred, idx = m.infer_batched(X, Y, Bt, top_k=1)
+            res[(graph, fused)] = (one, st, {int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)})
+    m.use_graph, m.fuse_token_step = True, True
+    ref = res[(True, False)]
+    assert ref[0].size > 3
+    for key, (one, st, many) in res.items():
+        assert np.array_equal(one, ref[0]), key
+        for k in st:
+            assert torch.equal(st[k], ref[1][k]), (key, k)
+        for i in range(len(rs)):
+            assert np.array_equal(many[i], ref[2][i]), (key, i)
