@@ -237,19 +237,21 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
     a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
     a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart; a.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
-    if (B > 16) {   // two sequences per block: one round of 1024-thread blocks up to 32 sequences (t2s_decode_multi.h)
-        const size_t ml = sizeof(float) * attn_multi_lds_floats<2>();
-        if (l == 0) hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 0, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
-        else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
-        return;
-    }
     if (l == 0 && fused_token) {
         StepTok& k = a.tk;
         k.tokpart = h->tokpart; k.tok_override = s.tok_override; k.ctl = s.ctl; k.x_len = s.x_len; k.pre_tokens = s.pre_tokens;
         k.seen = s.seen; k.step = s.step; k.eos_at = s.eos_at; k.emb = h->emb_audio; k.pe = h->pe_audio;
         k.V = h->cfg.vocab; k.eos = h->cfg.eos; k.n_pos = h->cfg.n_pos;
-        hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
-    } else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
+    }
+    if (B > 16) {   // two sequences per block: one round of 1024-thread blocks up to 32 sequences (t2s_decode_multi.h)
+        const size_t ml = sizeof(float) * attn_multi_lds_floats<2>();
+        if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 2, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
+        else if (l == 0) hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 0, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
+        else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
+        return;
+    }
+    if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
+    else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
 
@@ -271,6 +273,7 @@ int t2s_multi_lds_attr() {
     const int la = (int)(sizeof(float) * attn_multi_lds_floats<2>());
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
+    HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<2>())));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<4>())));
     return GSV_OK;
@@ -415,8 +418,8 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
 
 template <typename WT>
 int t2s_step(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st, bool fused_token = false) {
-    // up to 16 sequences with greedy / host-chosen tokens: layer 0's attention kernel does the token kernel's work
-    if (fused_token && s.batch <= 16 && !(sizeof(WT) == 2 && s.batch >= h->batched_min && s.max_kv <= 1024)) {
+    // the 2-launches-per-layer kernels with greedy / host-chosen tokens: layer 0's attention kernel does the token kernel's work
+    if (fused_token && !(sizeof(WT) == 2 && s.batch >= h->batched_min && s.max_kv <= 1024)) {
         if (int rc = t2s_layers<WT>(h, s, h->xcur, st, true)) return rc;
         return t2s_logits<WT>(h, s, 1, nullptr, 0, s.batch, h->cfg.vocab, 1, st);
     }

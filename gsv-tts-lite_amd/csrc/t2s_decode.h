@@ -295,6 +295,39 @@ struct StepTok {
     const float* pe;             // [n_pos][512]
     int V, eos, n_pos;
 };
+struct StepTokLoads { TokPart tp; int ctl0, ctl2; int64_t ovr, xl; };
+__device__ __forceinline__ StepTokLoads steptok_issue(const StepTok& k, int b, int lane) {
+    StepTokLoads L;
+    L.tp = k.tokpart[(size_t)b * kNP + min(lane, kNP - 1)];
+    L.ctl0 = k.ctl[0]; L.ctl2 = k.ctl[2];
+    L.ovr = k.tok_override[b];
+    L.xl = k.x_len[b];
+    return L;
+}
+// -> channel `tid` of sequence b's next input row (owner threads); `books`: this thread records the token (one per sequence)
+__device__ __forceinline__ float steptok_finish(const StepTok& k, const StepTokLoads& L, int b, int lane, int tid, bool owner, int64_t n64,
+                                                int T, bool books) {
+    // the pending token: arg-max over the logits kernel's kNP partials (lowest index on ties), or the host's choice
+    float bv = lane < kNP ? L.tp.v : -INFINITY;
+    int tok = lane < kNP ? L.tp.idx : 0x7fffffff;
+    argmax_step<32>(bv, tok); argmax_step<16>(bv, tok); argmax_step<8>(bv, tok);
+    argmax_step<4>(bv, tok); argmax_step<2>(bv, tok); argmax_step<1>(bv, tok);
+    if (L.ctl0 != 0) tok = (int)L.ovr;
+    if (tok < 0 || tok >= k.V) tok = 0;
+    int64_t pos = n64 - L.xl;
+    if (pos < 0) pos += k.n_pos;  // torch negative indexing of the PE table (idle slots only)
+    if (pos < 0) pos = 0;
+    if (pos >= k.n_pos) pos = k.n_pos - 1;
+    const float v = owner ? k.emb[(size_t)tok * kD + tid] * 1.0f + k.pe[(size_t)pos * kD + tid] : 0.f;
+    if (books) {
+        if (n64 >= 0 && n64 <= T) k.pre_tokens[(size_t)b * (T + 1) + n64] = tok;
+        if (L.ctl2 != 0 && n64 >= 0) k.seen[(size_t)b * k.V + tok] = 1;
+        const int stp = k.step[b];
+        if (tok == k.eos && k.eos_at[b] < 0) k.eos_at[b] = stp;
+        k.step[b] = stp + 1;
+    }
+    return v;
+}
 
 template <typename WT>
 struct AttnArgs {
@@ -354,16 +387,12 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // ---- issue everything whose address is known now, in consumption order
     PartialSum<kNJ> ps;
     float xd = 0.f;
-    TokPart tp; tp.v = -INFINITY; tp.idx = 0x7fffffff;
-    int ctl0 = 0, ctl2 = 0;
-    int64_t ovr = 0, xl64 = 0;
+    StepTokLoads tl;
+    tl.tp.v = 0.f;
     if constexpr (MODE == 0) {
         if (owner) xd = a.xdirect[(size_t)b * kD + tid];
     } else if constexpr (MODE == 2) {
-        tp = a.tk.tokpart[(size_t)b * kNP + min(lane, kNP - 1)];
-        ctl0 = a.tk.ctl[0]; ctl2 = a.tk.ctl[2];
-        ovr = a.tk.tok_override[b];
-        xl64 = a.tk.x_len[b];
+        tl = steptok_issue(a.tk, b, lane);
     } else {
         ps.issue(a.zpart + (size_t)b * kNJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
     }
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // chain, so no add can be scheduled above it, while the memory clobber keeps every load above
     // it.  It only needs the FIRST-issued load to have landed.
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
-    else if constexpr (MODE == 2) asm volatile("" : "+v"(tp.v) : : "memory");
+    else if constexpr (MODE == 2) asm volatile("" : "+v"(tl.tp.v) : : "memory");
     else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
     stamp(a.dbg, 1);
 
@@ -399,26 +428,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     if constexpr (MODE == 0) {
         v = xd;
     } else if constexpr (MODE == 2) {
-        // the pending token: arg-max over the logits kernel's kNP partials (lowest index on ties), or the host's choice
-        float bv = lane < kNP ? tp.v : -INFINITY;
-        int tok = lane < kNP ? tp.idx : 0x7fffffff;
-        argmax_step<32>(bv, tok); argmax_step<16>(bv, tok); argmax_step<8>(bv, tok);
-        argmax_step<4>(bv, tok); argmax_step<2>(bv, tok); argmax_step<1>(bv, tok);
-        if (ctl0 != 0) tok = (int)ovr;
-        if (tok < 0 || tok >= a.tk.V) tok = 0;
-        const int64_t n64 = a.kv_len[b];
-        int64_t pos = n64 - xl64;
-        if (pos < 0) pos += a.tk.n_pos;  // torch negative indexing of the PE table (idle slots only)
-        if (pos < 0) pos = 0;
-        if (pos >= a.tk.n_pos) pos = a.tk.n_pos - 1;
-        v = owner ? a.tk.emb[(size_t)tok * kD + tid] * 1.0f + a.tk.pe[(size_t)pos * kD + tid] : 0.f;
-        if (h == 0 && tid == 0) {
-            if (n64 >= 0 && n64 <= a.T) a.tk.pre_tokens[(size_t)b * (a.T + 1) + n64] = tok;
-            if (ctl2 != 0 && n64 >= 0) a.tk.seen[(size_t)b * a.tk.V + tok] = 1;
-            const int stp = a.tk.step[b];
-            if (tok == a.tk.eos && a.tk.eos_at[b] < 0) a.tk.eos_at[b] = stp;
-            a.tk.step[b] = stp + 1;
-        }
+        v = steptok_finish(a.tk, tl, b, lane, tid, owner, a.kv_len[b], a.T, h == 0 && tid == 0);
     } else {
         ps.park(stage);
         __syncthreads();

@@ -81,16 +81,20 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
     // ---- issue everything whose address is known now, in consumption order (t2s_decode.h, "latency discipline")
     PartialSum<kNJ> ps[R];
     float xd[R];
+    StepTokLoads tl[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         xd[r] = 0.f;
+        tl[r].tp.v = 0.f;
         if constexpr (MODE == 0) {
             if (owner) xd[r] = a.xdirect[(size_t)bs[r] * kD + tid];
+        } else if constexpr (MODE == 2) {
+            tl[r] = steptok_issue(a.tk, bs[r], lane);
         } else {
             ps[r].issue(a.zpart + (size_t)bs[r] * kNJ * kD, a.b2, a.x1 + (size_t)bs[r] * kD, a.ln2g, a.ln2b);
         }
     }
-    if constexpr (MODE != 0) __builtin_amdgcn_s_barrier();
+    if constexpr (MODE == 1) __builtin_amdgcn_s_barrier();
     asm volatile("" : : : "memory");
     const WT* wp = a.wqkv + ((size_t)h * 96 + wid * RW) * kD;
     raw16 wq[RW][CPR];
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
     const int oi = sumN_index<8>();
     const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd[0]) : : "memory");
+    else if constexpr (MODE == 2) asm volatile("" : "+v"(tl[0].tp.v) : : "memory");
     else asm volatile("" : "+v"(ps[0].p[0][0]) : : "memory");
 
     // ---- layer inputs of the R sequences
@@ -113,6 +118,10 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = xd[r];
+    } else if constexpr (MODE == 2) {   // the token kernel's work as this kernel's prologue (t2s_decode.h, StepTok)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            v[r] = steptok_finish(a.tk, tl[r], bs[r], lane, tid, owner, a.kv_len[bs[r]], a.T, h == 0 && tid == 0 && b0 + r < B);
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) ps[r].park(stage + (size_t)r * kNW * kD);

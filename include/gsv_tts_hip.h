@@ -150,8 +150,8 @@ int gsv_t2s_decode_hidden(gsv_t2s* h, int batch, const float* x, void* stream);
  * compute the next logits (suppression while step < ctl[1]; repetition penalty over `seen`).
  * `use_graph` is a bit set: GSV_STEP_GRAPH replays the step from a hipGraph captured on first use (one per batch size and
  * flag combination); GSV_STEP_FUSED_TOKEN is the caller's promise that ctl[0] is 0 or 1 (greedy or tok_override, i.e. no
- * device sampling) for these steps -- up to 16 sequences the first layer's attention kernel then does the token kernel's
- * work itself (one launch less per step; same tokens, same state).
+ * device sampling) for these steps -- on the two-launches-per-layer path (below the batched chain's size) the first layer's
+ * attention kernel then does the token kernel's work itself (one launch less per step; same tokens, same state).
  * From a tuned batch size on (bf16 / fp8 handles) the step is the batched chain of csrc/t2s_batch.h: weights
  * streamed once per step through MFMA GEMMs instead of once per sequence. */
 #define GSV_STEP_GRAPH 1

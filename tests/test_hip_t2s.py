@@ -572,11 +572,12 @@ def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
     """GSV_STEP_FUSED_TOKEN: with greedy / host-chosen tokens the first layer's attention kernel derives the pending token,
     its embedding + position row and keeps the books (pre_tokens, seen, eos_at, step) itself.  Same tokens and the same
     state as the step that starts with t2s_token_kernel: single sequence with repetition penalty and suppression
-    (infer), 4 slots with refills (infer_batched), graph replay and eager launches."""
+    (infer), 4 slots (one sequence per block) and 19 slots (two per block, the odd last block half empty) with refills
+    (infer_batched), graph replay and eager launches."""
     cfg = synth.gpt_config(n_layer=4)
     w = synth.gpt_weights(cfg, seed=41, eos_gain=2.0)
-    m = _model(cfg, w, [(1, 200), (4, 200)], dtype, dev)
-    rs = [synth.synth_request(500 + i, 6, 10 + 3 * i, 12 + 5 * i, seed=41, bert="random") for i in range(9)]
+    m = _model(cfg, w, [(1, 200), (4, 200), (19, 200)], dtype, dev)
+    rs = [synth.synth_request(500 + i, 6, 10 + (3 * i) % 40, 12 + (5 * i) % 60, seed=41, bert="random") for i in range(45)]
     X, Y, Bt = [_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs]
     res = {}
     for graph in (True, False):
@@ -584,8 +585,11 @@ def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
             m.use_graph, m.fuse_token_step = graph, fused
             one = m.infer(X[0][None], Y[0][None], Bt[0][None], top_k=1, repetition_penalty=1.35).cpu().numpy()
             st = {k: m._rt[1][k].clone() for k in ("pre_tokens", "seen", "step", "eos_at", "kv_len")}
-            pred, idx = m.infer_batched(X, Y, Bt, top_k=1)
-            res[(graph, fused)] = (one, st, {int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)})
+            many = {}
+            for slots, n in ((4, 9), (19, 45)):
+                pred, idx = m.infer_batched(X[:n], Y[:n], Bt[:n], top_k=1, slots=slots)
+                many.update({(slots, int(i)): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)})
+            res[(graph, fused)] = (one, st, many)
     m.use_graph, m.fuse_token_step = True, True
     ref = res[(True, False)]
     assert ref[0].size > 3
@@ -593,5 +597,6 @@ def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
         assert np.array_equal(one, ref[0]), key
         for k in st:
             assert torch.equal(st[k], ref[1][k]), (key, k)
-        for i in range(len(rs)):
+        assert set(many) == set(ref[2]) and len(many) == 9 + 45
+        for i in many:
             assert np.array_equal(many[i], ref[2][i]), (key, i)
