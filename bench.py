@@ -209,6 +209,9 @@ def _profile_traffic(out, a):
                 k["traffic"] = tr[k["kernel"]]
         if "kernel" in out["roofline"]:
             out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"])
+            out["roofline"]["traffic_source"] = ("profiles/traffic.json: per-launch mean of two rocprofv3 --pmc passes (FETCH_SIZE x2 per the "
+                                                 "micro-architecture guide, WRITE_SIZE) over this command with --steps 2 --no-extras, "
+                                                 "tools/sweep.sh of this round; hardware counters cannot be read from inside the process")
         if a.version == "v2Pro" and a.dtype == "bf16" and "roofline_vocoder" in out:
             out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
     except Exception:

@@ -3,7 +3,11 @@
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); what = sys.argv[2] if len(sys.argv) > 2 else "voc"
 rows = list(db.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x from kernels order by start"))
-if what == "voc":
+if what == "vocpass":   # tools/voc_time.py: passes back to back, each starts with two cf_to_cl launches; take the 10th (T = 500)
+    starts = [i for i, r in enumerate(rows) if 'cf_to_cl' in r[0]][0::2]
+    rows = rows[:starts[11]]
+    i0 = starts[10]; stop = lambda n: False
+elif what == "voc":
     idx = [i for i, r in enumerate(rows) if 'cf_to_cl' in r[0]]
     i0 = idx[-2]; stop = lambda n: 't2s_' in n
 else:

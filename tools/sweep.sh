@@ -1,0 +1,40 @@
+#!/bin/bash
+# Round-end measurement sweep on one MI355X (run on the GPU box through tools/gpu.sh): writes everything under gpurun_out/sweep/.
+# Copy what is to be kept into profiles/ afterwards.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/sweep; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run() { echo "== $*" >&2; "$@"; }
+# 1. default bench line (configs[1]) and its rocprofv3 summary
+run timeout 900 python $R/bench.py > $O/bench_line.json 2> $O/bench_line.log
+rm -rf /tmp/p1; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/prof_bench.log
+f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/rocprofv3_kernel_stats.csv
+# 2. HBM / fabric traffic: two PMC passes (counters only, no tracing beyond kernel dispatch)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pm_$c; run timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$c.log
+done
+ff=$(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+[ -n "$ff" ] && [ -n "$fw" ] && python $R/tools/pmc_traffic.py "$ff" "$fw" $O/traffic.json > $O/traffic_table.txt 2>&1
+# 3. continuous batching lines
+run timeout 900 python $R/bench.py --workload cb --version v2ProPlus > $O/cb_configs2.json 2> $O/cb_configs2.log
+run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --sync-refill --no-cpu-baseline > $O/cb_configs2_sync_refill.json 2> /dev/null
+run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32.json 2> /dev/null
+run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --no-cpu-baseline > $O/cb_bf16_bs64.json 2> /dev/null
+run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --dtype fp8 --no-cpu-baseline > $O/cb_fp8_bs64.json 2> /dev/null
+run timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $R/bench.py --gpus 2 --workload cb --share-gpu --dist-backend gloo --steps 1 --warmup 1 --requests 64 --no-cpu-baseline > $O/cb_2ranks_shared_gpu_gloo.json 2> $O/cb_2ranks.log
+rm -rf /tmp/p2; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python $R/bench.py --workload cb --version v2ProPlus --steps 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+f=$(find /tmp/p2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/rocprofv3_kernel_stats_cb_configs2.csv
+# 4. raw step times
+( for b in 1 4 8 16 17 24 32 33 40 64 128 256; do timeout 300 python $R/tools/step_time.py $b bf16 | grep step; done
+  for b in 64 256; do timeout 300 python $R/tools/step_time.py $b fp8 | grep step; done
+  timeout 300 python $R/tools/step_time.py 1 fp32 | grep step ) > $O/step_time.txt 2>&1
+# 5. vocoder: pass times and per-kernel timelines
+timeout 600 python $R/tools/voc_time.py 2>&1 | grep "T=" > $O/voc_time.txt
+for v in v2Pro v2ProPlus; do
+  rm -rf /tmp/pv_$v; timeout 600 rocprofv3 --kernel-trace -d /tmp/pv_$v -- python $R/tools/voc_time.py $v > /dev/null 2>&1
+  db=$(find /tmp/pv_$v -name "*.db" | head -1)
+  [ -n "$db" ] && python $R/tools/prof_timeline.py "$db" vocpass > $O/vocoder_timeline_$v.txt 2>&1
+done
+timeout 300 python $R/tools/sample_speed.py 2>&1 | grep token > $O/sample_speed.txt
+ls -la $O >&2
