@@ -11,8 +11,8 @@ m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1))
 lens = synth.mixed_lengths(B)
 rs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
 X = [torch.from_numpy(r[0]).to(dev) for r in rs]; Y = [torch.from_numpy(r[1]).to(dev) for r in rs]; Bt = [torch.from_numpy(r[2]).to(dev) for r in rs]
-m._set_ctl(m._rt[B], 0, 0, False, 1.0)
 with torch.inference_mode():
+    m._set_ctl(m._rt[B], 0, 0, False, 1.0)
     for it in range(6):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         xy, xl, yl, _, _ = m.embed_prompt(X, Y, Bt)
