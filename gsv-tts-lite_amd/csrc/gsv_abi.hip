@@ -339,11 +339,20 @@ struct ChainBufs {
 };
 
 template <typename AttnFn>
-int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, AttnFn attn_launch, hipStream_t st) {
+int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, AttnFn attn_launch, hipStream_t st, bool prompt = false) {
     const int rtiles = cdiv(M, 32);
     const unsigned skip = h->dbg_skip;
-    auto run = [&](auto kern, int nthreads, const BGemmArgs& ba) {
-        hipLaunchKernelGGL(kern, dim3(rtiles, ba.mtiles), dim3(nthreads), 0, st, ba);
+    // A prompt pass re-reads its X tile once per 32-column tile at 32 x 32 output per block (9 056 rows: 870 MB per QKV
+    // launch), so there a block walks 2 / 4 / 8 column tiles with its X rows -- and their LayerNorm -- in registers.  Measured
+    // prompt pass, ms, blocks of 1 / 2 / 4 / 8 column tiles: 241 rows 1.18 / 1.13 / 1.41 / 2.00; 980 rows 2.00 / 1.60 / 1.64 /
+    // 2.12; 1 968 rows 3.19 / 2.43 / 2.10 / 2.39; 4 000 rows 5.91 / 4.37 / 3.51 / 3.31; 9 056 rows 12.65 / - / - / 7.10.
+    // The decode step (one row per sequence) keeps one tile per block: it lives on launch latency, not on bytes.
+    static const int force_cpb = getenv("GSV_CHAIN_CPB") ? atoi(getenv("GSV_CHAIN_CPB")) : 0;   // scan aid
+    int cpb = 1;
+    if (prompt) cpb = force_cpb > 0 ? force_cpb : (rtiles < 40 ? 2 : (rtiles < 100 ? 4 : 8));
+    auto run = [&](auto kern, int nthreads, BGemmArgs ba) {
+        ba.cpb = cpb;
+        hipLaunchKernelGGL(kern, dim3(rtiles, cdiv(ba.mtiles, cpb)), dim3(nthreads), 0, st, ba);
     };
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
@@ -470,7 +479,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
         };
-        if (int rc = t2s_gemm_chain(h, M, xy, c, false, attn_launch, st)) return rc;
+        if (int rc = t2s_gemm_chain(h, M, xy, c, false, attn_launch, st, true)) return rc;
         const T2SLayer& LL = h->layers.back();
         hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const float*)c.y2, (const float*)LL.ln2g, (const float*)LL.ln2b, xy, M);
         HIPCHK(hipGetLastError());

@@ -46,6 +46,8 @@ struct BGemmArgs {
     int ldres, relu;
     void* Y;              // [M][ldy]: fp32, bf16 or fp8 (saturating e4m3 at unit scale)
     int ldy;
+    int cpb;              // column tiles per block (grid.y = ceil(mtiles / cpb)): 1 for the decode step; a prompt pass of many
+                          // rows walks 8 column tiles with its X rows (and their LayerNorm) in registers instead of re-reading them
 };
 
 __device__ __forceinline__ float clamp_e4m3(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
@@ -77,45 +79,51 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
     __shared__ float stat[PRO == PRO_LN ? NW * 32 * 2 : 2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
-    const int rt = blockIdx.x, mt = blockIdx.y;
+    const int rt = blockIdx.x;
+    const int cpb = a.cpb > 1 ? a.cpb : 1;
+    const int mt0 = blockIdx.y * cpb;
+    int mt = mt0;
     const int row = rt * 32 + j;
     const int rowc = min(row, a.M - 1);
     constexpr int KS = NW * 8;                              // k-steps of the whole contraction
 
     // ---- everything in flight at once: weight fragments, then the X rows
     u32x4 wf[F8 ? 4 : 8];
-    if constexpr (F8) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            wf[p] = __builtin_bit_cast(u32x4, a.W[((size_t)mt * (KS / 2) + wid * 4 + p) * 64 + lane]);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            wf[s] = __builtin_bit_cast(u32x4, a.W[((size_t)mt * KS + wid * 8 + s) * 64 + lane]);
-    }
     // epilogue operands (bias, fp8 scale, residual) of the lanes that will write the tile: addresses are known now
     constexpr int NEP = NW == 4 ? 4 : 1;                     // f32x4 per writer lane
     const bool writer = NW == 4 ? wid == 0 : tid < 256;
     const int erow = NW == 4 ? row : rt * 32 + (tid >> 3);
-    const int ech = NW == 4 ? mt * 32 + 16 * hf : mt * 32 + (tid & 7) * 4;
     f32x4 e_bias[NEP], e_scale[NEP], e_res[NEP];
-#pragma unroll
-    for (int g = 0; g < NEP; ++g) { e_bias[g] = f32x4{0.f, 0.f, 0.f, 0.f}; e_scale[g] = f32x4{1.f, 1.f, 1.f, 1.f}; e_res[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (writer) {
-        if (a.bias) {
-#pragma unroll
-            for (int g = 0; g < NEP; ++g) e_bias[g] = *reinterpret_cast<const f32x4*>(a.bias + ech + 4 * g);
-        }
+    auto load_w = [&](int m) {
         if constexpr (F8) {
 #pragma unroll
-            for (int g = 0; g < NEP; ++g) e_scale[g] = *reinterpret_cast<const f32x4*>(a.wscale + ech + 4 * g);
-        }
-        if (a.res) {
-            const float* rp = a.res + (size_t)min(erow, a.M - 1) * a.ldres + ech;
+            for (int p = 0; p < 4; ++p)
+                wf[p] = __builtin_bit_cast(u32x4, a.W[((size_t)m * (KS / 2) + wid * 4 + p) * 64 + lane]);
+        } else {
 #pragma unroll
-            for (int g = 0; g < NEP; ++g) e_res[g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+            for (int s = 0; s < 8; ++s)
+                wf[s] = __builtin_bit_cast(u32x4, a.W[((size_t)m * KS + wid * 8 + s) * 64 + lane]);
         }
-    }
+        const int ech = NW == 4 ? m * 32 + 16 * hf : m * 32 + (tid & 7) * 4;
+#pragma unroll
+        for (int g = 0; g < NEP; ++g) { e_bias[g] = f32x4{0.f, 0.f, 0.f, 0.f}; e_scale[g] = f32x4{1.f, 1.f, 1.f, 1.f}; e_res[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (writer) {
+            if (a.bias) {
+#pragma unroll
+                for (int g = 0; g < NEP; ++g) e_bias[g] = *reinterpret_cast<const f32x4*>(a.bias + ech + 4 * g);
+            }
+            if constexpr (F8) {
+#pragma unroll
+                for (int g = 0; g < NEP; ++g) e_scale[g] = *reinterpret_cast<const f32x4*>(a.wscale + ech + 4 * g);
+            }
+            if (a.res) {
+                const float* rp = a.res + (size_t)min(erow, a.M - 1) * a.ldres + ech;
+#pragma unroll
+                for (int g = 0; g < NEP; ++g) e_res[g] = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+            }
+        }
+    };
+    load_w(mt);
     uint32_t xb[8][4];   // bf16: xb[g][0..3] = 8 bf16 of group g; fp8: xb[g][0..1] = 8 e4m3 of group g
     if constexpr (sizeof(XT) == 4) {
         const float* xp = reinterpret_cast<const float*>(a.X) + (size_t)rowc * a.ldx;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
                     lo[g][i] = (lo[g][i] - mean) * rs * g0[i] + b0[i];
                     hi[g][i] = (hi[g][i] - mean) * rs * g1[i] + b1[i];
                 }
-                if (mt == 0 && a.xout != nullptr && row < a.M) {
+                if (mt0 == 0 && a.xout != nullptr && row < a.M) {
                     *reinterpret_cast<f32x4*>(a.xout + (size_t)row * kD + c) = lo[g];
                     *reinterpret_cast<f32x4*>(a.xout + (size_t)row * kD + c + 4) = hi[g];
                 }
@@ -197,6 +205,8 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
         }
     }
 
+    for (int ct = 0; ct < cpb && mt < a.mtiles; ++ct, ++mt) {
+    if (ct > 0) load_w(mt);
     // all loads issued, THEN arithmetic: hipcc otherwise re-uses operand registers and interleaves the later loads
     // with the MFMAs (measured in the ISA: 8 of 16 loads up front), i.e. two exposed memory latencies instead of one
     asm volatile("" : "+v"(wf[0]) : : "memory");
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             Mma<bf16_t>::run(acc, wf[g], bv);
         }
     }
+    const bool more = ct + 1 < cpb && mt + 1 < a.mtiles;    // block-uniform
 
     // ---- the NW partial tiles meet in LDS, summed in wave order (bit-reproducible)
     const int chl = 16 * hf;                                 // register q = channel mt*32 + chl + q (packer's row permutation)
@@ -223,12 +234,12 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             for (int q = 0; q < 16; ++q) red[((wid - 1) * 16 + q) * 64 + lane] = acc[q];
         }
         __syncthreads();
-        if (wid > 0) return;
+        if (wid == 0) {
 #pragma unroll
         for (int w = 0; w < 3; ++w)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] += red[(w * 16 + q) * 64 + lane];
-        if (row >= a.M) return;
+        if (row < a.M) {
         const int ch = mt * 32 + chl;
         float v[16];
 #pragma unroll
@@ -263,6 +274,10 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             pack_fp8x8(v1, o2, o3);
             *reinterpret_cast<u32x4*>(yp) = u32x4{o0, o1, o2, o3};
         }
+        }   // row < M
+        }   // wave 0
+        if (!more) return;
+        __syncthreads();                                    // the next column tile's partials reuse `red`
     } else {
         // 16 waves: every wave parks its tile, then wave w sums register w over the 16 waves (16 LDS reads instead
         // of 240 by one wave), the tile is transposed through LDS and the first four waves write whole rows
@@ -276,10 +291,9 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
         __syncthreads();
         red[j * 33 + chl + wid] = r;                        // tile [32 rows][33]: register `wid` of lane (j, hf)
         __syncthreads();
-        if (tid >= 256) return;
         const int orow = tid >> 3, c4 = (tid & 7) * 4;
         const int grow = rt * 32 + orow;
-        if (grow >= a.M) return;
+        if (tid < 256 && grow < a.M) {
         const int ch = mt * 32 + c4;
         float v[4];
 #pragma unroll
@@ -292,7 +306,11 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
         }
         static_assert(NW != 16 || sizeof(OT) == 4, "the 16-wave form writes fp32 rows");
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.Y) + (size_t)grow * a.ldy + ch) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+        if (!more) return;
+        __syncthreads();
     }
+    }   // column tiles
 }
 
 // ---- attention of the batched step ------------------------------------------------------------------
