@@ -567,6 +567,26 @@ def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_
             assert np.array_equal(ref[int(i)], p)
 
 
+def test_staged_refill_with_device_sampling_and_callbacks(dev):
+    """the staged slot loop under the production sampling parameters (device sampler, noise keyed by slot: which slot a
+    request gets is decided when the slot is parked, so a run is as reproducible as the reference-order one) and with an
+    on_finish callback (the engine's overlapped vocoder hook): every request served once, callback per request, tokens in range"""
+    cfg = synth.gpt_config(n_layer=4)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=9, eos_gain=3.0), [(6, 200)], torch.bfloat16, dev)
+    reqs = [synth.synth_request(i, 8, 10 + i % 7, 15 + i % 9, seed=9) for i in range(40)]
+    X, Y, Bt = [_T(r[0], dev) for r in reqs], [_T(r[1], dev) for r in reqs], [_T(r[2], dev) for r in reqs]
+    seen = []
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    pred, idx = m.infer_batched(X, Y, Bt, top_k=15, top_p=0.9, temperature=0.8, generator=g, async_refill=True,
+                                on_finish=lambda i, t: seen.append((int(i), int(t.numel()))))
+    assert sorted(idx.tolist()) == list(range(40)) and sorted(i for i, _ in seen) == list(range(40))
+    assert [n for _, n in seen] == [int(p.numel()) for p in pred]
+    for p in pred:
+        a = p.cpu().numpy()
+        assert ((a >= 0) & (a < 1024)).all()
+    assert max(int(p.numel()) for p in pred) > 3 and m.last_stats["refills"] == 34
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
     """GSV_STEP_FUSED_TOKEN: with greedy / host-chosen tokens the first layer's attention kernel derives the pending token,
