@@ -567,6 +567,28 @@ def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_
             assert np.array_equal(ref[int(i)], p)
 
 
+def test_staged_refill_cuts_a_full_cache_like_the_reference_order_loop(dev):
+    """requests that never sample EOS end when kv + check_interval reaches the cache size at a 5-step window boundary
+    (t2s_model.py:655-657); where that boundary falls depends on the window a slot was filled at, so the staged loop may cut
+    up to one window earlier or later than the reference-order loop -- the tokens themselves are the same sequence."""
+    cfg = synth.gpt_config(n_layer=3)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=13, eos_gain=0.0), [(4, 96)], torch.float32, dev)   # EOS (almost) never wins
+    reqs = [synth.synth_request(900 + i, 5, 8 + 2 * i, 10 + 3 * i, seed=13, bert="random") for i in range(11)]
+    X, Y, Bt = [_T(r[0], dev) for r in reqs], [_T(r[1], dev) for r in reqs], [_T(r[2], dev) for r in reqs]
+    out = {}
+    for mode in (False, True):
+        pred, idx = m.infer_batched(X, Y, Bt, top_k=1, async_refill=mode)
+        assert sorted(idx.tolist()) == list(range(11))
+        out[mode] = {int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)}
+    for i in range(11):
+        a, b = out[False][i], out[True][i]
+        L = len(reqs[i][0]) + len(reqs[i][1])
+        n = min(len(a), len(b))
+        assert n > 0 and np.array_equal(a[:n], b[:n]), i
+        assert abs(len(a) - len(b)) <= 5 and L + max(len(a), len(b)) < 96, (i, len(a), len(b), L)
+        assert L + min(len(a), len(b)) >= 96 - 12, (i, len(a), len(b), L)      # both ran the cache (nearly) full
+
+
 def test_staged_refill_with_device_sampling_and_callbacks(dev):
     """the staged slot loop under the production sampling parameters (device sampler, noise keyed by slot: which slot a
     request gets is decided when the slot is parked, so a run is as reproducible as the reference-order one) and with an
