@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--requests", type=int, default=CB_REQUESTS_PER_GPU, help="cb: requests per GPU per step")
     ap.add_argument("--sync-refill", action="store_true", help="cb: refill finished slots as the reference does, every slot waiting for "
                     "the prompt pass (default: the prompt pass runs on a side stream and the slot joins when it is done)")
+    ap.add_argument("--lpt-budget", action="store_true", help="cb: order the queue by prompt length + the request's token budget (longest "
+                    "first) instead of by text length alone; the default workload's budgets are independent of the text on purpose")
     ap.add_argument("--overlap", action="store_true", help="cb: vocoder batches on a side stream while the slot loop decodes (measured "
                     "+1 .. +4 %% end to end: the two share the chip) instead of after it in TTS.infer_batched's length-balanced order")
     ap.add_argument("--no-graph", action="store_true")
@@ -501,6 +503,7 @@ def run_cb(a):
     ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
     bs = [torch.from_numpy(r[2]).to(dev) for r in reqs]
     acc = {"tok": 0, "frames": 0, "t_ar": 0.0, "t_voc": 0.0, "steps": 0, "kv_rows": 0, "mine": 0}
+    costs = [int(x.shape[0]) + int(y.shape[0]) + int(n) for x, y, n in zip(xs, ys, new_tok)] if a.lpt_budget else None
 
     def vocode(items):
         """flow + Generator over this rank's finished utterances, time-concatenated in batches of 10 with per-frame ge,
@@ -531,11 +534,11 @@ def run_cb(a):
     def step(i, timed_idx):
         torch.cuda.synchronize(dev); s0 = time.perf_counter()
         if (not a.overlap):
-            pred, idx = eng.run_gpt(xs, ys, bs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            pred, idx = eng.run_gpt(xs, ys, bs, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             torch.cuda.synchronize(dev); s1 = time.perf_counter()
             frames = vocode(list(zip(idx.tolist(), pred)))
         else:
-            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             s1 = time.perf_counter()
             frames = int(sum(res.values()))
         torch.cuda.synchronize(dev); s2 = time.perf_counter()
@@ -565,6 +568,7 @@ def run_cb(a):
                    "requests_per_step": n_req, "gpt_cache": [(a.slots, 512), (a.slots, 1024)],
                    "refill": "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)" if a.sync_refill else
                              "staged: the prompt pass of a finished slot runs on a side stream, the slot joins at the next window after it",
+                   "queue_order": "longest first by prompt rows + token budget" if a.lpt_budget else "longest first by text length (the budgets are independent of it)",
                    "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
                               "overlapped with the slot loop on a side stream, batches of 10 in completion order",
                    "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "

@@ -19,6 +19,7 @@ ff=$(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(fi
 # 3. continuous batching lines
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus > $O/cb_configs2.json 2> $O/cb_configs2.log
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --sync-refill --no-cpu-baseline > $O/cb_configs2_sync_refill.json 2> /dev/null
+run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --lpt-budget --no-cpu-baseline > $O/cb_configs2_lpt_budget.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --no-cpu-baseline > $O/cb_bf16_bs64.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --dtype fp8 --no-cpu-baseline > $O/cb_fp8_bs64.json 2> /dev/null
