@@ -91,6 +91,24 @@ def test_world2_dynamic_dealing_and_ordered_gather():
     assert len(t1) > len(t0), "the 4x faster rank must have pulled more requests (dealing is on demand): %d vs %d" % (len(t1), len(t0))
 
 
+def test_world4_every_request_once_and_in_order():
+    """four ranks (the node has eight): the shared cursor deals every request exactly once, every rank ends with the full
+    list in input order, the slow rank 0 pulls the fewest"""
+    world, port = 4, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    steps = ret[0][4]
+    n = len(steps)
+    taken = [ret[r][0] for r in range(world)]
+    assert all(ret[r][3] for r in range(world))
+    assert sorted(sum(taken, [])) == list(range(n)) and sum(len(t) for t in taken) == n
+    for r in range(world):
+        for out in (ret[r][1], ret[r][2]):
+            assert [len(o) for o in out] == steps and all(all(v == i for v in o) for i, o in enumerate(out))
+    assert len(taken[0]) <= min(len(t) for t in taken[1:])
+
+
 def test_single_process_engine_is_the_plain_slot_loop():
     steps = [3, 1, 4, 1, 5, 9, 2, 6]
     xs = [torch.zeros(k + 2, dtype=torch.int64) for k in steps]
