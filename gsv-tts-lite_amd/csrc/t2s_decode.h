@@ -912,8 +912,13 @@ static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
     if (a.ctl[0] == 2 && tid < 64) {
         const float* lg = a.logits + (size_t)b * a.V;
         const uint32_t pos = (uint32_t)a.kv_len[b], stp = (uint32_t)a.step[b];
-        sampled = a.V <= 64 * 17 ? t2s_sample_wave<17>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp)
-                                 : t2s_sample_wave<32>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], (uint32_t)b, pos, stp);
+        // the noise stream of this sequence: tok_override[b] - 1 when the caller set one (> 0; continuous batching keys it
+        // by REQUEST, so what a request samples does not depend on the slot, the refill order or the rank it runs on),
+        // else the slot index
+        const int64_t sid = a.tok_override[b];
+        const uint32_t stream = sid > 0 ? (uint32_t)(sid - 1) : (uint32_t)b;
+        sampled = a.V <= 64 * 17 ? t2s_sample_wave<17>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], stream, pos, stp)
+                                 : t2s_sample_wave<32>(lg, a.V, a.fctl[1], a.fctl[2], a.ctl[4], (uint32_t)a.ctl[5], (uint32_t)a.ctl[6], stream, pos, stp);
     }
     if (tid == 0) {
         int tok;

@@ -18,9 +18,10 @@ slot loop over ITS slots, and the only shared thing is the head of the queue.
   * gather    per-utterance results (token ids, audio) are variable-length host objects: `all_gather_object`
               keyed by the GLOBAL request index (`semantic_orig_idx` semantics kept globally).
 
-Greedy decoding is placement-invariant (rows are independent through every kernel), so N ranks return exactly
-the tokens one rank returns (tests/test_engine_*.py).  Device sampling keys its noise by slot, so sampled runs are
-reproducible per (seed, world size), not across world sizes.
+Decoding is placement-invariant: rows are independent through every kernel, and device sampling draws a request's noise
+from the REQUEST's stream (t2s.py puts request index + 1 into tok_override, gsv_tts_hip.h), not from its slot's.  N ranks
+therefore return exactly the tokens one rank returns, greedy or sampled with the same generator seed
+(tests/test_hip_engine.py, tests/test_engine_gloo.py).
 """
 from __future__ import annotations
 

@@ -427,7 +427,7 @@ class Text2SemanticDecoder:
 
     @torch.inference_mode()
     def _infer_batched_staged(self, x, y, bert_feature, B, first, nxt, exhausted, first_len, check_interval, on_finish,
-                              max_new_tokens):
+                              max_new_tokens, stream_by_request=False):
         """The slot loop of t2s_model.py:555-734 with nothing on the decode steps' critical path but the steps:
 
           * a finished slot is PARKED (kv_len = -1: the step leaves its rows and state alone and attends over one row),
@@ -510,11 +510,12 @@ class Text2SemanticDecoder:
                 # copy blocks the host until its stream gets there -- it must not sit behind the wait on the steps
                 xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in rq], [y[c] for c in rq], [bert_feature[c] for c in rq])
                 sl = torch.tensor([i for i, _, _ in group], dtype=torch.int32, device=dev)
+                ids = torch.tensor([c + 1 for _, c, _ in group], dtype=torch.int64, device=dev)
                 side.wait_event(ev)
                 self.prefill_slots_staged(B, sl, xy1, xl1, yl1, side.cuda_stream)
                 done = torch.cuda.Event()
                 done.record(side)
-            inflight.append((group, sl, done, (xy1, xl1, yl1), window))
+            inflight.append((group, sl, done, (xy1, xl1, yl1, ids), window))
             self.last_stats["refills"] += len(group)
             self.last_stats["prefill_rows"] += len(group)
 
@@ -535,6 +536,9 @@ class Text2SemanticDecoder:
             main.wait_event(done)
             self.commit_slots(B, sl)
             sl.record_stream(main)      # allocated on the side stream's pool, read here by the steps' stream
+            if stream_by_request:       # device sampling: the joined slots draw from their requests' noise streams
+                rt["tok_override"].index_copy_(0, sl.long(), _keep[3])
+                _keep[3].record_stream(main)
             for i, _, n_new in group:
                 state[i], steps[i], start[i], joined[i] = LIVE, 0, n_new, window
             inflight.clear()
@@ -663,10 +667,13 @@ class Text2SemanticDecoder:
             raise ValueError("prompt longer than the largest KV bucket")
         self.prefill(batch_size, 0, xy, xl, yl)
         rows = torch.arange(batch_size, device=dev)
+        if mode == 2:       # device sampling: the noise stream of a slot is its REQUEST (placement-invariant samples)
+            rt["tok_override"].zero_()
+            rt["tok_override"][:actual] = torch.tensor([c + 1 for c in first], dtype=torch.int64, device=dev)
         if async_refill and mode != 1:      # host-sampled tokens need every refill's logits at once: reference order
             return self._infer_batched_staged(x, y, bert_feature, batch_size, first, nxt, exhausted,
                                               [int(a) + int(b) for a, b in zip(x_lens_h, y_lens_h)], check_interval,
-                                              on_finish, max_new_tokens)
+                                              on_finish, max_new_tokens, mode == 2)
 
         have_tok = False
 
@@ -773,6 +780,9 @@ class Text2SemanticDecoder:
                 xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in req], [y[c] for c in req], [bert_feature[c] for c in req])
                 self.prefill_slots(batch_size, [i for i, _ in refill], xy1, xl1, yl1)
                 self.last_stats["refills"] += len(refill)
+                if mode == 2:
+                    rt["tok_override"][torch.tensor([i for i, _ in refill], device=dev)] = \
+                        torch.tensor([c + 1 for _, c in refill], dtype=torch.int64, device=dev)
                 if not greedy:  # every refilled slot needs its own first sample, drawn in slot order (t2s_model.py:713-714)
                     for i, _ in refill:
                         rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]

@@ -657,11 +657,15 @@ class TTS:
                     phones2_all.append(ph2)
 
                 if eng is None:
+                    # staged refill: same tokens per request as the reference-order loop (greedy: rows are independent;
+                    # sampling: the noise stream is the request's), no stall of the other slots on a prompt pass
                     pred, orig_idx = t2s.infer_batched(ids, prompts, berts, top_k=top_k, top_p=top_p,
-                                                       temperature=temperature, repetition_penalty=repetition_penalty)
+                                                       temperature=temperature, repetition_penalty=repetition_penalty,
+                                                       async_refill=True)
                 else:   # this rank's share of the segment queue (engine.py): global indices come back
                     pred, orig_idx = eng.run_gpt(ids, prompts, berts, costs=[int(i.shape[0]) for i in ids], top_k=top_k, top_p=top_p,
-                                                 temperature=temperature, repetition_penalty=repetition_penalty)
+                                                 temperature=temperature, repetition_penalty=repetition_penalty,
+                                                 async_refill=True)
                 lengths = torch.tensor([len(p) for p in pred])
                 order = balance_order(lengths)                     # short/long interleave, TTS.py:705-716
                 m = len(order)

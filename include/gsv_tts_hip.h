@@ -84,7 +84,9 @@ typedef struct {
     int32_t* eos_at;        /* [B]   first step whose sample was EOS, else -1 */
     float* logits;          /* [B][vocab] last logits after suppression/penalty (host sampling) */
     float* hidden;          /* [B][hidden] last final hidden state (Bucket.graph_xy_dec) */
-    int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] == 1 */
+    int64_t* tok_override;  /* [B]   host-sampled tokens, consumed when ctl[0] == 1; with ctl[0] == 2 (device sampling) a value
+                               v > 0 makes v - 1 the sequence's noise stream instead of its slot index (key it by request
+                               and a request's samples do not depend on slot, refill order or rank) */
     int32_t* ctl;           /* [8]   {sample_mode, suppress_steps, rep_enabled, -, top_k, seed_lo, seed_hi,
                                suppress_first}; suppress_first != 0: the prefill's sample never takes 280 / 486 / EOS
                                (infer / infer_stream, t2s_model.py:415-416), independent of suppress_steps; sample_mode 0 = greedy argmax, 1 = tok_override (host sampling),

@@ -38,7 +38,7 @@ def _model(dev, dtype=torch.float32):
     return cfg, m
 
 
-def _worker(rank, world, port, ret, async_refill):
+def _worker(rank, world, port, ret, async_refill, sampled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -52,7 +52,11 @@ def _worker(rank, world, port, ret, async_refill):
     eng = engine.ContinuousBatchingEngine(m, slots=SLOTS, chunk=1)
     book = engine.SpeakerBook(dev)
     ge = book.sync("spk", [T(synth.synth_ge(0, 1024, SEED))] if rank == 0 else None)[0]
-    out = eng.run([T(r[0]) for r in rs], [T(r[1]) for r in rs], [T(r[2]) for r in rs], top_k=1, async_refill=async_refill)
+    kw = dict(top_k=1)
+    if sampled:
+        g = torch.Generator(device=dev); g.manual_seed(23)
+        kw = dict(top_k=15, top_p=0.9, temperature=0.8, generator=g)
+    out = eng.run([T(r[0]) for r in rs], [T(r[1]) for r in rs], [T(r[2]) for r in rs], async_refill=async_refill, **kw)
     ret[rank] = ([t.tolist() for t in out], list(eng.last_taken), float(ge.abs().sum().item()), book.broadcasts)
     dist.barrier()
     dist.destroy_process_group()
@@ -95,3 +99,34 @@ def test_two_ranks_sharing_one_gpu_equal_single_process_and_oracle(async_refill)
         else:
             assert out0[i] == single.tolist(), i
     assert capped <= N_REQ // 4, "too few EOS-terminated requests for the placement-invariance claim"
+
+
+def test_two_ranks_sample_what_one_process_samples():
+    """device sampling draws each request's noise from the request's own stream, so two ranks (staged refill, requests
+    pulled on demand) return exactly what ONE process with another slot count samples for the same generator seed"""
+    assert torch.cuda.is_available()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, True, True), nprocs=world, join=True)
+    out0, t0, _, _ = ret[0]
+    out1, t1, _, _ = ret[1]
+    assert out0 == out1 and t0 and t1
+    dev = torch.device("cuda:0")
+    _, m = _model(dev)
+    rs = _requests()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(23)
+    pred, idx = m.infer_batched([T(r[0]) for r in rs], [T(r[1]) for r in rs], [T(r[2]) for r in rs], top_k=15, top_p=0.9,
+                                temperature=0.8, generator=g)
+    single = {int(i): p.cpu().numpy().tolist() for i, p in zip(idx.tolist(), pred)}
+    capped = 0
+    for i, r in enumerate(rs):
+        if len(r[0]) + len(r[1]) + len(single[i]) + 8 >= CACHE[-1][1]:      # ended by capacity: cut within a window (see above)
+            capped += 1
+            n = min(len(single[i]), len(out0[i]))
+            assert out0[i][:n] == single[i][:n], i
+        else:
+            assert out0[i] == single[i], i
+    assert capped <= N_REQ // 4 and len({tuple(v) for v in single.values()}) > N_REQ // 2

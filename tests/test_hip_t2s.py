@@ -589,6 +589,25 @@ def test_staged_refill_cuts_a_full_cache_like_the_reference_order_loop(dev):
         assert L + min(len(a), len(b)) >= 96 - 12, (i, len(a), len(b), L)      # both ran the cache (nearly) full
 
 
+def test_device_sampling_is_keyed_by_request_not_by_slot(dev):
+    """continuous batching draws each request's noise from ITS stream (tok_override carries request index + 1 in device-
+    sampling mode): the sampled tokens of a request are the same with 4 or 6 slots, with the reference-order or the staged
+    refill -- i.e. independent of the slot, the refill order and (engine tests) the rank it lands on"""
+    cfg = synth.gpt_config(n_layer=4)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=9, eos_gain=3.0), [(4, 200), (6, 200)], torch.bfloat16, dev)
+    reqs = [synth.synth_request(i, 8, 10 + i % 7, 15 + i % 9, seed=9) for i in range(30)]
+    X, Y, Bt = [_T(r[0], dev) for r in reqs], [_T(r[1], dev) for r in reqs], [_T(r[2], dev) for r in reqs]
+    runs = []
+    for slots, mode in ((4, False), (6, False), (4, True), (6, True)):
+        g = torch.Generator(device=dev); g.manual_seed(11)
+        pred, idx = m.infer_batched(X, Y, Bt, top_k=15, top_p=0.9, temperature=0.8, generator=g, slots=slots, async_refill=mode)
+        runs.append({int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)})
+    assert max(len(v) for v in runs[0].values()) > 5 and len({tuple(v) for v in runs[0].values()}) > 20   # real sampling, not one answer
+    for r in runs[1:]:
+        for i in range(30):
+            assert np.array_equal(r[i], runs[0][i]), i
+
+
 def test_staged_refill_with_device_sampling_and_callbacks(dev):
     """the staged slot loop under the production sampling parameters (device sampler, noise keyed by slot: which slot a
     request gets is decided when the slot is parked, so a run is as reproducible as the reference-order one) and with an
