@@ -309,6 +309,8 @@ class Text2SemanticDecoder:
         self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p,
                       suppress_first=True)
         rt["seen"].zero_()
+        if mode == 2:
+            rt["tok_override"].zero_()      # noise stream = slot 0 (a batched run may have left a request's stream id here)
         if rep_on:
             rt["seen"][0, y[0].to(self.device)] = 1
         xy, xl, yl, _, _ = self.embed_prompt([x[0]], [y[0]], [bert_feature[0]])
@@ -386,6 +388,8 @@ class Text2SemanticDecoder:
             self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p,
                           suppress_first=True)
             rt["seen"].zero_()
+            if mode == 2:
+                rt["tok_override"].zero_()
             if rep_on:
                 rt["seen"][0, y[0].to(self.device)] = 1
             xy, xl, yl, _, _ = self.embed_prompt([x[0]], [y[0]], [bert_feature[0]])

@@ -606,6 +606,16 @@ def test_device_sampling_is_keyed_by_request_not_by_slot(dev):
     for r in runs[1:]:
         for i in range(30):
             assert np.array_equal(r[i], runs[0][i]), i
+    # a single-sequence run after a batched one draws from slot 0's stream again (the batched run's ids are cleared)
+    m2 = _model(cfg, synth.gpt_weights(cfg, seed=9, eos_gain=3.0), [(1, 200)], torch.bfloat16, dev)
+    outs = []
+    for pre in (False, True):
+        if pre:
+            g = torch.Generator(device=dev); g.manual_seed(5)
+            m2.infer_batched(X[:3], Y[:3], Bt[:3], top_k=15, generator=g)          # 3 requests through the 1-slot family
+        g = torch.Generator(device=dev); g.manual_seed(11)
+        outs.append(m2.infer(X[7][None], Y[7][None], Bt[7][None], top_k=15, top_p=0.9, temperature=0.8, generator=g).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_staged_refill_with_device_sampling_and_callbacks(dev):
