@@ -675,9 +675,13 @@ class Text2SemanticDecoder:
             rt["tok_override"].zero_()
             rt["tok_override"][:actual] = torch.tensor([c + 1 for c in first], dtype=torch.int64, device=dev)
         if async_refill and mode != 1:      # host-sampled tokens need every refill's logits at once: reference order
-            return self._infer_batched_staged(x, y, bert_feature, batch_size, first, nxt, exhausted,
-                                              [int(a) + int(b) for a, b in zip(x_lens_h, y_lens_h)], check_interval,
-                                              on_finish, max_new_tokens, mode == 2)
+            try:
+                return self._infer_batched_staged(x, y, bert_feature, batch_size, first, nxt, exhausted,
+                                                  [int(a) + int(b) for a, b in zip(x_lens_h, y_lens_h)], check_interval,
+                                                  on_finish, max_new_tokens, mode == 2)
+            finally:    # also on an exception (a prompt that does not fit): no prompt pass may outlive the call
+                if getattr(self, "_refill_stream", None) is not None:
+                    self._refill_stream.synchronize()
 
         have_tok = False
 

@@ -589,6 +589,23 @@ def test_staged_refill_cuts_a_full_cache_like_the_reference_order_loop(dev):
         assert L + min(len(a), len(b)) >= 96 - 12, (i, len(a), len(b), L)      # both ran the cache (nearly) full
 
 
+def test_staged_refill_raises_on_a_prompt_that_does_not_fit_and_recovers(dev):
+    """a queued request whose prompt exceeds the cache raises (as the reference-order loop does) also when the slot loop is
+    the staged one; nothing of the aborted run (parked slots, a prompt pass in flight) leaks into the next call"""
+    cfg = synth.gpt_config(n_layer=3)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=21, eos_gain=2.5), [(2, 64)], torch.float32, dev)
+    ok = [synth.synth_request(700 + i, 4, 6 + i, 8 + i, seed=21, bert="random") for i in range(6)]
+    bad = synth.synth_request(799, 4, 40, 40, seed=21, bert="random")           # 80 positions > 64
+    X = lambda rs: ([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs])
+    ref, ridx = m.infer_batched(*X(ok), top_k=1)
+    want = {int(i): p.cpu().numpy() for i, p in zip(ridx.tolist(), ref)}
+    with pytest.raises(ValueError):
+        m.infer_batched(*X(ok[:4] + [bad] + ok[4:]), top_k=1, async_refill=True)
+    got, gidx = m.infer_batched(*X(ok), top_k=1, async_refill=True)
+    for i, p in zip(gidx.tolist(), got):
+        assert np.array_equal(p.cpu().numpy(), want[int(i)]), i
+
+
 def test_device_sampling_is_keyed_by_request_not_by_slot(dev):
     """continuous batching draws each request's noise from ITS stream (tok_override carries request index + 1 in device-
     sampling mode): the sampled tokens of a request are the same with 4 or 6 slots, with the reference-order or the staged
