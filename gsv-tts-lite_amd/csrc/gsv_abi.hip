@@ -33,8 +33,13 @@ struct T2SLayer {
     unsigned have = 0;
 };
 
+struct T2SStateX : gsv_t2s_state {      // the caller's state + what the library keeps beside it
+    int32_t* eos_host = nullptr;         // host-mapped mirror of eos_at (gsv_t2s_set_eos_mirror)
+};
+inline int32_t* eos_host_of(const gsv_t2s_state& s) { return static_cast<const T2SStateX&>(s).eos_host; }   // every state here is a T2SBound's
+
 struct T2SBound {
-    gsv_t2s_state st;
+    T2SStateX st;
     hipGraphExec_t graph = nullptr;       // the captured decode step
     hipGraphExec_t graph_ft = nullptr;    // ... with the token kernel's work in layer 0's attention kernel (GSV_STEP_FUSED_TOKEN)
     // staging of a refill that runs on ANOTHER stream while the decode step keeps replaying on the caller's
@@ -240,7 +245,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     if (l == 0 && fused_token) {
         StepTok& k = a.tk;
         k.tokpart = h->tokpart; k.tok_override = s.tok_override; k.ctl = s.ctl; k.x_len = s.x_len; k.pre_tokens = s.pre_tokens;
-        k.seen = s.seen; k.step = s.step; k.eos_at = s.eos_at; k.emb = h->emb_audio; k.pe = h->pe_audio;
+        k.seen = s.seen; k.step = s.step; k.eos_at = s.eos_at; k.emb = h->emb_audio; k.pe = h->pe_audio; k.eos_host = eos_host_of(s);
         k.V = h->cfg.vocab; k.eos = h->cfg.eos; k.n_pos = h->cfg.n_pos;
     }
     if (B > 16) {   // two sequences per block: one round of 1024-thread blocks up to 32 sequences (t2s_decode_multi.h)
@@ -309,7 +314,7 @@ int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirec
 int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
     TokenArgs a;
     a.tokpart = h->tokpart; a.tok_override = s.tok_override; a.ctl = s.ctl; a.kv_len = s.kv_len; a.x_len = s.x_len;
-    a.pre_tokens = s.pre_tokens; a.seen = s.seen; a.step = s.step; a.eos_at = s.eos_at; a.emb = h->emb_audio;
+    a.pre_tokens = s.pre_tokens; a.seen = s.seen; a.step = s.step; a.eos_at = s.eos_at; a.eos_host = eos_host_of(s); a.emb = h->emb_audio;
     a.pe = h->pe_audio; a.xcur = h->xcur; a.T = s.max_kv; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.n_pos = h->cfg.n_pos;
     a.advance = advance;
     a.logits = s.logits; a.fctl = s.fctl;
@@ -517,8 +522,8 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     }
     PrefillFinishArgs fa;
     fa.hidden = xy; fa.x_lens = x_lens; fa.y_lens = y_lens; fa.hlast = hlast; fa.kv_len = s.kv_len; fa.x_len = s.x_len;
-    fa.step = s.step; fa.eos_at = s.eos_at; fa.slot0 = slot0; fa.slots = slots; fa.l_max = l_max;
-    if (staged) { fa.kv_len = bd.sg_kv; fa.x_len = bd.sg_x; fa.step = bd.sg_step; fa.eos_at = bd.sg_eos; }
+    fa.step = s.step; fa.eos_at = s.eos_at; fa.eos_host = bd.st.eos_host; fa.slot0 = slot0; fa.slots = slots; fa.l_max = l_max;
+    if (staged) { fa.kv_len = bd.sg_kv; fa.x_len = bd.sg_x; fa.step = bd.sg_step; fa.eos_at = bd.sg_eos; fa.eos_host = nullptr; }
     hipLaunchKernelGGL(t2s_prefill_finish_kernel, dim3(nrows), dim3(128), 0, st, fa);
     HIPCHK(hipGetLastError());
     // first sample: logits[:, :-1] (t2s_model.py:417,613) -> EOS column dropped
@@ -529,7 +534,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
 struct CommitArgs {
     const int32_t* slots;
     const int64_t *sg_kv, *sg_x; const int32_t *sg_step, *sg_eos; const float *sg_logits, *sg_hidden; const TokPart* sg_tok;
-    int64_t *kv_len, *x_len; int32_t *step, *eos_at; float *logits, *hidden; TokPart* tokpart;
+    int64_t *kv_len, *x_len; int32_t *step, *eos_at, *eos_host; float *logits, *hidden; TokPart* tokpart;
     int V;
 };
 __global__ __launch_bounds__(256) void t2s_commit_kernel(CommitArgs a) {
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void t2s_commit_kernel(CommitArgs a) {
     for (int v = tid; v < a.V; v += 256) a.logits[(size_t)s * a.V + v] = a.sg_logits[(size_t)s * a.V + v];
     for (int c = tid; c < kD; c += 256) a.hidden[(size_t)s * kD + c] = a.sg_hidden[(size_t)s * kD + c];
     if (tid < kNP) a.tokpart[(size_t)s * kNP + tid] = a.sg_tok[(size_t)s * kNP + tid];
-    if (tid == 0) { a.kv_len[s] = a.sg_kv[s]; a.x_len[s] = a.sg_x[s]; a.step[s] = a.sg_step[s]; a.eos_at[s] = a.sg_eos[s]; }
+    if (tid == 0) { a.kv_len[s] = a.sg_kv[s]; a.x_len[s] = a.sg_x[s]; a.step[s] = a.sg_step[s]; a.eos_at[s] = a.sg_eos[s]; eos_publish(a.eos_host, s, a.sg_eos[s]); }
 }
 
 }  // namespace
@@ -681,7 +686,8 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     T2SBound& b = h->bound[st->batch];
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
     if (b.graph_ft) { (void)hipGraphExecDestroy(b.graph_ft); b.graph_ft = nullptr; }
-    b.st = *st;
+    static_cast<gsv_t2s_state&>(b.st) = *st;
+    b.st.eos_host = nullptr;
     t2s_free_staging(b);
     const size_t B = (size_t)st->batch;
     HIPCHK(hipMalloc(&b.sg_kv, 8 * B)); HIPCHK(hipMalloc(&b.sg_x, 8 * B));
@@ -765,7 +771,7 @@ int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows,
     if (!slots || nrows < 1 || nrows > batch) return fail(GSV_ERR_ARG, "commit_slots: need 1..batch slots");
     CommitArgs a;
     a.slots = slots; a.sg_kv = b->sg_kv; a.sg_x = b->sg_x; a.sg_step = b->sg_step; a.sg_eos = b->sg_eos; a.sg_logits = b->sg_logits;
-    a.sg_hidden = b->sg_hidden; a.sg_tok = b->sg_tok; a.kv_len = b->st.kv_len; a.x_len = b->st.x_len; a.step = b->st.step; a.eos_at = b->st.eos_at;
+    a.sg_hidden = b->sg_hidden; a.sg_tok = b->sg_tok; a.kv_len = b->st.kv_len; a.x_len = b->st.x_len; a.step = b->st.step; a.eos_at = b->st.eos_at; a.eos_host = b->st.eos_host;
     a.logits = b->st.logits; a.hidden = b->st.hidden; a.tokpart = h->tokpart; a.V = h->cfg.vocab;
     hipLaunchKernelGGL(t2s_commit_kernel, dim3(nrows), dim3(256), 0, S(stream), a);
     HIPCHK(hipGetLastError());
@@ -820,6 +826,17 @@ int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* 
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     return h->cfg.dtype == GSV_BF16 ? t2s_time_impl<bf16_t>(h, b, iters, out_ms, S(stream))
                                     : t2s_time_impl<float>(h, b, iters, out_ms, S(stream));
+}
+
+int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* b = t2s_find(h, batch);
+    if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
+    b->st.eos_host = host_mapped;
+    // the captured steps hold their kernel arguments by value
+    if (b->graph) { (void)hipGraphExecDestroy(b->graph); b->graph = nullptr; }
+    if (b->graph_ft) { (void)hipGraphExecDestroy(b->graph_ft); b->graph_ft = nullptr; }
+    return GSV_OK;
 }
 
 int gsv_t2s_batched_min(gsv_t2s* h) { return h && h->cfg.dtype == GSV_BF16 ? h->batched_min : 0x7fffffff; }

@@ -38,6 +38,12 @@ struct TokPart {
     int idx;
 };
 
+// eos_at[slot] also goes to a host-mapped mirror when the caller registered one (gsv_t2s_set_eos_mirror): the host reads the
+// flag from its own memory after an event instead of enqueuing a device-to-host copy between the decode windows
+__device__ __forceinline__ void eos_publish(int32_t* eos_host, int slot, int value) {
+    if (eos_host != nullptr) __hip_atomic_store(eos_host + slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- shared pieces ---------------------------------------------------------------------------
 //
 // Latency discipline.  The step is a chain of ~50 dependent kernels and, at batch 1, each kernel
@@ -294,6 +300,7 @@ struct StepTok {
     const float* emb;            // [V][512]
     const float* pe;             // [n_pos][512]
     int V, eos, n_pos;
+    int32_t* eos_host;           // null, or a host-mapped mirror of eos_at (gsv_t2s_set_eos_mirror)
 };
 struct StepTokLoads { TokPart tp; int ctl0, ctl2; int64_t ovr, xl; };
 __device__ __forceinline__ StepTokLoads steptok_issue(const StepTok& k, int b, int lane) {
@@ -323,7 +330,7 @@ __device__ __forceinline__ float steptok_finish(const StepTok& k, const StepTokL
         if (n64 >= 0 && n64 <= T) k.pre_tokens[(size_t)b * (T + 1) + n64] = tok;
         if (L.ctl2 != 0 && n64 >= 0) k.seen[(size_t)b * k.V + tok] = 1;
         const int stp = k.step[b];
-        if (tok == k.eos && k.eos_at[b] < 0) k.eos_at[b] = stp;
+        if (tok == k.eos && k.eos_at[b] < 0) { k.eos_at[b] = stp; eos_publish(k.eos_host, b, stp); }
         k.step[b] = stp + 1;
     }
     return v;
@@ -777,6 +784,7 @@ struct TokenArgs {
     int T, V, eos, n_pos, advance;
     const float* logits;     // [B][V] penalised logits of the pending sample (device sampling, ctl[0] == 2)
     const float* fctl;       // fctl[1] = temperature
+    int32_t* eos_host;       // null, or a host-mapped mirror of eos_at
 };
 
 // Counter-based uniform in (0, 1): one draw per (seed, slot, absolute position, vocabulary entry).  The
@@ -939,7 +947,7 @@ static __global__ __launch_bounds__(256) void t2s_token_kernel(TokenArgs a) {
         const int64_t n = a.kv_len[b];
         if (n >= 0 && n <= a.T) a.pre_tokens[(size_t)b * (a.T + 1) + n] = tok;
         if (a.ctl[2] != 0 && n >= 0) a.seen[(size_t)b * a.V + tok] = 1;   // a parked slot's `seen` belongs to its refill
-        if (tok == a.eos && a.eos_at[b] < 0) a.eos_at[b] = a.step[b];
+        if (tok == a.eos && a.eos_at[b] < 0) { a.eos_at[b] = a.step[b]; eos_publish(a.eos_host, b, a.step[b]); }
         if (a.advance) a.step[b] += 1;
     }
     __syncthreads();

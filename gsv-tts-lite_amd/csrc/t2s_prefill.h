@@ -414,6 +414,7 @@ struct PrefillFinishArgs {
     int64_t* x_len;
     int32_t* step;
     int32_t* eos_at;
+    int32_t* eos_host;     // null, or the host-mapped mirror of eos_at (not with staged outputs: the commit publishes)
     int slot0, l_max;
     const int32_t* slots;  // state slot of every row, or null = slot0 + row
 };
@@ -430,6 +431,7 @@ static __global__ __launch_bounds__(128) void t2s_prefill_finish_kernel(PrefillF
         a.x_len[slot] = lx;
         a.step[slot] = 0;
         a.eos_at[slot] = -1;
+        eos_publish(a.eos_host, slot, -1);
     }
 }
 

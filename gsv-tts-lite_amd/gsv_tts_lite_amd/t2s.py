@@ -174,6 +174,9 @@ class Text2SemanticDecoder:
                 "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden",
                 "tok_override", "ctl", "fctl")])
             N.check(L.gsv_t2s_bind_state(h, ctypes.byref(st)))
+            if b == 1:   # single-sequence loop: the EOS flag is read from a host-mapped mirror, not copied per window
+                rt["eos_host"] = torch.full((b,), -1, dtype=torch.int32).pin_memory()
+                N.check(L.gsv_t2s_set_eos_mirror(h, b, rt["eos_host"].data_ptr()))
             self._rt[b] = rt
             self.cuda_graph_buckets[b] = [Bucket(b, t, rt) for t in ts]
         self._ws = None
@@ -322,29 +325,31 @@ class Text2SemanticDecoder:
             # cadence here, but the test of chunk i is read AFTER chunk i+1 has been enqueued (async copy of the
             # flag into pinned memory + an event), so the GPU never idles on the host round trip.  A chunk that
             # runs past the EOS costs nothing observable: tokens are cut at the first EOS anyway (:459-462).
+            # The flag itself is not copied either: the kernels publish eos_at to a host-mapped mirror
+            # (gsv_t2s_set_eos_mirror), the host reads its own memory once the window's event has fired.  (A device-to-host
+            # copy between the windows cost 0 - 15 us per token, bimodal from run to run.)  The pending sample of a window
+            # becomes a token at the next step, so an EOS is seen at most one window late; only the last window is flushed.
             if self._eos_pipe is None:
-                self._eos_pipe = [(torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+                self._eos_pipe = [torch.cuda.Event() for _ in range(2)]
+            mirror = rt["eos_host"]
             pending = None
             k = 0
             while done < n_iter:
                 n = min(check_interval, n_iter - done)
                 self._decode(1, n)
                 done += n
-                self._flush(1)
-                buf, ev = self._eos_pipe[k]
+                if done >= n_iter:
+                    self._flush(1)
+                ev = self._eos_pipe[k]
                 k ^= 1
-                buf.copy_(rt["eos_at"][:1], non_blocking=True)
                 ev.record()
                 if pending is not None:
-                    pending[1].synchronize()
-                    if int(pending[0][0]) >= 0:
-                        eos_at = int(pending[0][0])
-                        pending = None
+                    pending.synchronize()
+                    if int(mirror[0]) >= 0:
                         break
-                pending = (buf, ev)
-            if pending is not None:
-                pending[1].synchronize()
-                eos_at = int(pending[0][0])
+                pending = ev
+            torch.cuda.current_stream(self.device).synchronize()
+            eos_at = int(mirror[0])
         else:
             while done < n_iter:
                 tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)

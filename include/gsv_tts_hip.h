@@ -98,6 +98,12 @@ typedef struct {
     float* fctl;            /* [4]   {repetition_penalty, temperature, top_p, -} */
 } gsv_t2s_state;
 int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st);
+/* Optional: `host_mapped` [batch] int32 in host memory the device can write (hipHostMalloc / a pinned torch tensor), or
+ * NULL to turn it off.  Every kernel that sets state.eos_at[slot] then also publishes the value there (system-scope store),
+ * so the host loop of t2s_model.py:451-453 reads the EOS flag from its own memory after an event instead of enqueuing a
+ * device-to-host copy between the decode windows.  Call after gsv_t2s_bind_state (which clears it); it invalidates the
+ * captured steps of this batch size. */
+int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped);
 
 /* replaces process_single_data / process_batch_data (t2s_model.py:300-383): builds packed rows
  * [x_b | y_b | 0-pad] = text-emb + bert_proj + alpha_t*pe, audio-emb + alpha_a*pe.
