@@ -108,8 +108,60 @@ class Text2SemanticDecoder:
         return self
 
     # ------------------------------------------------------------------ runtime
+    _RUNTIME_FIELDS = ("_h", "k_cache_root", "v_cache_root", "_rt", "cuda_graph_buckets", "batched_min", "_ws")
+
     @torch.inference_mode()
-    def initialize_runtime(self, dtype, device, gpt_cache):
+    def initialize_runtime(self, dtype, device, gpt_cache, tune_placement=None):
+        """t2s_model.py:210-298 (`_build_runtime`), plus a placement pick: the decode step of a full-size model lands at its
+        usual time or 3-9 % above it depending on where the allocator happens to put the handle's buffers and the state
+        tensors (measured: about one instance in four; contiguous arenas are worse), so `tune_placement`
+        instances are built (default 3 for models of >= 12 layers, GSV_TUNE_PLACEMENT overrides, 0 / 1 = off), each is
+        timed on 40 replays of its smallest batch size's step, the fastest is kept and the others are released."""
+        if tune_placement is None:
+            tune_placement = int(os.environ.get("GSV_TUNE_PLACEMENT", "3" if self.num_layers >= 12 else "1"))
+        if tune_placement <= 1:
+            return self._build_runtime(dtype, device, gpt_cache)
+        best, losers = None, []
+        for _ in range(tune_placement):
+            self.cuda_graph_buckets, self._rt, self._ws, self._h = {}, {}, None, None
+            self._build_runtime(dtype, device, gpt_cache)
+            t = self._time_step(min(self._rt))
+            cand = (t, {k: getattr(self, k) for k in self._RUNTIME_FIELDS})
+            if best is None or t < best[0]:
+                if best is not None:
+                    losers.append(best)
+                best = cand
+            else:
+                losers.append(cand)
+        for k, v in best[1].items():
+            setattr(self, k, v)
+        self.placement_times_ms = [best[0]] + [c[0] for c in losers]
+        for _, fields in losers:            # released only now: a freed block would be handed to the next candidate again
+            N.lib().gsv_t2s_destroy(fields["_h"])
+        del losers
+        torch.cuda.synchronize(self.device)
+
+    def _time_step(self, batch):
+        """ms per decode step of this instance at `batch` sequences: hipGraph replay behind a prompt of about a quarter of the
+        cache, so that the K/V rows a real run reads are the ones the probe reads"""
+        rt, dev = self._rt[batch], self.device
+        lp = max(1, min(100, rt["T"] // 8))
+        one = torch.ones(lp, dtype=torch.int64, device=dev)
+        bert = torch.zeros(lp, 1024, dtype=torch.float32, device=dev)
+        self._set_ctl(rt, 0, 0, False, 1.0)
+        rt["kv_len"].zero_(); rt["x_len"].zero_()
+        xy, xl, yl, _, _ = self.embed_prompt([one] * batch, [one] * batch, [bert] * batch)
+        self.prefill(batch, 0, xy, xl, yl)
+        n = max(8, min(40, rt["T"] - 8))
+        self._decode(batch, 3)
+        torch.cuda.synchronize(dev)
+        import time
+        t0 = time.perf_counter()
+        self._decode(batch, n)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3 / n
+
+    def _build_runtime(self, dtype, device, gpt_cache):
         """t2s_model.py:210-298.  Builds the native handle, uploads/repacks weights, allocates the
         nested KV cache (one root K and V; per batch size a [L,B,H,T,Dh] view; smaller buckets
         are prefix slices on T) and binds one state per batch size."""
@@ -344,7 +396,11 @@ class Text2SemanticDecoder:
                 k ^= 1
                 ev.record()
                 if pending is not None:
-                    pending.synchronize()
+                    if os.environ.get("GSV_EV_SPIN"):
+                        while not pending.query():
+                            pass
+                    else:
+                        pending.synchronize()
                     if int(mirror[0]) >= 0:
                         break
                 pending = ev
