@@ -115,10 +115,10 @@ class Text2SemanticDecoder:
         """t2s_model.py:210-298 (`_build_runtime`), plus a placement pick: the decode step of a full-size model lands at its
         usual time or 3-9 % above it depending on where the allocator happens to put the handle's buffers and the state
         tensors (measured: about one instance in four; contiguous arenas are worse), so `tune_placement`
-        instances are built (default 3 for models of >= 12 layers, GSV_TUNE_PLACEMENT overrides, 0 / 1 = off), each is
+        instances are built (default 4 for models of >= 12 layers, GSV_TUNE_PLACEMENT overrides, 0 / 1 = off), each is
         timed on 40 replays of its smallest batch size's step, the fastest is kept and the others are released."""
         if tune_placement is None:
-            tune_placement = int(os.environ.get("GSV_TUNE_PLACEMENT", "3" if self.num_layers >= 12 else "1"))
+            tune_placement = int(os.environ.get("GSV_TUNE_PLACEMENT", "4" if self.num_layers >= 12 else "1"))
         if tune_placement <= 1:
             return self._build_runtime(dtype, device, gpt_cache)
         best, losers = None, []
@@ -145,7 +145,7 @@ class Text2SemanticDecoder:
         """ms per decode step of this instance at `batch` sequences: hipGraph replay behind a prompt of about a quarter of the
         cache, so that the K/V rows a real run reads are the ones the probe reads"""
         rt, dev = self._rt[batch], self.device
-        lp = max(1, min(100, rt["T"] // 8))
+        lp = max(1, min(100, rt["T"] // 4))
         one = torch.ones(lp, dtype=torch.int64, device=dev)
         bert = torch.zeros(lp, 1024, dtype=torch.float32, device=dev)
         self._set_ctl(rt, 0, 0, False, 1.0)
