@@ -1,6 +1,80 @@
 // C ABI of the MI355X GPT-SoVITS hot path (include/gsv_tts_hip.h), GPT part: handle management, weight
 // repacking into library-owned arenas, kernel sequencing, hipGraph capture of the decode step.  (SoVITS: gsv_voc.hip.)
 // No allocation happens inside a step; nothing here falls back to a CPU or library path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+// One arena per GPT handle: every device buffer the handle owns (decode panels, MFMA fragments, scratch, staging) is carved out
+// of a few 256 MB blocks at 64 KB alignment instead of ~450 separate hipMalloc calls.  Measured reason (10 model instances per
+// setting, ms per decode step): separate allocations 0.323 - 0.343 (the small buffers land wherever the driver's sub-allocator
+// has room; about one instance in four is 3 - 9 % slow); arena at 4 KB alignment 0.329 - 0.335, at 2 MB + k * 4 KB 0.323 - 0.335,
+// at 2 MB + k * 68 KB 0.329 - 0.339; arena at 64 KB alignment 0.323 - 0.326 and at 2 MB + k * 256 B 0.324 - 0.326 -- every
+// instance at the best time.  GSV_NO_ARENA=1 switches it off, GSV_ARENA_ALIGN / GSV_ARENA_SKEW are the experiment's knobs.
+namespace gsv_arena {
+struct Arena {
+    std::vector<std::pair<char*, size_t>> blocks;
+    size_t used = 0;
+    size_t count = 0;
+};
+static std::mutex g_mu;
+static std::vector<std::pair<char*, size_t>> g_all;
+static thread_local Arena* g_cur = nullptr;
+static hipError_t amalloc(void** p, size_t n) {
+    if (!g_cur) return hipMalloc(p, n);
+    static const size_t align = getenv("GSV_ARENA_ALIGN") ? (size_t)atol(getenv("GSV_ARENA_ALIGN")) : 65536;
+    static const size_t skew = getenv("GSV_ARENA_SKEW") ? (size_t)atol(getenv("GSV_ARENA_SKEW")) : 0;
+    constexpr size_t kBlock = (size_t)256 << 20;
+    Arena& a = *g_cur;
+    const size_t sk = (a.count * skew) % align;
+    size_t start = (a.used + align - 1) / align * align + sk;
+    if (a.blocks.empty() || start + n > a.blocks.back().second) {
+        const size_t sz = std::max(n + align, kBlock);
+        char* base = nullptr;
+        const hipError_t e = hipMalloc(&base, sz);
+        if (e != hipSuccess) return e;
+        a.blocks.emplace_back(base, sz);
+        a.used = 0;
+        start = sk;
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_all.emplace_back(base, sz);
+    }
+    *p = a.blocks.back().first + start;
+    a.used = start + n;
+    a.count++;
+    return hipSuccess;
+}
+static hipError_t afree(void* p) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& b : g_all)
+            if ((char*)p >= b.first && (char*)p < b.first + b.second) return hipSuccess;
+    }
+    return hipFree(p);
+}
+static void release(Arena& a) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& b : a.blocks) {
+        (void)hipFree(b.first);
+        g_all.erase(std::remove(g_all.begin(), g_all.end(), b), g_all.end());
+    }
+    a.blocks.clear();
+    a.used = 0;
+}
+struct Scope {
+    Arena* prev;
+    explicit Scope(Arena* a) : prev(g_cur) { g_cur = a; }
+    ~Scope() { g_cur = prev; }
+};
+}  // namespace gsv_arena
+#define hipMalloc(p, n) gsv_arena::amalloc((void**)(p), (n))
+#define hipFree(p) gsv_arena::afree((void*)(p))
+
 #include "abi_common.h"
 #include "t2s_decode.h"
 #include "t2s_decode_multi.h"
@@ -75,7 +149,10 @@ struct gsv_t2s {
     TokPart* tokpart = nullptr;
     hipStream_t cap_stream = nullptr;
     unsigned long long* dbg = nullptr;
+    gsv_arena::Arena arena;
+    bool use_arena = true;
 };
+#define GSV_ARENA_SCOPE(h) gsv_arena::Scope arena_scope_((h)->use_arena ? &(h)->arena : nullptr)
 
 namespace {
 
@@ -607,6 +684,7 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
     h->batched_min = kBatchedMinDefault;
     if (const char* e = getenv("GSV_BATCHED_MIN")) h->batched_min = std::max(1, atoi(e));
     if (const char* e = getenv("GSV_BSTEP_SKIP")) h->dbg_skip = (unsigned)atoi(e);
+    if (getenv("GSV_NO_ARENA")) h->use_arena = false;
     h->layers.resize(cfg->n_layer);
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -637,12 +715,14 @@ int gsv_t2s_destroy(gsv_t2s* h) {
         if (p) (void)hipFree(p);
     free_conv(h->g_bert);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    gsv_arena::release(h->arena);
     delete h;
     return GSV_OK;
 }
 
 int gsv_t2s_load_tensor(gsv_t2s* h, const char* name, const float* data, int64_t numel, void* stream) {
     if (!h || !name || !data) return fail(GSV_ERR_ARG, "null argument");
+    GSV_ARENA_SCOPE(h);
     std::string n(name);
     const std::string pre = "t2s_transformer.blocks.";
     h->finalized = false;
@@ -661,6 +741,7 @@ int gsv_t2s_load_tensor(gsv_t2s* h, const char* name, const float* data, int64_t
 
 int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
     if (!h) return fail(GSV_ERR_ARG, "null handle");
+    GSV_ARENA_SCOPE(h);
     for (int l = 0; l < h->cfg.n_layer; ++l)
         if (h->layers[l].have != 0xfffu) return fail(GSV_ERR_STATE, "layer %d incomplete (mask 0x%x)", l, h->layers[l].have);
     if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
@@ -678,6 +759,7 @@ int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
 
 int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     if (!h || !st) return fail(GSV_ERR_ARG, "null argument");
+    GSV_ARENA_SCOPE(h);
     if (st->batch < 1 || st->max_kv < 2) return fail(GSV_ERR_ARG, "bad batch/max_kv");
     if (!st->k_cache || !st->v_cache || !st->kv_len || !st->x_len || !st->pre_tokens || !st->seen || !st->step ||
         !st->eos_at || !st->logits || !st->hidden || !st->tok_override || !st->ctl || !st->fctl)
