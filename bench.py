@@ -220,10 +220,30 @@ def _profile_traffic(out, a):
         pass
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: re-run this command as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1 and pass its output through.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    if not a.share_gpu and torch.cuda.device_count() < a.gpus:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (a.gpus, torch.cuda.device_count()))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks: %s" % (a.gpus, " ".join(cmd[1:])))
+    return subprocess.call(cmd, env=env)
+
+
 def setup_dist(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:      # a line that says n_gpus: 1 for a --gpus 8 request is worse than no line
+        raise SystemExit("bench.py --gpus %d is running with WORLD_SIZE=%d: launch it bare (it starts its own ranks) or under "
+                         "torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -233,10 +253,14 @@ def setup_dist(a):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     return world, rank, dev, dist
+
+
+def dist_info(a, world, book):
+    return {"world_size": world, "backend": (a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else "")) if world > 1 else None,
+            "speaker_broadcasts": book.broadcasts, "ranks_share_one_gpu": bool(a.share_gpu)}
 
 
 def timed_region(steps, warmup, step_fn, dev, dist):
@@ -637,6 +661,8 @@ def main():
     if a.cpu_baseline_worker:
         cpu_baseline_worker(a.cpu_baseline_worker, a.version)
         return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     if a.workload == "cb":
         if a.steps == 10 and a.warmup == 2 and "--steps" not in sys.argv:
             a.steps, a.warmup = 3, 1      # a step is a whole queue (~2 s): keep the default run within minutes

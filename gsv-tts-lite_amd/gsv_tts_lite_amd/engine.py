@@ -127,7 +127,9 @@ class ContinuousBatchingEngine:
         self.store = store if store is not None else (_default_store() if _dist_on(group) else None)
         self.rank = dist.get_rank(group) if _dist_on(group) else 0
         self.world = dist.get_world_size(group) if _dist_on(group) else 1
+        self.device = getattr(decoder, "device", torch.device("cpu"))
         self.last_taken: List[int] = []
+        self._cursor_keys: List[str] = []
 
     def _source(self, costs: Sequence[float]) -> RequestSource:
         order = lpt_order(costs)
@@ -138,7 +140,22 @@ class ContinuousBatchingEngine:
             from .scheduler import shard_indices
             mine = set(shard_indices([int(c) for c in costs], self.world, self.rank))
             return RequestSource([i for i in order if i in mine], None, chunk=len(order) or 1)
-        return RequestSource(order, self.store, key="gsv/cursor/%d" % run, chunk=self.chunk)
+        key = "gsv/cursor/%d" % run
+        self._cursor_keys.append(key)
+        return RequestSource(order, self.store, key=key, chunk=self.chunk)
+
+    def _retire_cursors(self, dst: Optional[int] = None):
+        """a finished run's cursor key leaves the rendezvous store (a long-lived server would grow it by one key per
+        infer_batched call).  Call it right after a gather / exchange of that run's results: the rank that RECEIVED from
+        everybody (`dst`; rank 0 after an all-gather) knows every slot loop has returned, so nobody can add to the key
+        any more -- a delete by anyone else could hand the queue out a second time."""
+        keys, self._cursor_keys = self._cursor_keys, []
+        if self.rank == (0 if dst is None else dst) and self.store is not None:
+            for k in keys:
+                try:
+                    self.store.delete_key(k)
+                except Exception:      # a store without delete (FileStore): the key stays, nothing else depends on it
+                    pass
 
     def run_gpt(self, xs, ys, berts, costs: Optional[Sequence[float]] = None, **sampling):
         """-> (pred, idx): this rank's finished requests, completion order, GLOBAL indices"""
@@ -186,8 +203,9 @@ class ContinuousBatchingEngine:
         side.synchronize()
         return results, pred, idx
 
-    def gather(self, local: Dict[int, object], n_total: int, dst: Optional[int] = None) -> Optional[List[object]]:
-        """index -> payload of this rank  =>  the full list in global index order (on `dst`, or on every rank)"""
+    def gather(self, local: Dict[int, object], n_total: int, dst: Optional[int] = 0) -> Optional[List[object]]:
+        """index -> (small, picklable) payload of this rank  =>  the full list in global index order on rank `dst` (None on
+        the other ranks), or on every rank with dst=None.  Tensors go through `exchange`, not through here."""
         if self.world == 1:
             parts = [local]
         elif dst is None:
@@ -199,20 +217,112 @@ class ContinuousBatchingEngine:
             if parts is None:
                 return None
         out: List[object] = [None] * n_total
-        seen = 0
+        filled = set()
         for p in parts:
             for i, v in p.items():
-                if out[i] is not None:
+                if not 0 <= int(i) < n_total:
+                    raise RuntimeError("gather: request index %r outside [0, %d)" % (i, n_total))
+                if i in filled:
                     raise RuntimeError("request %d was produced by two ranks" % i)
+                filled.add(i)
                 out[i] = v
-                seen += 1
-        if seen != n_total:
-            raise RuntimeError("gather: %d of %d requests returned" % (seen, n_total))
+        if len(filled) != n_total:
+            raise RuntimeError("gather: %d of %d requests returned" % (len(filled), n_total))
         return out
+
+    def _staged(self) -> bool:
+        """gloo moves host tensors only (CI on a 1-GPU box); RCCL moves device tensors over xGMI"""
+        return dist.get_backend(self.group) != "nccl"
+
+    def exchange(self, local: Dict[int, torch.Tensor], n_total: int, dst: Optional[int] = 0) -> Optional[List[torch.Tensor]]:
+        """Variable-length 1-D tensors keyed by GLOBAL request index (token ids, audio samples), all of one dtype and on
+        one device  =>  the list in index order on rank `dst` (None elsewhere), or on every rank with dst=None.
+        Device-side: one all-reduce of the [3, n_total] length / owner / count table, then each rank's tensors travel as ONE
+        concatenated buffer -- point-to-point to `dst` (RCCL send/recv over the peer's xGMI link: nothing is pickled, nothing
+        touches the host), or an all-gather padded to the largest rank when every rank wants them."""
+        for i in local:
+            if not 0 <= int(i) < n_total:
+                raise RuntimeError("exchange: request index %r outside [0, %d)" % (i, n_total))
+        if self.world == 1:
+            if len(local) != n_total:
+                raise RuntimeError("exchange: %d of %d requests present" % (len(local), n_total))
+            return [local[i] for i in range(n_total)]
+        mine = sorted(local)
+        ref = local[mine[0]] if mine else None
+        dev = self.device if ref is None else ref.device
+        tab = torch.zeros(3, n_total, dtype=torch.int64)
+        for i in mine:
+            tab[0, i], tab[1, i], tab[2, i] = local[i].numel(), self.rank, 1
+        tab = tab.to(dev)
+        dist.all_reduce(tab, group=self.group)
+        tab = tab.cpu()
+        bad = (tab[2] != 1).nonzero().flatten().tolist()
+        if bad:
+            raise RuntimeError("exchange: requests %s were produced by %s ranks" % (bad[:8], tab[2][bad[:8]].tolist()))
+        lens, owner = tab[0].tolist(), tab[1].tolist()
+        totals = [0] * self.world
+        for l, o in zip(lens, owner):
+            totals[o] += l
+        dtype = self._exchange_dtype(ref, dev)
+        cat = torch.cat([local[i].reshape(-1) for i in mine]) if mine else torch.empty(0, dtype=dtype, device=dev)
+        staged = self._staged()
+        cdev = torch.device("cpu") if staged else dev
+        bufs: List[Optional[torch.Tensor]] = [None] * self.world
+        if dst is None:
+            cap = max(totals)
+            pad = torch.zeros(cap, dtype=dtype, device=cdev)
+            pad[:cat.numel()] = cat.to(cdev)
+            got = [torch.empty(cap, dtype=dtype, device=cdev) for _ in range(self.world)]
+            dist.all_gather(got, pad, group=self.group)
+            bufs = [g[:t] for g, t in zip(got, totals)]
+        else:
+            ops = []
+            if self.rank == dst:
+                for r in range(self.world):
+                    if r == dst:
+                        bufs[r] = cat.to(cdev)
+                    elif totals[r]:
+                        bufs[r] = torch.empty(totals[r], dtype=dtype, device=cdev)
+                        ops.append(dist.P2POp(dist.irecv, bufs[r], self._global_rank(r), group=self.group))
+                    else:
+                        bufs[r] = torch.empty(0, dtype=dtype, device=cdev)
+            elif cat.numel():
+                ops.append(dist.P2POp(dist.isend, cat.to(cdev).contiguous(), self._global_rank(dst), group=self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if self.rank != dst:
+                return None
+        out: List[torch.Tensor] = [None] * n_total
+        pos = [0] * self.world
+        for i in range(n_total):
+            o, l = owner[i], lens[i]
+            out[i] = bufs[o][pos[o]:pos[o] + l]
+            pos[o] += l
+        return [t.to(dev) for t in out] if staged else out
+
+    def _global_rank(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _exchange_dtype(self, ref, dev):
+        """every rank must use one dtype, also a rank that holds nothing: agree on it through a tiny all-reduce"""
+        codes = [torch.float32, torch.int64, torch.int32, torch.float16, torch.bfloat16, torch.uint8]
+        c = torch.tensor([codes.index(ref.dtype) + 1 if ref is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+        if int(c.item()) == 0:
+            return torch.float32
+        return codes[int(c.item()) - 1]
+
+    def deal_batches(self, n_batches: int) -> List[int]:
+        """vocoder batches (TTS.py:728-764) are dealt round-robin: batch b runs on rank b mod world.  The batches come out of
+        the reference's length-balancing interleave, so their totals are near-equal and a static deal is balanced."""
+        return [b for b in range(n_batches) if b % self.world == self.rank]
 
     def run(self, xs, ys, berts, costs=None, vocode: Optional[Callable] = None, dst: Optional[int] = None, **sampling):
         """GPT on this rank's share, optional per-rank vocoder stage, gather in input order."""
         pred, idx = self.run_gpt(xs, ys, berts, costs, **sampling)
         items = list(zip(idx.tolist(), pred))
         local = vocode(items) if vocode is not None else {int(i): p.cpu() for i, p in items}
-        return self.gather(local, len(xs), dst=dst)
+        out = self.gather(local, len(xs), dst=dst)
+        self._retire_cursors(dst)
+        return out

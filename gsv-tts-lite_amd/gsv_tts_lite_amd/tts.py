@@ -161,6 +161,9 @@ class TTS:
         self.audio_queue = None
         self._infer_lock = _EngineLock()
         self._text_frontend = None
+        # multi-GPU (one process per GPU): the rank on which infer_batched returns the clips; the other ranks return None.
+        # None = every rank gets every clip (an all-gather of the audio instead of point-to-point sends to one rank)
+        self.gather_dst = 0
 
     # ------------------------------------------------------------------ model management
     def load_gpt_model(self, *model_paths):
@@ -662,23 +665,29 @@ class TTS:
                     pred, orig_idx = t2s.infer_batched(ids, prompts, berts, top_k=top_k, top_p=top_p,
                                                        temperature=temperature, repetition_penalty=repetition_penalty,
                                                        async_refill=True)
-                else:   # this rank's share of the segment queue (engine.py): global indices come back
+                    tokens = [None] * len(segs)
+                    for p_, o in zip(pred, orig_idx.tolist()):
+                        tokens[o] = p_
+                else:   # this rank's share of the segment queue (engine.py), then every rank learns every segment's tokens
                     pred, orig_idx = eng.run_gpt(ids, prompts, berts, costs=[int(i.shape[0]) for i in ids], top_k=top_k, top_p=top_p,
                                                  temperature=temperature, repetition_penalty=repetition_penalty,
                                                  async_refill=True)
-                lengths = torch.tensor([len(p) for p in pred])
-                order = balance_order(lengths)                     # short/long interleave, TTS.py:705-716
-                m = len(order)
-                pred = [pred[i] for i in order.tolist()]
-                orig_idx = orig_idx.cpu()[order]
-                lengths = lengths[order]
+                    tokens = eng.exchange({int(o): p_ for p_, o in zip(pred, orig_idx.tolist())}, len(segs), dst=None)
+                    eng._retire_cursors(None)
+                # TTS.py:705-716 sorts the COMPLETION-order list by length; completion order depends on slot timing (and on
+                # the rank count), the request order does not: the balance runs over the request-order lengths, so one
+                # process and N ranks form the same vocoder batches and return the same samples
+                lengths_all = torch.tensor([len(p_) for p_ in tokens])
+                order_all = balance_order(lengths_all)
+                batches = [order_all[s:s + sovits_batch_size] for s in range(0, len(order_all), sovits_batch_size)]
+                my_batches = range(len(batches)) if eng is None else eng.deal_batches(len(batches))
 
-                audios, subs_out = [], []
-                for s in range(0, m, sovits_batch_size):
-                    e = min(s + sovits_batch_size, m)
-                    sem = pred[s:e]
-                    oi = orig_idx[s:e].tolist()
-                    ln = lengths[s:e]
+                audios, subs_out, orig_done = [], [], []
+                for b in my_batches:
+                    oi = batches[b].tolist()
+                    sem = [tokens[o] for o in oi]
+                    ln = lengths_all[batches[b]]
+                    orig_done += oi
                     ge_cat = torch.cat([ges[o].expand(-1, int(l)) for o, l in zip(oi, ln)], dim=1).unsqueeze(0)
                     ph_cat = torch.cat([torch.tensor(phones2_all[o], dtype=torch.int64, device=dev) for o in oi]).unsqueeze(0)
                     plens = torch.tensor([len(phones2_all[o]) for o in oi], device=dev)
@@ -704,7 +713,7 @@ class TTS:
                             last_i = best_i
                             a = audio[int(part[0]["start_s"] * self.samplerate):int(part[-1]["end_s"] * self.samplerate)]
                             h, t = self._find_head_threshold_offsets(a), self._find_tail_threshold_offsets(a)
-                            audios.append(a[h:-t].float().cpu().numpy())
+                            audios.append(a[h:-t].float())
                             part[0]["start_s"] += h / self.samplerate
                             part[-1]["end_s"] -= t / self.samplerate
                             subs_out.append(sub.sub2text_index(part, norm_all[o], segs[o]))
@@ -712,21 +721,24 @@ class TTS:
                     for lo, hi in split_bounds(ln.tolist(), vq.samples_per_frame, speed):   # TTS.py:806-811
                         a = audio[lo:hi]
                         h, t = self._find_head_threshold_offsets(a), self._find_tail_threshold_offsets(a)
-                        audios.append(a[h:-t].float().cpu().numpy())
+                        audios.append(a[h:-t].float())
 
                 if eng is None:
-                    ordered = [None] * len(audios)
-                    ordered_subs = [None] * len(audios)
-                    for cur, o in enumerate(orig_idx.tolist()):
-                        ordered[o] = audios[cur]
+                    ordered = [None] * len(segs)
+                    ordered_subs = [None] * len(segs)
+                    for cur, o in enumerate(orig_done):
+                        ordered[o] = audios[cur].cpu().numpy()
                         if return_subtitles:
                             ordered_subs[o] = subs_out[cur]
-                else:   # every rank vocoded its own segments; all ranks assemble the full result (TTS.py:820-865)
-                    local = {int(o): (audios[cur], subs_out[cur] if return_subtitles else None)
-                             for cur, o in enumerate(orig_idx.tolist())}
-                    full = eng.gather(local, len(segs))
-                    ordered = [a for a, _ in full]
-                    ordered_subs = [sb for _, sb in full]
+                else:   # every rank vocoded its batches; the samples meet on rank `gather_dst` over RCCL (TTS.py:820-865)
+                    dst = self.gather_dst
+                    full = eng.exchange({int(o): audios[cur].contiguous() for cur, o in enumerate(orig_done)}, len(segs), dst=dst)
+                    ordered_subs = [None] * len(segs)
+                    if return_subtitles:
+                        ordered_subs = eng.gather({int(o): subs_out[cur] for cur, o in enumerate(orig_done)}, len(segs), dst=dst)
+                    if full is None:
+                        return None     # not the gathering rank
+                    ordered = [a.cpu().numpy() for a in full]
                 per_text = [[] for _ in range(n)]
                 per_text_subs = [[] for _ in range(n)]
                 last_orig, cur_text_l = None, 0

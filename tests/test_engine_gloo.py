@@ -70,6 +70,29 @@ def _worker(rank, world, port, ret):
     c = book.sync("spk-b", [torch.ones(2, 3)] if rank == 0 else None)
     ok = (torch.equal(a[0], torch.from_numpy(synth.synth_ge(3, 1024, 7))) and torch.equal(a[1], torch.arange(70))
           and b is a and n1 == 2 and n2 == 2 and book.broadcasts == 3 and torch.equal(c[0], torch.ones(2, 3)))
+    # variable-length tensors keyed by global index: all-gather form, point-to-point form (to rank 0 and to the last rank),
+    # a rank that holds nothing, zero-length entries, a float payload
+    mine = {i: torch.full((steps[i] if i % 5 else 0,), i, dtype=torch.int64) for i in taken}
+    ex_all = eng.exchange(mine, n, dst=None)
+    ex_0 = eng.exchange(mine, n, dst=0)
+    ex_l = eng.exchange({i: v.float() * 0.5 for i, v in mine.items()}, n, dst=world - 1)
+    only0 = eng.exchange({i: torch.arange(i + 1) for i in range(6)} if rank == 0 else {}, 6, dst=None)
+    exp = [[i] * (steps[i] if i % 5 else 0) for i in range(n)]
+    ok = ok and [t.tolist() for t in ex_all] == exp and [t.tolist() for t in only0] == [list(range(i + 1)) for i in range(6)]
+    ok = ok and ((ex_0 is None) if rank != 0 else [t.tolist() for t in ex_0] == exp)
+    ok = ok and ((ex_l is None) if rank != world - 1 else
+                 (all(t.dtype == torch.float32 for t in ex_l) and [t.tolist() for t in ex_l] == [[0.5 * v for v in e] for e in exp]))
+    try:
+        eng.exchange({0: torch.zeros(1)}, 3, dst=None)      # index 0 from every rank, 1 and 2 from nobody
+        ok = False
+    except RuntimeError:
+        pass
+    g0 = eng.gather({i: ("r", i) for i in taken}, n)         # default: on rank 0 only
+    ok = ok and ((g0 is None) if rank != 0 else g0 == [("r", i) for i in range(n)])
+    ok = ok and eng.deal_batches(7) == [b for b in range(7) if b % world == rank]
+    # retired cursors leave the store (rank 0 deletes after a gather it received)
+    if rank == 0:
+        ok = ok and not eng._cursor_keys
     ret[rank] = (taken, [t.tolist() for t in out], [t.tolist() for t in out2], ok, steps)
     dist.barrier()
     dist.destroy_process_group()
