@@ -241,6 +241,8 @@ def setup_dist(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if a.share_gpu and a.dist_backend == "nccl" and world > 1:
+        raise SystemExit("--share-gpu needs --dist-backend gloo: RCCL wants one device per rank")
     if world != a.gpus:      # a line that says n_gpus: 1 for a --gpus 8 request is worse than no line
         raise SystemExit("bench.py --gpus %d is running with WORLD_SIZE=%d: launch it bare (it starts its own ranks) or under "
                          "torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
@@ -353,6 +355,7 @@ def run_single(a):
                                (a.version, N_NEW, FRAMES, audio_s, "off" if a.no_graph else "on"),
                    "utterances_per_step": world, "gpt_cache": GPT_CACHE, "max_new_tokens": N_NEW,
                    "parallelism": "replicas x%d, ge broadcast once per speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
+        "dist": dist_info(a, world, book),
         "audio_s_per_s_end_to_end": world * a.steps * audio_s / elapsed,
         "ar_tokens_per_s_per_gpu": tokens_per_step / t_ar,
         "vocoder_audio_s_per_s_per_gpu": audio_s / t_voc,
@@ -529,23 +532,29 @@ def run_cb(a):
     acc = {"tok": 0, "frames": 0, "t_ar": 0.0, "t_voc": 0.0, "steps": 0, "kv_rows": 0, "mine": 0}
     costs = [int(x.shape[0]) + int(y.shape[0]) + int(n) for x, y, n in zip(xs, ys, new_tok)] if a.lpt_budget else None
 
-    def vocode(items):
-        """flow + Generator over this rank's finished utterances, time-concatenated in batches of 10 with per-frame ge,
-        sorted short/long-interleaved as TTS.infer_batched does (TTS.py:705-764)"""
+    def vocode(tokens):
+        """TTS.infer_batched's vocoder stage (TTS.py:705-764, tts.py): length-balanced order over ALL requests, time-concatenated
+        batches of 10 with per-frame ge, batch b on rank b mod world; -> ({request: its samples (device)}, frames vocoded here)"""
         from gsv_tts_lite_amd.batchmath import balance_order
-        if not items:
-            return 0
-        lengths = torch.tensor([len(p) for _, p in items])
-        order = balance_order(lengths).tolist()
-        tot = 0
-        for s in range(0, len(order), 10):
-            T = int(sum(2 * int(lengths[i]) for i in order[s:s + 10]))
+        lengths = torch.tensor([len(p) for p in tokens])
+        order = balance_order(lengths)
+        batches = [order[s:s + 10].tolist() for s in range(0, len(order), 10)]
+        tot, audio = 0, {}
+        for b in eng.deal_batches(len(batches)):
+            T = int(sum(2 * int(lengths[i]) for i in batches[b]))
             if T == 0:
+                for i in batches[b]:
+                    audio[i] = torch.empty(0, device=dev)
                 continue
             z = torch.randn(1, 192, T, device=dev)
-            voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge.expand(-1, -1, T).contiguous())
+            o = voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge.expand(-1, -1, T).contiguous())[0, 0]
+            pos = 0
+            for i in batches[b]:
+                n_ = 2 * int(lengths[i]) * voc.samples_per_frame
+                audio[i] = o[pos:pos + n_]
+                pos += n_
             tot += T
-        return tot
+        return audio, tot
 
     def vocode_batch(items):
         """one time-concatenated vocoder batch (completion order): the overlapped engine calls this on its side stream"""
@@ -560,7 +569,15 @@ def run_cb(a):
         if (not a.overlap):
             pred, idx = eng.run_gpt(xs, ys, bs, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             torch.cuda.synchronize(dev); s1 = time.perf_counter()
-            frames = vocode(list(zip(idx.tolist(), pred)))
+            # every rank learns every request's tokens (ids: a few hundred KB), vocodes the batches dealt to it, and the
+            # samples meet on rank 0 -- what TTS.infer_batched does between its GPT and its return (tts.py)
+            tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, n_req, dst=None)
+            eng._retire_cursors(None)
+            audio, frames = vocode(tokens)
+            full = eng.exchange(audio, n_req, dst=0)
+            if timed_idx is not None and full is not None:
+                acc["gathered_samples"] = acc.get("gathered_samples", 0) + int(sum(t.numel() for t in full))
+            del full, audio
         else:
             res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
             s1 = time.perf_counter()
@@ -597,6 +614,9 @@ def run_cb(a):
                               "overlapped with the slot loop on a side stream, batches of 10 in completion order",
                    "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "
                                   "speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
+        "dist": dist_info(a, world, book),
+        "gather": None if a.overlap else "inside the timed step: token ids all-gathered (device), every request's samples sent to rank 0 "
+                                         "(device, point-to-point); %d samples arrived on rank 0 over the %d timed steps" % (acc.get("gathered_samples", 0), a.steps),
         "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
         "tokens_per_step": tok_all / a.steps, "mean_tokens_per_request": tok_all / a.steps / n_req,
         "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"],

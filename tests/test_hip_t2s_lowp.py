@@ -126,11 +126,13 @@ def test_bf16_greedy_tokens_bench_shape_vs_bf16_oracle(dev):
         assert len(ref) == 250 and len(tok) == 250
         first = _first_mismatch(tok, ref)
         if first is not None:
+            print("request %d: first divergence at step %d, oracle top-1/top-2 gap there %.3e (gate %.0e); smallest gap before it %.3e"
+                  % (i, first, o.margins[first + 1], TOKEN_MARGIN, min(o.margins[:first + 1])))
             assert o.margins[first + 1] < TOKEN_MARGIN, (i, first, o.margins[first + 1])
         agree.append(250 if first is None else first)
         del m
     print("bf16 tokens equal to the bf16 oracle for the first %s of 250 steps" % agree)
-    assert max(agree) >= 25, agree
+    assert min(agree) >= 25, agree     # BOTH requests: a matched prefix far beyond the suppression window
 
 
 @pytest.mark.parametrize("dtype,numerics", [(torch.float32, "fp32"), (torch.bfloat16, "bf16")])
