@@ -6,7 +6,9 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -21,9 +23,13 @@ struct Arena {
     std::vector<std::pair<char*, size_t>> blocks;
     size_t used = 0;
     size_t count = 0;
+    std::unordered_map<void*, size_t> live;      // carved pieces by address
+    std::multimap<size_t, void*> freed;          // pieces given back (a re-bound state's staging, a re-loaded tensor's fragments,
+                                                 // grown scratch): handed out again by size, so a handle that is re-bound or
+                                                 // re-loaded for its whole life does not grow
 };
 static std::mutex g_mu;
-static std::vector<std::pair<char*, size_t>> g_all;
+static std::vector<std::pair<std::pair<char*, size_t>, Arena*>> g_all;
 static thread_local Arena* g_cur = nullptr;
 static hipError_t amalloc(void** p, size_t n) {
     if (!g_cur) return hipMalloc(p, n);
@@ -31,6 +37,16 @@ static hipError_t amalloc(void** p, size_t n) {
     static const size_t skew = getenv("GSV_ARENA_SKEW") ? (size_t)atol(getenv("GSV_ARENA_SKEW")) : 0;
     constexpr size_t kBlock = (size_t)256 << 20;
     Arena& a = *g_cur;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = a.freed.lower_bound(n);        // smallest given-back piece that fits, if it is not wastefully large
+        if (it != a.freed.end() && it->first <= n + std::max<size_t>(n / 4, align)) {
+            *p = it->second;
+            a.live[*p] = it->first;
+            a.freed.erase(it);
+            return hipSuccess;
+        }
+    }
     const size_t sk = (a.count * skew) % align;
     size_t start = (a.used + align - 1) / align * align + sk;
     if (a.blocks.empty() || start + n > a.blocks.back().second) {
@@ -42,18 +58,28 @@ static hipError_t amalloc(void** p, size_t n) {
         a.used = 0;
         start = sk;
         std::lock_guard<std::mutex> lk(g_mu);
-        g_all.emplace_back(base, sz);
+        g_all.push_back({{base, sz}, &a});
     }
     *p = a.blocks.back().first + start;
     a.used = start + n;
     a.count++;
+    std::lock_guard<std::mutex> lk(g_mu);
+    a.live[*p] = n;
     return hipSuccess;
 }
 static hipError_t afree(void* p) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         for (auto& b : g_all)
-            if ((char*)p >= b.first && (char*)p < b.first + b.second) return hipSuccess;
+            if ((char*)p >= b.first.first && (char*)p < b.first.first + b.first.second) {
+                Arena& a = *b.second;
+                auto it = a.live.find(p);
+                if (it != a.live.end()) {
+                    a.freed.emplace(it->second, p);
+                    a.live.erase(it);
+                }
+                return hipSuccess;
+            }
     }
     return hipFree(p);
 }
@@ -61,9 +87,12 @@ static void release(Arena& a) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& b : a.blocks) {
         (void)hipFree(b.first);
-        g_all.erase(std::remove(g_all.begin(), g_all.end(), b), g_all.end());
+        g_all.erase(std::remove_if(g_all.begin(), g_all.end(), [&](const std::pair<std::pair<char*, size_t>, Arena*>& e) { return e.first == b; }),
+                    g_all.end());
     }
     a.blocks.clear();
+    a.live.clear();
+    a.freed.clear();
     a.used = 0;
 }
 struct Scope {
@@ -629,16 +658,23 @@ __global__ __launch_bounds__(256) void t2s_commit_kernel(CommitArgs a) {
 // The result still contains the dependent-launch gap that every kernel of a real step pays too.
 template <typename WT>
 static int t2s_time_impl(gsv_t2s* h, T2SBound* b, int iters, float* out_ms, hipStream_t st) {
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    struct Guard {      // whatever path leaves this function: no event, graph or executable graph stays behind
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ~Guard() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } gd;
+    HIPCHK(hipEventCreate(&gd.e0));
+    HIPCHK(hipEventCreate(&gd.e1));
     const int NL = h->cfg.n_layer;
     for (int cls = 0; cls < 4; ++cls) {
         hipGraph_t g = nullptr;
-        hipGraphExec_t exec = nullptr;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = GSV_OK;
+        int rc = GSV_OK;                      // nothing between Begin and End returns: a stream left capturing is lost to the handle
         for (int l = 0; l < NL && !rc; ++l) {
             if (cls == 0) t2s_launch_attn<WT>(h, b->st, l, h->xcur, h->cap_stream);
             if (cls == 1) t2s_launch_ffn<WT>(h, b->st, l, h->cap_stream);
@@ -648,21 +684,20 @@ static int t2s_time_impl(gsv_t2s* h, T2SBound* b, int iters, float* out_ms, hipS
         hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&gd.exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
-        if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-        HIPCHK(hipGraphLaunch(exec, st));                    // warm-up
-        HIPCHK(hipEventRecord(e0, st));
-        for (int it = 0; it < iters; ++it) HIPCHK(hipGraphLaunch(exec, st));
-        HIPCHK(hipEventRecord(e1, st));
-        HIPCHK(hipEventSynchronize(e1));
+        if (e != hipSuccess) { gd.exec = nullptr; return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        HIPCHK(hipGraphLaunch(gd.exec, st));                    // warm-up
+        HIPCHK(hipEventRecord(gd.e0, st));
+        for (int it = 0; it < iters; ++it) HIPCHK(hipGraphLaunch(gd.exec, st));
+        HIPCHK(hipEventRecord(gd.e1, st));
+        HIPCHK(hipEventSynchronize(gd.e1));
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        HIPCHK(hipEventElapsedTime(&ms, gd.e0, gd.e1));
         out_ms[cls] = ms / (float)(iters * NL);
-        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphExecDestroy(gd.exec);
+        gd.exec = nullptr;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return GSV_OK;
 }
 
@@ -922,6 +957,13 @@ int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped) {
 }
 
 int gsv_t2s_batched_min(gsv_t2s* h) { return h && h->cfg.dtype == GSV_BF16 ? h->batched_min : 0x7fffffff; }
+
+size_t gsv_t2s_device_bytes(gsv_t2s* h) {
+    if (!h) return 0;
+    size_t n = 0;
+    for (auto& b : h->arena.blocks) n += b.second;
+    return n;
+}
 
 int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
     if (!h) return fail(GSV_ERR_ARG, "null handle");

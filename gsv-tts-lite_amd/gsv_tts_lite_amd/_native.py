@@ -19,7 +19,7 @@ EXPORTS = [
     "gsv_version", "gsv_last_error",
     "gsv_t2s_create", "gsv_t2s_destroy", "gsv_t2s_load_tensor", "gsv_t2s_finalize", "gsv_t2s_bind_state",
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_set_eos_mirror", "gsv_t2s_prefill_slots", "gsv_t2s_prefill_slots_staged", "gsv_t2s_commit_slots", "gsv_t2s_decode_hidden",
-    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min",
+    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min", "gsv_t2s_device_bytes",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow_dec_graph", "gsv_voc_resample_linear", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p",
     "gsv_align_workspace", "gsv_align_viterbi",
@@ -111,6 +111,8 @@ def lib():
         fn.restype = i
     L.gsv_t2s_prefill_workspace.argtypes = [vp, i, i]
     L.gsv_t2s_prefill_workspace.restype = sz
+    L.gsv_t2s_device_bytes.argtypes = [vp]
+    L.gsv_t2s_device_bytes.restype = sz
     L.gsv_voc_workspace.argtypes = [vp, i]
     L.gsv_voc_workspace.restype = sz
     L.gsv_voc_enc_workspace.argtypes = [vp, i, i]

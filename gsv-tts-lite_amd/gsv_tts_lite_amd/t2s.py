@@ -108,37 +108,37 @@ class Text2SemanticDecoder:
         return self
 
     # ------------------------------------------------------------------ runtime
-    _RUNTIME_FIELDS = ("_h", "k_cache_root", "v_cache_root", "_rt", "cuda_graph_buckets", "batched_min", "_ws")
+    _RUNTIME_FIELDS = ("_h", "k_cache_root", "v_cache_root", "_rt", "cuda_graph_buckets", "batched_min", "_ws", "_ws_staged")
 
     @torch.inference_mode()
     def initialize_runtime(self, dtype, device, gpt_cache, tune_placement=None):
-        """t2s_model.py:210-298 (`_build_runtime`), plus a placement pick: the decode step of a full-size model lands at its
-        usual time or 3-9 % above it depending on where the allocator happens to put the handle's buffers and the state
-        tensors (measured: about one instance in four; contiguous arenas are worse), so `tune_placement`
-        instances are built (default 4 for models of >= 12 layers, GSV_TUNE_PLACEMENT overrides, 0 / 1 = off), each is
-        timed on 40 replays of its smallest batch size's step, the fastest is kept and the others are released."""
+        """t2s_model.py:210-298 (`_build_runtime`).  `tune_placement` > 1 (GSV_TUNE_PLACEMENT; default off) is a diagnostic:
+        that many instances are built, each timed on 40 replays of its smallest batch size's step, the fastest kept.  It was the
+        default while a handle's ~450 buffers came from separate allocations and one instance in four decoded 3-9 % slower;
+        the library's per-handle arena (64 KB sub-allocation alignment, gsv_abi.hip) and the one-block state below put every
+        instance at the best time, so a load builds ONE runtime."""
         if tune_placement is None:
-            tune_placement = int(os.environ.get("GSV_TUNE_PLACEMENT", "4" if self.num_layers >= 12 else "1"))
+            tune_placement = int(os.environ.get("GSV_TUNE_PLACEMENT", "1"))
         if tune_placement <= 1:
             return self._build_runtime(dtype, device, gpt_cache)
-        best, losers = None, []
-        for _ in range(tune_placement):
-            self.cuda_graph_buckets, self._rt, self._ws, self._h = {}, {}, None, None
-            self._build_runtime(dtype, device, gpt_cache)
-            t = self._time_step(min(self._rt))
-            cand = (t, {k: getattr(self, k) for k in self._RUNTIME_FIELDS})
-            if best is None or t < best[0]:
-                if best is not None:
-                    losers.append(best)
-                best = cand
-            else:
-                losers.append(cand)
-        for k, v in best[1].items():
-            setattr(self, k, v)
-        self.placement_times_ms = [best[0]] + [c[0] for c in losers]
-        for _, fields in losers:            # released only now: a freed block would be handed to the next candidate again
-            N.lib().gsv_t2s_destroy(fields["_h"])
-        del losers
+        cands = []
+        try:
+            for _ in range(tune_placement):
+                self.cuda_graph_buckets, self._rt, self._ws, self._ws_staged, self._h = {}, {}, None, None, None
+                self._build_runtime(dtype, device, gpt_cache)
+                cands.append((self._time_step(min(self._rt)), {k: getattr(self, k) for k in self._RUNTIME_FIELDS}))
+                self._h = None
+        finally:                      # also when a build raised half way: every handle but the kept one is released
+            if self._h is not None:   # the instance whose build or timing raised
+                N.lib().gsv_t2s_destroy(self._h)
+                self._h = None
+            cands.sort(key=lambda c: c[0])
+            for _, fields in cands[1:]:
+                N.lib().gsv_t2s_destroy(fields["_h"])
+            if cands:
+                for k, v in cands[0][1].items():
+                    setattr(self, k, v)
+        self.placement_times_ms = [c[0] for c in cands]
         torch.cuda.synchronize(self.device)
 
     def _time_step(self, batch):
@@ -206,22 +206,29 @@ class Text2SemanticDecoder:
             ts = sorted(self.cuda_graph_buckets[b])
             T = ts[-1]
             n = self.num_layers * b * T * self.model_dim
+            # the step's state lives in ONE block, every tensor on a 64 KB boundary: where the small ones land relative to
+            # each other then never depends on what torch's caching allocator has free (the placement lottery of DESIGN 7)
+            spec = [("kv_len", (b,), torch.int64), ("x_len", (b,), torch.int64), ("pre_tokens", (b, T + 1), torch.int64),
+                    ("seen", (b, self.vocab_size), torch.uint8), ("step", (b,), torch.int32), ("eos_at", (b,), torch.int32),
+                    ("logits", (b, self.vocab_size), torch.float32), ("hidden", (b, self.model_dim), torch.float32),
+                    ("tok_override", (b,), torch.int64), ("ctl", (8,), torch.int32), ("fctl", (4,), torch.float32)]
+            al = 65536
+            offs, pos = [], 0
+            for _, shp, dt in spec:
+                offs.append(pos)
+                pos += -(-(int(np.prod(shp)) * torch.empty(0, dtype=dt).element_size()) // al) * al
+            block = torch.zeros(pos + al, dtype=torch.uint8, device=device)
+            base = (-block.data_ptr()) % al
             rt = {
-                "batch": b, "T": T,
+                "batch": b, "T": T, "_state_block": block,
                 "k": self.k_cache_root[:n].view(self.num_layers, b, self.num_head, T, dh),
                 "v": self.v_cache_root[:n].view(self.num_layers, b, self.num_head, T, dh),
-                "kv_len": torch.zeros(b, dtype=torch.int64, device=device),
-                "x_len": torch.zeros(b, dtype=torch.int64, device=device),
-                "pre_tokens": torch.zeros(b, T + 1, dtype=torch.int64, device=device),
-                "seen": torch.zeros(b, self.vocab_size, dtype=torch.uint8, device=device),
-                "step": torch.zeros(b, dtype=torch.int32, device=device),
-                "eos_at": torch.full((b,), -1, dtype=torch.int32, device=device),
-                "logits": torch.zeros(b, self.vocab_size, dtype=torch.float32, device=device),
-                "hidden": torch.zeros(b, self.model_dim, dtype=torch.float32, device=device),
-                "tok_override": torch.zeros(b, dtype=torch.int64, device=device),
-                "ctl": torch.zeros(8, dtype=torch.int32, device=device),
-                "fctl": torch.ones(4, dtype=torch.float32, device=device),
             }
+            for (name, shp, dt), o in zip(spec, offs):
+                nb = int(np.prod(shp)) * torch.empty(0, dtype=dt).element_size()
+                rt[name] = block[base + o: base + o + nb].view(dt).view(*shp)
+            rt["eos_at"].fill_(-1)
+            rt["fctl"].fill_(1.0)
             st = N.T2SState(b, T, *[rt[k].data_ptr() for k in (
                 "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden",
                 "tok_override", "ctl", "fctl")])
@@ -232,6 +239,7 @@ class Text2SemanticDecoder:
             self._rt[b] = rt
             self.cuda_graph_buckets[b] = [Bucket(b, t, rt) for t in ts]
         self._ws = None
+        self._ws_staged = None
         torch.cuda.synchronize(device)
 
     def __del__(self):
@@ -295,7 +303,12 @@ class Text2SemanticDecoder:
         the step also writes into the library's staging (gsv_t2s_prefill_slots_staged); `sl` int32 device slot list"""
         n, lmax, _ = xy.shape
         L = N.lib()
-        ws = self._workspace(L.gsv_t2s_prefill_workspace(self._h, n, lmax))
+        need = L.gsv_t2s_prefill_workspace(self._h, n, lmax)
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr, device=self.device)):
+            # its own workspace, allocated on ITS stream: the prompt pass of the main stream (self._ws) may be running
+            if getattr(self, "_ws_staged", None) is None or self._ws_staged.numel() < need:
+                self._ws_staged = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws_staged
         N.check(L.gsv_t2s_prefill_slots_staged(self._h, batch, sl.data_ptr(), n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
                                                ws.data_ptr(), ws.numel(), stream_ptr))
 
@@ -515,6 +528,11 @@ class Text2SemanticDecoder:
             self._refill_stream = torch.cuda.Stream(device=dev)
         side = self._refill_stream
         main = torch.cuda.current_stream(dev)
+        # the requests' inputs (phoneme ids, prompt tokens, BERT rows) were produced on the caller's stream; the side stream
+        # reads them in embed_prompt BEFORE it waits on any step.  One event orders the inputs, not the steps.
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)
+        side.wait_event(inputs_ready)
         LIVE, PARKED, IDLE = 0, 1, 2
         actual = len(first)
         state = [LIVE] * actual + [IDLE] * (B - actual)

@@ -168,6 +168,12 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
 /* Batch size from which gsv_t2s_decode runs the batched chain (INT_MAX on fp32 handles: never).  Tests mirror the
  * choice in the oracle, whose reduced-precision modes round the operands each path rounds. */
 int gsv_t2s_batched_min(gsv_t2s* h);
+/* Device memory the handle owns, in bytes (its arena's blocks: repacked weights, fragments, scratch, the staging of every
+ * bound state).  Pieces given back inside the handle -- a state re-bound with gsv_t2s_bind_state, a tensor re-loaded with
+ * gsv_t2s_load_tensor, scratch that grew -- are handed out again by size, so re-binding the same shapes or hot-swapping
+ * weights of the same architecture for a handle's whole life leaves this number where it was; all of it is released by
+ * gsv_t2s_destroy. */
+size_t gsv_t2s_device_bytes(gsv_t2s* h);
 /* Measurement aid (bench.py `roofline`): average time in ms of ONE launch of each per-sequence decode-step
  * kernel class {attn, ffn, logits, token}: the class's launches over all layers (every layer streams its own
  * weights, as in a real step) are captured into a hipGraph and replayed `iters` times between two hipEvents on

@@ -73,7 +73,7 @@ def test_fp32_flow_dec_at_500_frames_within_1e3_of_the_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ facade vs oracle tokens
-N_LAYER, EOS_GAIN, SEED = 6, 1.0, 1234
+SEED = 1234
 PROMPT_PH, PROMPT_TOK = 12, 30
 
 
@@ -82,10 +82,10 @@ def _toy_frontend(text):
     return ids, {"word": list(text), "ph": [1] * len(text)}, None, text
 
 
-def _make_tts(dev, gpt_cache):
+def _make_tts(dev, gpt_cache, n_layer, eos_gain):
     from gsv_tts import TTS
     tts = TTS(gpt_cache=gpt_cache, sovits_cache=[50, 55], device=str(dev), dtype="float32")
-    tts.load_gpt_model("synthetic://gpt?seed=%d&n_layer=%d&eos_gain=%s" % (SEED, N_LAYER, EOS_GAIN))
+    tts.load_gpt_model("synthetic://gpt?seed=%d&n_layer=%d&eos_gain=%s" % (SEED, n_layer, eos_gain))
     tts.load_sovits_model("synthetic://sovits?version=v2Pro&seed=%d" % SEED)
     tts.set_text_frontend(_toy_frontend)
     tts.cache_spk_audio("spk.wav", ge=torch.from_numpy(synth.synth_ge(0, 1024)))
@@ -94,21 +94,22 @@ def _make_tts(dev, gpt_cache):
     return tts, x, y
 
 
-def _oracle(gpt_cache):
+def _oracle(gpt_cache, n_layer, eos_gain):
     from oracle import oracle as orc
-    cfg = synth.gpt_config(n_layer=N_LAYER)
-    return orc.T2SOracle(cfg, synth.gpt_weights(cfg, seed=SEED, eos_gain=EOS_GAIN), gpt_cache)
+    cfg = synth.gpt_config(n_layer=n_layer)
+    return orc.T2SOracle(cfg, synth.gpt_weights(cfg, seed=SEED, eos_gain=eos_gain), gpt_cache)
 
 
 def test_tts_infer_audio_equals_oracle_tokens_through_decode(dev):
     cache = [(1, 128), (1, 192)]
-    tts, x1, y = _make_tts(dev, cache)
+    tts, x1, y = _make_tts(dev, cache, 6, 1.0)
     text = "Hello there, this is a test."
     clip = tts.infer("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0)
     ph2 = _toy_frontend(text)[0]
     x = np.asarray(x1.tolist() + ph2, np.int64)
-    tok = _oracle(cache).infer(x, y, np.zeros((len(x), 1024), np.float32), top_k=1, repetition_penalty=1.35)
-    assert 8 < len(tok) < 192 - len(x) - len(y) - 6, "the oracle's utterance must end by EOS for this comparison (%d tokens)" % len(tok)
+    # infer() is deterministic also when the utterance ends by filling the largest bucket (t2s_model.py:425), as this one may
+    tok = _oracle(cache, 6, 1.0).infer(x, y, np.zeros((len(x), 1024), np.float32), top_k=1, repetition_penalty=1.35)
+    assert len(tok) > 8
     vq = next(iter(tts.sovits_models.values())).vq_model
     ge = tts.spk_audio_cache["spk.wav"]["ge"][next(iter(tts.sovits_models))]
     o, _ = vq.decode(_T(tok, dev)[None, None], _T(np.asarray(ph2, np.int64), dev)[None], ge, noise_scale=0.0)
@@ -129,8 +130,8 @@ def test_tts_infer_batched_audio_equals_oracle_tokens_through_batched_decode(dev
     slice_indices), :806-816 (split + trim), :820-865 (silence, per-text concatenation) written out over the oracle's tokens."""
     from gsv_tts_lite_amd.batchmath import balance_order, split_bounds
     slots = 3
-    cache = [(1, 192), (slots, 192)]
-    tts, x1, y = _make_tts(dev, cache)
+    cache = [(1, 320), (slots, 320)]
+    tts, x1, y = _make_tts(dev, cache, 4, 2.0)
     texts = ["First sentence is here.", "Another text, with a comma.", "Third!", "Number four is longer than the others are.",
              "Five.", "Six is the last but one?", "Seven"]
     BS = 3
@@ -138,12 +139,14 @@ def test_tts_infer_batched_audio_equals_oracle_tokens_through_batched_decode(dev
     segs = [t if t[-1] in ".!?," else t + "." for t in texts]            # TTS.py:613 (no cutting: one segment per text)
     ph2 = [_toy_frontend(s)[0] for s in segs]
     xs = [np.asarray(x1.tolist() + p, np.int64) for p in ph2]
-    o = _oracle(cache)
+    o = _oracle(cache, 4, 2.0)
     pred, idx = o.infer_batched(xs, [y] * len(xs), [np.zeros((len(x), 1024), np.float32) for x in xs], top_k=1)
     tokens = [None] * len(xs)
     for p, i in zip(pred, np.asarray(idx).tolist()):
         tokens[i] = np.asarray(p, np.int64)
-    assert all(4 < len(t) < 192 - len(x) - len(y) - 8 for t, x in zip(tokens, xs)), [len(t) for t in tokens]
+    # a request that ends by filling the cache is cut where the 5-step cadence falls, which the staged refill does not keep
+    # (tests/test_hip_engine.py): this comparison needs EOS-terminated requests
+    assert all(4 < len(t) < 320 - len(x) - len(y) - 8 for t, x in zip(tokens, xs)), [len(t) for t in tokens]
     vq = next(iter(tts.sovits_models.values())).vq_model
     ge = tts.spk_audio_cache["spk.wav"]["ge"][next(iter(tts.sovits_models))].squeeze(0)     # [gin, 1]
     lengths = torch.tensor([len(t) for t in tokens])

@@ -688,3 +688,37 @@ def test_token_step_fused_into_layer0_equals_the_token_kernel(dev, dtype):
         assert set(many) == set(ref[2]) and len(many) == 9 + 45
         for i in many:
             assert np.array_equal(many[i], ref[2][i]), (key, i)
+
+
+def test_rebinding_state_and_reloading_weights_do_not_grow_the_handle(dev):
+    """the handle's arena hands given-back pieces out again by size (gsv_t2s_device_bytes): a C-ABI user who re-binds a
+    state per request or hot-swaps weights of the same architecture must not leak device memory until destroy"""
+    import ctypes
+    from gsv_tts_lite_amd import _native as N
+    cfg = synth.gpt_config(n_layer=2)
+    w = synth.gpt_weights(cfg, seed=3)
+    m = _model(cfg, w, [(1, 64), (4, 64)], torch.bfloat16, dev)
+    L = N.lib()
+    x, y, bert, _ = synth.synth_request(1, 5, 9, 11, seed=3)
+    tok0 = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1)[0, 0].cpu().numpy()
+    before = L.gsv_t2s_device_bytes(m._h)
+    assert before > 0
+    for b, rt in m._rt.items():
+        st = N.T2SState(b, rt["T"], *[rt[k].data_ptr() for k in (
+            "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden", "tok_override", "ctl", "fctl")])
+        for _ in range(40):
+            N.check(L.gsv_t2s_bind_state(m._h, ctypes.byref(st)))
+        if b == 1:
+            N.check(L.gsv_t2s_set_eos_mirror(m._h, b, rt["eos_host"].data_ptr()))
+    stream = N.current_stream_ptr(dev)
+    for _ in range(6):     # the same tensors again: fragments and panels are re-packed
+        for name, t in m._weights.items():
+            if name.endswith("position.alpha"):
+                continue
+            d = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            N.check(L.gsv_t2s_load_tensor(m._h, name.encode(), d.data_ptr(), d.numel(), stream))
+        N.check(L.gsv_t2s_finalize(m._h, stream))
+    torch.cuda.synchronize(dev)
+    assert L.gsv_t2s_device_bytes(m._h) == before, (before, L.gsv_t2s_device_bytes(m._h))
+    tok1 = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=1)[0, 0].cpu().numpy()
+    assert np.array_equal(tok0, tok1)
