@@ -4,6 +4,7 @@
 
 #include "abi_common.h"
 #include "flowfuse.h"
+#include "rbfuse.h"
 #include "encp.h"
 #include "voc_kernels.h"
 
@@ -25,6 +26,11 @@ struct VocStage {
     PackedConv up;
     std::vector<VocResBlock> rb;
     int cin = 0, cout = 0, u = 1;
+    // rbfuse.h (bf16 stages of <= 32 channels with the 3 / 7 / 11 resblocks): the stage's 18 convs as A fragments + biases
+    void* rb_w = nullptr;
+    float* rb_b = nullptr;
+    int rb_c = 0;            // 16 or 32 (24 channels run padded to 32), 0 = not fused
+    int rb_wofs[3] = {0, 0, 0};
 };
 
 struct EncLayer {
@@ -215,6 +221,23 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
         if (ru > 0) return ru;
         if (ru < 0)
             if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
+        if (sizeof(AT) == 2 && sg.rb_c && ldo == sg.rb_c) {
+            // <= 32 channels: the three branches and their mean in ONE kernel, intermediates never leave the CU (rbfuse.h)
+            RbFuseArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.X = (const bf16_t*)xu; ra.Y = (bf16_t*)x; ra.W = (const uint4*)sg.rb_w; ra.B = sg.rb_b;
+            for (int j = 0; j < 3; ++j) { ra.wofs[j] = sg.rb_wofs[j]; ra.dil[j] = c.resblock_dilations[j]; }
+            ra.ld = ldo; ra.n_rows = Tn; ra.slope = 0.1f;
+            if (sg.rb_c == 16) {
+                HIPCHK(hipFuncSetAttribute((const void*)rbfuse_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbShape<16>::LDS));
+                hipLaunchKernelGGL(rbfuse_kernel<16>, dim3(cdiv(Tn, RbShape<16>::BN)), dim3(512), RbShape<16>::LDS, st, ra);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void*)rbfuse_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RbShape<32>::LDS));
+                hipLaunchKernelGGL(rbfuse_kernel<32>, dim3(cdiv(Tn, RbShape<32>::BN)), dim3(512), RbShape<32>::LDS, st, ra);
+            }
+            Tc = Tn;
+            continue;
+        }
         if (ldo != sg.cout) HIPCHK(hipMemsetAsync(x, 0, sizeof(AT) * (size_t)Tn * ldo, st));
         // the three resblocks (k = 3, 7, 11) advance in lock step: one launch per conv position
         const AT* cur[3] = {xu, xu, xu};
@@ -743,6 +766,34 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
                 }
             }
         }
+        // one fused kernel for the whole stage (three branches + mean) where the channels allow it
+        if (!rc && sizeof(CT) == 2 && !getenv("GSV_NO_RBFUSE") && (co == 16 || co == 24 || co == 32) && c.n_resblock_kernels == 3 &&
+            c.resblock_kernel_sizes[0] == 3 && c.resblock_kernel_sizes[1] == 7 && c.resblock_kernel_sizes[2] == 11) {
+            const int RC = co == 16 ? 16 : 32;
+            RbPackArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            int ofs = 0;
+            for (int j = 0; j < 3; ++j) {
+                pa.k[j] = c.resblock_kernel_sizes[j];
+                pa.wofs[j] = sg.rb_wofs[j] = ofs;
+                ofs += 6 * (RC == 16 ? RbShape<16>::steps(pa.k[j]) * RbShape<16>::HV : RbShape<32>::steps(pa.k[j]) * RbShape<32>::HV);
+            }
+            for (int j = 0; j < 3 && !rc; ++j)
+                for (int d = 0; d < 3 && !rc; ++d)
+                    for (int which = 0; which < 2 && !rc; ++which) {
+                        const std::string cn = "dec.resblocks." + std::to_string(i * 3 + j) + (which ? ".convs2." : ".convs1.") + std::to_string(d);
+                        if ((rc = get(cn + ".weight", (int64_t)co * co * pa.k[j], &pa.w[j * 6 + d * 2 + which])) ||
+                            (rc = get(cn + ".bias", co, &pa.b[j * 6 + d * 2 + which]))) break;
+                    }
+            if (!rc) {
+                if (!sg.rb_w) HIPCHK(hipMalloc(&sg.rb_w, (size_t)ofs * 1024));
+                if (!sg.rb_b) HIPCHK(hipMalloc(&sg.rb_b, sizeof(float) * 18 * RC));
+                pa.creal = co; pa.W = (uint4*)sg.rb_w; pa.B = sg.rb_b;
+                if (RC == 16) hipLaunchKernelGGL(rbfuse_pack_kernel<16>, dim3(18), dim3(256), 0, st, pa);
+                else hipLaunchKernelGGL(rbfuse_pack_kernel<32>, dim3(18), dim3(256), 0, st, pa);
+                sg.rb_c = RC;
+            }
+        }
         ch = co;
     }
     v->total_up = tm;
@@ -794,6 +845,9 @@ void voc_free(gsv_voc* v) {
     v->post_w = nullptr;
     for (VocStage& s : v->stages) {
         free_conv(s.up);
+        if (s.rb_w) (void)hipFree(s.rb_w);
+        if (s.rb_b) (void)hipFree(s.rb_b);
+        s.rb_w = nullptr; s.rb_b = nullptr; s.rb_c = 0;
         for (VocResBlock& r : s.rb)
             for (int d = 0; d < 3; ++d) { free_conv(r.c1[d]); free_conv(r.c2[d]); }
     }
