@@ -109,18 +109,19 @@ def _calibrate_threads(o, orc):
     """fastest OpenMP team for a 1-row decode step (a GEMV does not scale to hundreds of threads)"""
     avail = _usable_cores()
     xin = np.zeros((1, 512), np.float32)
-    best, best_t = 1, 1e9
-    for nt in [c for c in (4, 8, 16, 32, 64, 128, 256) if c <= avail] or [avail]:
+    best, best_t, sweep = 1, 1e9, {}
+    for nt in sorted(set([c for c in (1, 4, 8, 16, 32, 64, 128, 256) if c <= avail] + [avail])):
         orc.set_num_threads(nt)
         o.decode(xin, 1, [200])
         t0 = time.perf_counter()
         for i in range(3):
             o.decode(xin, 1, [200 + i])
         dt = time.perf_counter() - t0
+        sweep[str(nt)] = round(dt / 3 * 1e3, 3)
         if dt < best_t:
             best, best_t = nt, dt
     orc.set_num_threads(best)
-    return best, avail
+    return best, avail, sweep
 
 
 def cpu_baseline_worker(kind, version):
@@ -140,7 +141,7 @@ def cpu_baseline_worker(kind, version):
         x, y, bert, _ = synth.synth_request(0, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)
         z = synth.hashed_uniform("bench.z", (1, 192, FRAMES), 1234) * np.float32(1.2)
         o = orc.T2SOracle(cfg, gw, [(1, 256), (1, 450)])       # 250 tokens: the cache fills at kv 450
-        best, avail = _calibrate_threads(o, orc)
+        best, avail, sweep = _calibrate_threads(o, orc)
         t0 = time.perf_counter()
         tok = o.infer(x, y, bert, top_k=1)
         t_ar = time.perf_counter() - t0
@@ -152,9 +153,13 @@ def cpu_baseline_worker(kind, version):
         print(json.dumps({
             "value": n / (t_ar + t_v), "unit": "semantic_tokens/s", "cores": best, "kind": "port",
             "sample": "oracle C/OpenMP fp32, %d of %d usable host threads for the AR phase (best of a calibration sweep), "
-                      "%d for the vocoder: one whole utterance = prefill + %d greedy tokens + flow/Generator on all %d frames"
+                      "%d for the vocoder: one whole utterance = prefill + %d greedy tokens + flow/Generator on all %d frames "
+                      "(no enc_p leg: the oracle restates the hot path, not the text / ssl encoder)"
                       % (best, avail, min(avail, max(best, 16)), n, FRAMES),
-            "ar_tokens_per_s": n / t_ar, "vocoder_audio_s_per_s": (FRAMES / 50.0) / t_v}))
+            "ar_tokens_per_s": n / t_ar, "vocoder_audio_s_per_s": (FRAMES / 50.0) / t_v,
+            "decode_step_ms_by_threads": sweep, "usable_threads": avail,
+            "note": "decode_step_ms_by_threads = one 24-layer decode step (kv 200) of the oracle per OpenMP team size on this host, the sweep "
+                    "`cores` was picked from (a 1-row GEMV does not scale to every core); the all-threads figure is its last entry"}))
     else:
         gw = synth.gpt_weights(cfg, seed=1234, eos_gain=4.0)
         nreq, slots = 12, 8
@@ -445,6 +450,28 @@ def run_single(a):
                 torch.cuda.synchronize(dev)
                 ta.append((time.perf_counter() - s0) * 1e3)
             out["ttfa_ms_p50"] = float(np.median(ta))
+            # end to end as SURVEY 8(d) words it (GPT + enc_p + flow_dec): the utterance's OWN tokens through SynthesizerTrn.decode
+            # -- quantizer lookup, device enc_p, noise draw, flow + Generator in one library call -- instead of a synthetic z_p
+            from gsv_tts_lite_amd.sovits import SynthesizerTrn
+            vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+            vq.load_state_dict(synth.sovits_weights(hps, seed=1234))
+            vq.initialize_runtime(dtype, dev, [])
+            txt = torch.from_numpy(synth.synth_request(rank * 100003, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)[3])[None].to(dev)
+            for _ in range(2):
+                vq.decode(t2s.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW), txt, ge, noise_scale=0.5)
+            torch.cuda.synchronize(dev); s0 = time.perf_counter()
+            nrep, t_dec = 5, 0.0
+            for _ in range(nrep):
+                tk = t2s.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
+                torch.cuda.synchronize(dev); s1 = time.perf_counter()
+                au, _ = vq.decode(tk, txt, ge, noise_scale=0.5)
+                torch.cuda.synchronize(dev); t_dec += time.perf_counter() - s1
+            s2 = time.perf_counter()
+            out["value_with_enc_p"] = nrep * N_NEW / (s2 - s0)
+            out["decode_ms"] = t_dec / nrep * 1e3
+            out["value_with_enc_p_note"] = ("semantic tokens/s of GPT + SynthesizerTrn.decode (enc_p + noise + flow + Generator, noise_scale 0.5) on "
+                                            "the utterance's own %d tokens, %d utterances; `value` feeds the vocoder a synthetic z_p" % (N_NEW, nrep))
+            del vq
             # the vocoder as TTS.infer_batched feeds it (TTS.py:728-764): 10 utterances time-concatenated, per-frame ge
             T10 = 10 * FRAMES
             z10 = z_p.repeat(1, 1, 10).contiguous()
@@ -556,6 +583,28 @@ def run_cb(a):
             tot += T
         return audio, tot
 
+    def vocode_decode(tokens, vq):
+        """the same batches through SynthesizerTrn.decode: the requests' own tokens and target phonemes, per-token ge, slice_indices
+        (quantizer lookup + device enc_p + noise + flow + Generator in one library call) -- exactly TTS.infer_batched's call"""
+        from gsv_tts_lite_amd.batchmath import balance_order
+        lengths = torch.tensor([len(p) for p in tokens])
+        order = balance_order(lengths)
+        batches = [order[s:s + 10].tolist() for s in range(0, len(order), 10)]
+        tot = 0
+        for b in eng.deal_batches(len(batches)):
+            oi = [i for i in batches[b] if int(lengths[i]) > 0]
+            if not oi:
+                continue
+            ln = [int(lengths[i]) for i in oi]
+            ph = [xs[i][40:] for i in oi]
+            ends = torch.cumsum(torch.tensor([len(p) for p in ph]), 0)
+            pairs = torch.stack([ends - torch.tensor([len(p) for p in ph]), ends], dim=1).to(dev)
+            sl = torch.repeat_interleave(pairs, (torch.tensor(ln) * 2).to(dev), dim=0)
+            vq.decode(torch.cat([tokens[i] for i in oi])[None, None], torch.cat(ph)[None], ge.expand(-1, -1, sum(ln)), noise_scale=0.5,
+                      cuda_graph=False, slice_indices=sl)
+            tot += 2 * sum(ln)
+        return tot
+
     def vocode_batch(items):
         """one time-concatenated vocoder batch (completion order): the overlapped engine calls this on its side stream"""
         T = int(sum(2 * len(p) for _, p in items))
@@ -623,6 +672,31 @@ def run_cb(a):
         "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
         "rank0_requests_served_per_step": acc["mine"] / a.steps,
     }
+    if (not a.no_extras) and (not a.overlap):
+        # one more pass over the queue with the vocoder stage as TTS.infer_batched runs it: decode() on the requests' own tokens
+        # (every rank takes part: the token exchange is a collective)
+        try:
+            from gsv_tts_lite_amd.sovits import SynthesizerTrn
+            vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+            vq.load_state_dict(synth.sovits_weights(hps, seed=1234))
+            vq.initialize_runtime(vdtype, dev, [])
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            q0 = time.perf_counter()
+            pred, idx = eng.run_gpt(xs, ys, bs, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, n_req, dst=None)
+            eng._retire_cursors(None)
+            vocode_decode(tokens, vq)
+            torch.cuda.synchronize(dev)
+            from gsv_tts_lite_amd import scheduler
+            dt = scheduler.max_over_ranks(time.perf_counter() - q0, device=dev)
+            out["value_with_enc_p"] = float(sum(len(p) for p in tokens)) / dt
+            out["value_with_enc_p_note"] = ("one pass over the queue with SynthesizerTrn.decode (enc_p + noise + flow + Generator, per-token ge, "
+                                            "slice_indices) as the vocoder stage instead of flow_dec on a synthetic z_p; no audio gather in it")
+            del vq
+        except Exception as e:  # noqa: BLE001
+            log("value_with_enc_p pass failed: %r" % (e,))
     if rank == 0 and not a.no_extras:
         # BASELINE's "p50 TTFT ... bs=32": the first `slots` requests of the queue arrive together -> packed prompt pass of
         # all of them + the first decode step (every request's first token exists), outside the timed region

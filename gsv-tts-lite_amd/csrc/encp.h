@@ -66,13 +66,15 @@ static __global__ __launch_bounds__(256) void encp_ln_sum_kernel(const float* __
 }
 
 // a + b (+ per-row or broadcast fp32 row g) -> bf16 : the MRTE sum  attn_out + ssl_enc + ge  (mrte_model.py:35-36)
-static __global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg,
+// g row of frame r: r >> gshift (per-TOKEN conditioning rows serve both of a token's frames: the x2 nearest upsampling of ge,
+// models.py:389, as an index instead of a copy)
+static __global__ void encp_add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ g, int ldg, int gshift,
                                  bf16_t* __restrict__ y, int rows, int C) {
     const size_t n = (size_t)rows * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / C;
         const int c = (int)(i % C);
-        y[i] = f32_to_bf16(bf16_to_f32(a[i]) + bf16_to_f32(b[i]) + g[(ldg ? r * (size_t)ldg : (size_t)0) + c]);
+        y[i] = f32_to_bf16(bf16_to_f32(a[i]) + bf16_to_f32(b[i]) + g[(ldg ? (r >> gshift) * (size_t)ldg : (size_t)0) + c]);
     }
 }
 
@@ -336,13 +338,13 @@ static __global__ __launch_bounds__(256) void encp_ln_f32_kernel(float* x, const
     for (int c = lane; c < C; c += 64) { x[(size_t)row * C + c] = v[n] * rs * gamma[c] + beta[c]; ++n; }
 }
 
-static __global__ void encp_add3_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g, int ldg,
+static __global__ void encp_add3_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g, int ldg, int gshift,
                                             float* __restrict__ y, int rows, int C) {
     const size_t n = (size_t)rows * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / C;
         const int c = (int)(i % C);
-        y[i] = a[i] + b[i] + g[(ldg ? r * (size_t)ldg : (size_t)0) + c];
+        y[i] = a[i] + b[i] + g[(ldg ? (r >> gshift) * (size_t)ldg : (size_t)0) + c];
     }
 }
 

@@ -40,6 +40,8 @@ struct EncLayer {
 struct EncP {
     bool ready = false;
     PackedConv ssl_proj, c_pre, text_pre, c_post, proj, xq, xkv, xo;
+    PackedConv ge512;                // ge_to512 (v2Pro / v2ProPlus, models.py:394): Linear gin -> 512 on the speaker embedding
+    bool has_ge512 = false;
     float *text_emb = nullptr, *codebook = nullptr;
     int n_text = 0, n_code = 0;
     std::vector<EncLayer> ssl, text, enc2;
@@ -401,13 +403,16 @@ int encp_finalize(gsv_voc* v, std::vector<float*>& temps, hipStream_t st) {
     if (int rc = stacked(E.xkv, {m + "cross_attention.conv_k", m + "cross_attention.conv_v"}, 512, 512)) return rc;
     if (int rc = conv(E.xo, m + "cross_attention.conv_o", 512, 512, 1)) return rc;
     if (int rc = conv(E.proj, "enc_p.proj", 2 * v->cfg.inter_channels, Hc, 1)) return rc;
+    E.has_ge512 = v->staged.count("ge_to512.weight") != 0;
+    if (E.has_ge512)
+        if (int rc = conv(E.ge512, "ge_to512", 512, v->cfg.gin_channels, 1)) return rc;
     E.ready = true;
     return GSV_OK;
 }
 
 void encp_free(gsv_voc* v) {
     EncP& E = v->enc;
-    for (PackedConv* p : {&E.ssl_proj, &E.c_pre, &E.text_pre, &E.c_post, &E.proj, &E.xq, &E.xkv, &E.xo}) free_conv(*p);
+    for (PackedConv* p : {&E.ssl_proj, &E.c_pre, &E.text_pre, &E.c_post, &E.proj, &E.xq, &E.xkv, &E.xo, &E.ge512}) free_conv(*p);
     for (auto* Ls : {&E.ssl, &E.text, &E.enc2})
         for (EncLayer& L : *Ls) { free_conv(L.qkv); free_conv(L.o); free_conv(L.c1); free_conv(L.c2); }
     for (float* p : E.owned) (void)hipFree(p);
@@ -490,7 +495,7 @@ int encp_encoder(gsv_voc* v, std::vector<EncLayer>& Ls, bf16_t* x, int R, EncWs&
     return GSV_OK;
 }
 
-int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg,
+int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg, int gshift,
              const int64_t* slice, float* m_p, float* logs_p, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
     EncP& E = v->enc;
     const int Hc = v->cfg.hidden_channels, C = v->cfg.inter_channels, T = 2 * n_codes;
@@ -516,7 +521,7 @@ int encp_run(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text,
     hipLaunchKernelGGL(encp_attn_kernel<128>, dim3(4, cdiv(T, 32)), dim3(256), encp_attn_lds_bytes<128>(), st, a);
     if (int rc = enc_gemm(E.xo, w.xatt, 512, T, true, 0, w.xo, 512, false, 1, 0, st)) return rc;
     hipLaunchKernelGGL(encp_add3_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const bf16_t*)w.xo, (const bf16_t*)w.ssl512, ge512,
-                       Tg == 1 ? 0 : 512, w.xsum, T, 512);
+                       Tg == 1 ? 0 : 512, gshift, w.xsum, T, 512);
     if (int rc = enc_gemm(E.c_post, w.xsum, 512, T, true, 0, w.y, Hc, false, 1, 0, st)) return rc;
     if (int rc = encp_encoder(v, E.enc2, w.y, T, w, st)) return rc;
     if (int rc = enc_gemm(E.proj, w.y, Hc, T, true, 0, w.stats, 2 * C, true, 1, 0, st)) return rc;
@@ -577,7 +582,7 @@ int encp_encoder_f32(gsv_voc* v, std::vector<EncLayer>& Ls, float* x, int R, Enc
     return GSV_OK;
 }
 
-int encp_run_f32(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg,
+int encp_run_f32(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge512, int Tg, int gshift,
                  const int64_t* slice, float* m_p, float* logs_p, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
     EncP& E = v->enc;
     const int Hc = v->cfg.hidden_channels, C = v->cfg.inter_channels, T = 2 * n_codes;
@@ -595,7 +600,7 @@ int encp_run_f32(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* t
     if (int rc = encp_attn_f32(w.xq, 512, 0, w.xkv, w.xkv, 1024, 0, 512, w.xatt, 512, T, P, 4, 128, nullptr, nullptr, slice, attn, st)) return rc;
     if (int rc = encp_dense_f32(E.xo, w.xatt, 512, T, w.xo, 512, ACT_NONE, nullptr, st)) return rc;
     hipLaunchKernelGGL(encp_add3_f32_kernel, dim3(std::min(2048, cdiv(T * 512, 256))), dim3(256), 0, st, (const float*)w.xo, (const float*)w.ssl512, ge512,
-                       Tg == 1 ? 0 : 512, w.xsum, T, 512);
+                       Tg == 1 ? 0 : 512, gshift, w.xsum, T, 512);
     if (int rc = encp_dense_f32(E.c_post, w.xsum, 512, T, w.y, Hc, ACT_NONE, nullptr, st)) return rc;
     if (int rc = encp_encoder_f32(v, E.enc2, w.y, T, w, st)) return rc;
     if (int rc = encp_dense_f32(E.proj, w.y, Hc, T, w.stats, 2 * C, ACT_NONE, nullptr, st)) return rc;
@@ -887,8 +892,9 @@ int gsv_voc_load_tensor(gsv_voc* v, const char* name, const float* data, int64_t
     if (!v || !name || !data || numel < 1) return fail(GSV_ERR_ARG, "null argument");
     if (v->finalized) return fail(GSV_ERR_STATE, "vocoder already finalized");
     std::string n(name);
-    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0 && n.compare(0, 6, "enc_p.") != 0 && n.compare(0, 10, "quantizer.") != 0)
-        return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow / dec / enc_p / quantizer", name);
+    if (n.compare(0, 4, "dec.") != 0 && n.compare(0, 5, "flow.") != 0 && n.compare(0, 6, "enc_p.") != 0 && n.compare(0, 10, "quantizer.") != 0 &&
+        n.compare(0, 9, "ge_to512.") != 0)
+        return fail(GSV_ERR_ARG, "tensor '%s' is not part of flow / dec / enc_p / quantizer / ge_to512", name);
     auto it = v->staged.find(n);
     if (it != v->staged.end()) { (void)hipFree(it->second.first); v->staged.erase(it); }
     float* p;
@@ -919,8 +925,8 @@ int gsv_voc_enc_p(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* 
     if (!codes || !text || !ge512 || !m_p || !logs_p || !workspace) return fail(GSV_ERR_ARG, "null argument");
     if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != 2 * n_codes)) return fail(GSV_ERR_ARG, "enc_p: bad lengths");
     if (v->cfg.dtype != GSV_BF16)
-        return encp_run_f32(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
-    return encp_run(v, codes, n_codes, text, n_text, ge512, Tg, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
+        return encp_run_f32(v, codes, n_codes, text, n_text, ge512, Tg, 0, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
+    return encp_run(v, codes, n_codes, text, n_text, ge512, Tg, 0, slice_indices, m_p, logs_p, attn, workspace, workspace_bytes, S(stream));
 }
 
 size_t gsv_voc_workspace(gsv_voc* v, int T) {
@@ -981,6 +987,191 @@ int gsv_voc_resample_linear(const float* x, int C, int T_in, float* y, int T_out
     hipLaunchKernelGGL(resample_linear_kernel, dim3(cdiv(T_out, 256), C), dim3(256), 0, S(stream), x, C, T_in, y, T_out);
     HIPCHK(hipGetLastError());
     return GSV_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// SynthesizerTrn.decode (SoVITS/models.py:385-429) in one call
+// =============================================================================================
+namespace {
+
+__device__ __forceinline__ uint32_t dec_lowbias32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+// standard normal for element `i` of the stream `seed`: Box-Muller over two counter-based uniforms (lowbias32 of the element
+// index mixed with the seed halves) -- replayable, no generator state; oracle.device_normal restates it
+__device__ __forceinline__ float dec_normal(uint32_t seed_lo, uint32_t seed_hi, uint32_t i) {
+    const uint32_t a = dec_lowbias32(dec_lowbias32(i * 0x9E3779B1u ^ seed_lo) + seed_hi);
+    const uint32_t b = dec_lowbias32(dec_lowbias32(i * 0x85EBCA77u ^ seed_hi ^ 0x68E31DA4u) + seed_lo);
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// streaming (models.py:209-215, applied to the projected statistics: proj is 1x1 affine, so it commutes): drop the first
+// `start` frames, cross-fade the first `ov` kept frames with the previous chunk's tail
+__global__ void dec_slice_xfade_kernel(const float* __restrict__ in, int T_in, int start, const float* __restrict__ prev, int has_prev, int ov,
+                                       float* __restrict__ out, int Tp, int C2) {
+    const size_t n = (size_t)C2 * Tp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / Tp), j = (int)(i % Tp);
+        float v = in[(size_t)c * T_in + start + j];
+        if (has_prev && j < ov) {
+            const float a = ov > 1 ? (float)j / (float)(ov - 1) : 0.f;       // torch.linspace(0, 1, ov)
+            v = prev[(size_t)c * ov + j] * (1.0f - a) + v * a;
+        }
+        out[i] = v;
+    }
+}
+__global__ void dec_keep_tail_kernel(const float* __restrict__ x, int Tp, int ov, float* __restrict__ state, int C2) {
+    const int n = C2 * ov;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c = i / ov, j = i % ov;
+        state[i] = x[(size_t)c * Tp + (Tp - ov) + j];
+    }
+}
+// z_p = m_p + randn * exp(logs_p) * noise_scale (models.py:404); stats = [m_p | logs_p] channels-first [2C][T]; mask = ones
+__global__ void dec_zp_kernel(const float* __restrict__ stats, int C, int T, float noise_scale, uint32_t seed_lo, uint32_t seed_hi,
+                              float* __restrict__ z, float* __restrict__ mask) {
+    const size_t n = (size_t)C * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = stats[i];
+        if (noise_scale != 0.f) v += dec_normal(seed_lo, seed_hi, (uint32_t)i) * expf(stats[n + i]) * noise_scale;
+        z[i] = v;
+        if (i < (size_t)T) mask[i] = 1.0f;
+    }
+}
+// per-token ge [gin][Tg] -> per-frame [gin][T_out]: x2 nearest (models.py:389), then F.interpolate(mode="nearest") to the
+// resampled length (models.py:402): frame j reads column min(floor(j * (2 Tg / T_out)), 2 Tg - 1) / 2
+__global__ void dec_ge_frames_kernel(const float* __restrict__ ge, int gin, int Tg, float* __restrict__ out, int T_out, int resized) {
+    const size_t n = (size_t)gin * T_out;
+    const float scale = (float)(2 * Tg) / (float)T_out;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / T_out), j = (int)(i % T_out);
+        const int f = resized ? min((int)floorf((float)j * scale), 2 * Tg - 1) : j;
+        out[i] = ge[(size_t)c * Tg + (f >> 1)];
+    }
+}
+
+struct DecWs {
+    float *z_p, *mask, *ge_fr, *out_static;  // what the captured flow + Generator pass reads / writes: first, so their
+    void* voc; size_t voc_bytes;             // addresses depend on T_out / Tg only
+    void* ge_cl; float *ge512, *stats, *stats_s, *stats_r;
+    void* enc; size_t enc_bytes;
+    size_t bytes;
+};
+DecWs dec_layout(gsv_voc* v, int n_codes, int P, int Tg, int Tp, int T_out, char* base) {
+    const gsv_voc_config& c = v->cfg;
+    const int C = c.inter_channels, T = 2 * n_codes;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    DecWs w;
+    const int Tgv = Tg == 1 ? 1 : T_out;
+    w.z_p = (float*)take(sizeof(float) * (size_t)C * T_out);
+    w.mask = (float*)take(sizeof(float) * (size_t)T_out);
+    w.ge_fr = (float*)take(sizeof(float) * (size_t)c.gin_channels * Tgv);
+    w.out_static = (float*)take(sizeof(float) * (size_t)T_out * v->total_up);
+    w.voc_bytes = c.dtype == GSV_BF16 ? voc_layout<bf16_t>(v, T_out, Tgv, nullptr).bytes : voc_layout<float>(v, T_out, Tgv, nullptr).bytes;
+    w.voc = take(w.voc_bytes);
+    w.ge_cl = take(sizeof(float) * (size_t)Tg * c.gin_channels);
+    w.ge512 = (float*)take(sizeof(float) * (size_t)Tg * 512);
+    w.stats = (float*)take(sizeof(float) * (size_t)2 * C * T);
+    w.stats_s = (float*)take(sizeof(float) * (size_t)2 * C * Tp);
+    w.stats_r = (float*)take(sizeof(float) * (size_t)2 * C * T_out);
+    w.enc_bytes = c.dtype == GSV_BF16 ? encp_layout(v, T, P, nullptr).bytes : encp_layout_f32(v, T, P, nullptr).bytes;
+    w.enc = take(w.enc_bytes);
+    w.bytes = off;
+    return w;
+}
+
+inline int dec_lengths(int n_codes, float speed, int valid_start, int* Tp, int* T_out) {
+    const int T = 2 * n_codes;
+    *Tp = T - valid_start;
+    *T_out = speed == 1.0f ? *Tp : (int)((float)*Tp / speed) + 1;      // models.py:217: int(T / speed) + 1
+    return *Tp >= 1 && *T_out >= 1;
+}
+
+template <typename AT>
+int voc_decode_impl(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge, int Tg, const int64_t* slice,
+                    float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len, float* overlap_state,
+                    int has_overlap, int use_graph, float* out, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
+    const gsv_voc_config& c = v->cfg;
+    const int C = c.inter_channels, gin = c.gin_channels, T = 2 * n_codes;
+    const bool stream = overlap_len > 0;
+    int Tp, T_out;
+    if (!dec_lengths(n_codes, speed, valid_start, &Tp, &T_out)) return fail(GSV_ERR_ARG, "decode: nothing left after valid_start %d", valid_start);
+    if (stream && (Tg != 1 || !overlap_state || overlap_len > Tp)) return fail(GSV_ERR_ARG, "decode: streaming needs a broadcast ge, a state buffer and overlap_len <= frames");
+    DecWs w = dec_layout(v, n_codes, P, Tg, Tp, T_out, (char*)ws);
+    if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "decode workspace %zu < %zu", ws_bytes, w.bytes);
+    EncP& E = v->enc;
+    // ---- conditioning of enc_p: ge_to512(ge) for v2Pro / v2ProPlus (models.py:394), ge itself (512 channels) otherwise
+    const float* g512;
+    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(gin, 32)), dim3(256), 0, st, ge, (AT*)w.ge_cl, gin, Tg, gin);
+    if (E.has_ge512) {
+        if (int rc = run_cond<AT>(E.ge512, w.ge_cl, gin, Tg, w.ge512, 512, st)) return rc;
+        g512 = w.ge512;
+    } else {
+        if (gin != 512) return fail(GSV_ERR_STATE, "decode: %d-channel ge and no ge_to512 tensors", gin);
+        hipLaunchKernelGGL((cf_to_cl_kernel<float>), dim3(cdiv(Tg, 32), cdiv(gin, 32)), dim3(256), 0, st, ge, w.ge512, gin, Tg, gin);
+        g512 = w.ge512;
+    }
+    // ---- enc_p: quantizer lookup, x2 upsampling, encoders, MRTE -> [m_p | logs_p] [2C][T]
+    int rc = sizeof(AT) == 2 ? encp_run(v, codes, n_codes, text, P, g512, Tg == 1 ? 1 : T, 1, slice, w.stats, w.stats + (size_t)C * T, attn, w.enc, w.enc_bytes, st)
+                             : encp_run_f32(v, codes, n_codes, text, P, g512, Tg == 1 ? 1 : T, 1, slice, w.stats, w.stats + (size_t)C * T, attn, w.enc, w.enc_bytes, st);
+    if (rc) return rc;
+    const float* cur = w.stats;
+    if (stream || valid_start > 0) {
+        hipLaunchKernelGGL(dec_slice_xfade_kernel, dim3(std::min(1024, cdiv(2 * C * Tp, 256))), dim3(256), 0, st, cur, T, valid_start, overlap_state,
+                           stream && has_overlap ? 1 : 0, overlap_len, w.stats_s, Tp, 2 * C);
+        if (stream) hipLaunchKernelGGL(dec_keep_tail_kernel, dim3(cdiv(2 * C * overlap_len, 256)), dim3(256), 0, st, (const float*)w.stats_s, Tp, overlap_len, overlap_state, 2 * C);
+        cur = w.stats_s;
+    }
+    if (T_out != Tp) {
+        hipLaunchKernelGGL(resample_linear_kernel, dim3(cdiv(T_out, 256), 2 * C), dim3(256), 0, st, cur, 2 * C, Tp, w.stats_r, T_out);
+        cur = w.stats_r;
+    }
+    hipLaunchKernelGGL(dec_zp_kernel, dim3(std::min(2048, cdiv(C * T_out, 256))), dim3(256), 0, st, cur, C, T_out, noise_scale,
+                       (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), w.z_p, w.mask);
+    const int Tgv = Tg == 1 ? 1 : T_out;
+    if (Tg == 1) HIPCHK(hipMemcpyAsync(w.ge_fr, ge, sizeof(float) * gin, hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(dec_ge_frames_kernel, dim3(std::min(2048, cdiv(gin * T_out, 256))), dim3(256), 0, st, ge, gin, Tg, w.ge_fr, T_out, T_out != T ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    // ---- flow + Generator (models.py:380-383), replayed from the bucket's hipGraph when asked to
+    if (use_graph) {
+        if (int rc2 = gsv_voc_flow_dec_graph(v, w.z_p, w.mask, w.ge_fr, T_out, Tgv, w.out_static, w.voc, w.voc_bytes, st)) return rc2;
+        HIPCHK(hipMemcpyAsync(out, w.out_static, sizeof(float) * (size_t)T_out * v->total_up, hipMemcpyDeviceToDevice, st));
+        return GSV_OK;
+    }
+    return voc_run<AT>(v, 3, w.z_p, w.mask, w.ge_fr, T_out, Tgv, out, w.voc, w.voc_bytes, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsv_voc_decode_workspace(gsv_voc* v, int n_codes, int n_text, int Tg, float speed, int valid_start) {
+    if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || !(speed > 0.f) || valid_start < 0) return 0;
+    int Tp, T_out;
+    if (!dec_lengths(n_codes, speed, valid_start, &Tp, &T_out)) return 0;
+    return dec_layout(v, n_codes, n_text, Tg, Tp, T_out, nullptr).bytes;
+}
+
+int gsv_voc_decode(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge, int Tg,
+                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len,
+                   float* overlap_state, int has_overlap, int use_graph, float* out, float* attn, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+    if (!v || !v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
+    if (!v->enc.ready) return fail(GSV_ERR_STATE, "decode() needs the enc_p / quantizer tensors");
+    if (!codes || !text || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
+    if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || !(speed > 0.f) || valid_start < 0 || overlap_len < 0)
+        return fail(GSV_ERR_ARG, "decode: bad lengths");
+    return v->cfg.dtype == GSV_BF16
+               ? voc_decode_impl<bf16_t>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, speed, valid_start, overlap_len,
+                                         overlap_state, has_overlap, use_graph, out, attn, workspace, workspace_bytes, S(stream))
+               : voc_decode_impl<float>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, speed, valid_start, overlap_len,
+                                        overlap_state, has_overlap, use_graph, out, attn, workspace, workspace_bytes, S(stream));
 }
 
 int gsv_voc_flow(gsv_voc* v, const float* z_p, const float* y_mask, const float* ge, int T, int Tg, float* z_out,

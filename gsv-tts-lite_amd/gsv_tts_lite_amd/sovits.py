@@ -6,10 +6,11 @@ overlap_len, slice_indices) -> (o, attn)`, `flow_dec(z_p, y_mask, ge) -> o`, and
 TTS reads (`samples_per_frame`, `enc_p.y_overlap`, `enc_p.mrte.cross_attention.attn`).
 
 flow + Generator (models.py:58-65, 113-132 -- the >90% of vocoder time)
-run as hand-written HIP behind `gsv_voc_flow_dec`.  The text/ssl encoder `enc_p` (SURVEY.md 8(f)
-rank 1) runs on device too (`gsv_voc_enc_p`, csrc/encp.h: bf16 MFMA kernels, and plain fp32 ones for the
-parity mode); its torch restatement in sovits_encoder.py is what the tests compare it with (and what serves
-batched `codes`, which the reference never passes).
+run as hand-written HIP behind `gsv_voc_flow_dec`.  `decode()` is ONE C-ABI call (`gsv_voc_decode`): ge_to512, the quantizer
+lookup and x2 upsampling, the text/ssl encoder `enc_p` (csrc/encp.h: bf16 MFMA kernels, plain fp32 ones for the parity
+mode), the streaming cross-fade, the speed resampling, the noise draw and flow + Generator all run inside the library; torch
+only allocates the tensors.  The torch restatement of `enc_p` that the tests compare the kernels with lives with the other
+checkers in oracle/sovits_encoder.py.
 """
 from __future__ import annotations
 
@@ -18,7 +19,6 @@ import math
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import _native as N
 
@@ -60,7 +60,7 @@ class _VocoderNative:
         self._h = h
         stream = N.current_stream_ptr(self.device)
         for name, t in weights.items():
-            enc = name.startswith("enc_p.") or name == "quantizer.vq.layers.0._codebook.embed"
+            enc = name.startswith("enc_p.") or name.startswith("ge_to512.") or name == "quantizer.vq.layers.0._codebook.embed"
             if not (name.startswith("dec.") or name.startswith("flow.") or enc):
                 continue
             d = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -168,6 +168,38 @@ class _VocoderNative:
                                 self._ews.data_ptr(), self._ews.numel(), N.current_stream_ptr(self.device)))
         return m_p, logs_p, attn
 
+    def decode(self, codes, text, ge, slice_indices, noise_scale, seed, speed, valid_start, overlap_len, overlap_state,
+               has_overlap, bucket):
+        """gsv_voc_decode: codes int64 [n], text int64 [P], ge fp32 [gin, Tg] (Tg = 1 or n) -> (audio [1, 1, T_out * hop],
+        attn [4, 2n, P]).  `bucket`: replay flow + Generator from the hipGraph of this chunk length (its own workspace)."""
+        L = N.lib()
+        n, P, Tg = int(codes.numel()), int(text.numel()), int(ge.shape[-1])
+        Tp = 2 * n - valid_start
+        T_out = Tp if speed == 1 else int(Tp / speed) + 1
+        need = L.gsv_voc_decode_workspace(self._h, n, P, Tg, float(speed), int(valid_start))
+        if need == 0:
+            raise RuntimeError("gsv_voc_decode_workspace failed (n_codes %d, n_text %d, Tg %d, speed %g, valid_start %d)" % (n, P, Tg, speed, valid_start))
+        if bucket:
+            if not hasattr(self, "_dws_bucket"):
+                self._dws_bucket = {}
+            key = (n, Tg, valid_start, float(speed))
+            ws = self._dws_bucket.get(key)
+            if ws is None or ws.numel() < need:     # sized for longer texts than this one: a regrown workspace is a re-captured graph
+                ws = self._dws_bucket[key] = torch.empty(max(need, L.gsv_voc_decode_workspace(self._h, n, max(P, 384), Tg, float(speed), int(valid_start))),
+                                                         dtype=torch.uint8, device=self.device)
+        else:
+            if getattr(self, "_dws", None) is None or self._dws.numel() < need:
+                self._dws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = self._dws
+        out = torch.empty(1, 1, T_out * self.samples_per_frame, dtype=torch.float32, device=self.device)
+        attn = torch.empty(4, 2 * n, P, dtype=torch.float32, device=self.device)
+        N.check(L.gsv_voc_decode(self._h, codes.data_ptr(), n, text.data_ptr(), P, ge.data_ptr(), Tg,
+                                 0 if slice_indices is None else slice_indices.data_ptr(), float(noise_scale), int(seed) & (2 ** 64 - 1),
+                                 float(speed), int(valid_start), int(overlap_len), 0 if overlap_state is None else overlap_state.data_ptr(),
+                                 1 if has_overlap else 0, 1 if bucket else 0, out.data_ptr(), attn.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 N.current_stream_ptr(self.device)))
+        return out, attn
+
     def dec(self, z, ge):
         z, ge, T, Tg = self._prep(z, ge)
         out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
@@ -175,6 +207,21 @@ class _VocoderNative:
         N.check(N.lib().gsv_voc_dec(self._h, z.data_ptr(), ge.data_ptr(), T, Tg, out.data_ptr(), ws.data_ptr(),
                                     ws.numel(), N.current_stream_ptr(self.device)))
         return out
+
+
+class _Holder:
+    pass
+
+
+class _EncPState:
+    """what TTS reads / resets on `vq_model.enc_p` (TTS.py:498, models.py:427): the streaming cross-fade state and the MRTE
+    attention of the last decode().  The encoder itself lives in the library (csrc/encp.h)."""
+
+    def __init__(self):
+        self.y_overlap = None        # fp32 [2 * inter, overlap_len]: the projected statistics of the previous chunk's tail
+        self.mrte = _Holder()
+        self.mrte.cross_attention = _Holder()
+        self.mrte.cross_attention.attn = None
 
 
 class SynthesizerTrn:
@@ -202,7 +249,7 @@ class SynthesizerTrn:
         self._voc = None
         self.enc_p = None
         self._ref = None
-        self.native_enc_p = True   # run enc_p on device when its tensors are loaded (bf16 and the fp32 parity mode), incl. speed != 1 and streaming
+        self._noise_calls = 0
 
     def load_state_dict(self, sd, strict=False):
         self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
@@ -224,12 +271,8 @@ class SynthesizerTrn:
         self.device, self.dtype = device, dtype
         self._voc = _VocoderNative(self.hps_model, self._weights, dtype, device)
         self.cuda_graph_buckets = sorted(sovits_caches)
-        try:
-            from .sovits_encoder import TextEncoder, codebook_decode  # torch, "next" row
-            self.enc_p = TextEncoder(self.hps_model, self._weights, device)
-            self._codebook_decode = codebook_decode
-        except KeyError:
-            self.enc_p = None  # hot-path-only weight sets (no enc_p tensors): flow_dec still works
+        # hot-path-only weight sets (no enc_p tensors): flow_dec still works, decode() raises
+        self.enc_p = _EncPState() if self._voc.has_enc_p else None
 
     def _ref_audio(self):
         if self._ref is None:
@@ -263,53 +306,39 @@ class SynthesizerTrn:
     @torch.inference_mode()
     def decode(self, codes, text, ge, noise_scale=0.5, speed=1, cuda_graph=True, stream_mode=False,
                valid_start_idx=None, overlap_len=None, slice_indices=None, generator=None):
-        """models.py:385-429"""
+        """models.py:385-429, one library call (gsv_voc_decode).  codes int64 [1, 1, N], text int64 [1, P], ge [1, gin, 1] or --
+        a time-concatenated batch -- [1, gin, N] (one column per TOKEN, what TTS.infer_batched builds; the reference
+        interpolates it to 2N frames, here that is an index map).  The noise is the library's counter-based stream, seeded from
+        `generator` (or torch's default CPU generator), not torch.randn's."""
         if self.enc_p is None:
             raise RuntimeError("decode() needs the enc_p / quantizer tensors in the state dict")
-        w = self._weights
-        ge = ge.to(device=self.device, dtype=torch.float32)
-        if ge.shape[-1] != 1:
-            ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
-        ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
-        if self.native_enc_p and self._voc.has_enc_p and codes.shape[0] == 1 and codes.shape[1] == 1:
-            # enc_p on device (csrc/encp.h): quantizer lookup, x2 upsampling, the three encoders and MRTE
-            m_p, logs_p, attn = self._voc.enc_p(codes[0, 0], text[0], ge_in, slice_indices)
-            if stream_mode:
-                # models.py:209-215 slices the encoder output at valid_start_idx and cross-fades its first
-                # overlap_len frames with the previous chunk's tail BEFORE the 1x1 `proj`; proj is affine, so
-                # the same cross-fade on its output (m_p | logs_p) is the same function.  y_overlap keeps the
-                # tail of the statistics instead of the tail of the features.
-                stats = torch.cat([m_p, logs_p], dim=1)[:, :, valid_start_idx:]
-                alpha = torch.linspace(0, 1, overlap_len, dtype=stats.dtype, device=stats.device).view(1, 1, -1)
-                if self.enc_p.y_overlap is not None:
-                    stats[:, :, :overlap_len] = self.enc_p.y_overlap * (1 - alpha) + stats[:, :, :overlap_len] * alpha
-                self.enc_p.y_overlap = stats[:, :, -overlap_len:].clone()
-                m_p, logs_p = torch.split(stats, self.inter_channels, dim=1)
-                m_p, logs_p = m_p.contiguous(), logs_p.contiguous()
-            if speed != 1:
-                # models.py:217-219 resamples the encoder features linearly to int(T / speed) + 1 frames before `proj`;
-                # proj is 1x1 affine, so the same resampling of its output is the same function (mask: all ones)
-                stats = torch.cat([m_p, logs_p], dim=1)
-                stats = self._voc.resample_linear(stats, int(stats.shape[-1] / speed) + 1)
-                m_p, logs_p = torch.split(stats, self.inter_channels, dim=1)
-                m_p, logs_p = m_p.contiguous(), logs_p.contiguous()
-            y_mask = torch.ones(1, 1, m_p.shape[-1], dtype=torch.float32, device=self.device)
-            self.enc_p.mrte.cross_attention.attn = attn[None]
-        else:
-            quantized = self._codebook_decode(w, codes.to(self.device))
-            quantized = F.interpolate(quantized, size=quantized.shape[-1] * 2, mode="nearest")
-            m_p, logs_p, y_mask = self.enc_p.infer(quantized, text.to(self.device), ge_in, speed, stream_mode,
-                                                   valid_start_idx, overlap_len, slice_indices)
-        if speed != 1 and ge.shape[-1] != 1:
-            ge = F.interpolate(ge, size=m_p.shape[-1], mode="nearest")
+        if codes.dim() != 3 or codes.shape[0] != 1 or codes.shape[1] != 1:
+            raise ValueError("decode() takes codes of shape [1, 1, N] (one quantizer, batch of one): the reference never passes "
+                             "anything else, and a time-concatenated batch is still a batch of one")
+        dev = self.device
+        n = int(codes.shape[-1])
+        codes = codes.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        text = text.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        ge = ge.to(device=dev, dtype=torch.float32).reshape(self.gin_channels, -1).contiguous()
+        if ge.shape[-1] not in (1, n):
+            raise ValueError("ge must have 1 column or one per token (%d), got %d" % (n, ge.shape[-1]))
+        sl = None if slice_indices is None else slice_indices.to(device=dev, dtype=torch.int64).contiguous()
+        seed = 0
         if noise_scale != 0:
-            noise = torch.randn(m_p.shape, dtype=m_p.dtype, device=m_p.device, generator=generator)
-            z_p = m_p + noise * torch.exp(logs_p) * noise_scale
-        else:
-            z_p = m_p
-        if cuda_graph and z_p.shape[-1] in self.cuda_graph_buckets and ge.shape[-1] == 1:
-            o = self._voc.flow_dec_bucket(z_p, y_mask, ge)
-        else:
-            o = self.flow_dec(z_p, y_mask, ge)
-        attn = self.enc_p.mrte.cross_attention.attn
-        return o, attn[0, ...]
+            if generator is not None:     # a replayable stream per generator seed: call k of a run draws from seed + k
+                seed = (int(generator.initial_seed()) * 0x9E3779B97F4A7C15 + self._noise_calls) & (2 ** 64 - 1)
+                self._noise_calls += 1
+            else:
+                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        start, ov, state, has = 0, 0, None, False
+        if stream_mode:
+            start, ov = int(valid_start_idx), int(overlap_len)
+            state, has = self.enc_p.y_overlap, self.enc_p.y_overlap is not None
+            if state is None or tuple(state.shape) != (2 * self.inter_channels, ov):
+                state, has = torch.zeros(2 * self.inter_channels, ov, dtype=torch.float32, device=dev), False
+            self.enc_p.y_overlap = state          # updated in place by the call: the tail of this chunk's statistics
+        T_out = 2 * n - start if speed == 1 else int((2 * n - start) / speed) + 1
+        bucket = bool(cuda_graph) and T_out in self.cuda_graph_buckets and ge.shape[-1] == 1
+        o, attn = self._voc.decode(codes, text, ge, sl, noise_scale, seed, float(speed), start, ov, state, has, bucket)
+        self.enc_p.mrte.cross_attention.attn = attn[None]
+        return o, attn

@@ -251,6 +251,25 @@ int gsv_voc_enc_p(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* 
                   const int64_t* slice_indices, float* m_p, float* logs_p, float* attn, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* SynthesizerTrn.decode (SoVITS/models.py:385-429) as ONE call -- nothing of it is left to the caller's tensor library:
+ *   codes int64 [n_codes] (n_q = 1, batch 1), text int64 [n_text];
+ *   ge fp32 [gin][Tg] channels-first, Tg = 1 (one speaker) or n_codes (per-TOKEN columns of a time-concatenated batch: the
+ *     x2 nearest upsampling of models.py:389 and the nearest resize of :402 are index maps inside);
+ *   ge_to512 (v2Pro / v2ProPlus, :394), quantizer lookup + x2 upsampling + TextEncoder.infer (enc_p, :395-400; slice_indices as
+ *     for gsv_voc_enc_p), streaming slice + cross-fade (valid_start, overlap_len > 0, overlap_state fp32 [2*inter][overlap_len]
+ *     in/out, has_overlap = 0 on a stream's first chunk; module/models.py:209-215), speed resampling to int(T / speed) + 1 frames
+ *     (:217-219), z_p = m_p + N(0,1) * exp(logs_p) * noise_scale (:404), flow + Generator (:380-383).
+ *   The noise is counter-based (lowbias32 of the element index and `seed`, Box-Muller): a call is replayable from its seed; it is
+ *   not torch's generator stream.  use_graph != 0 replays flow + Generator from a hipGraph captured for this workspace
+ *   (keep one workspace per chunk length: the reference's per-bucket CUDA graphs, models.py:322-369).
+ *   -> out fp32 [T_out * prod(upsample_rates)], T_out = T' (speed 1) or int(T' / speed) + 1, T' = 2 n_codes - valid_start;
+ *      attn fp32 [4][2 n_codes][n_text] or NULL.  workspace: gsv_voc_decode_workspace(...) bytes, device. */
+size_t gsv_voc_decode_workspace(gsv_voc* h, int n_codes, int n_text, int Tg, float speed, int valid_start);
+int gsv_voc_decode(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge, int Tg,
+                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len,
+                   float* overlap_state, int has_overlap, int use_graph, float* out, float* attn, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* Subtitle alignment: monotonic Viterbi path of vocoder frames over phonemes -- replaces
  * TTS._viterbi_monotonic (gsv_tts/TTS.py:1744-1797), which TTS.infer / infer_stream / infer_batched call on
  * the `attn` returned by vq_model.decode (TTS.py:250, 445, 769).

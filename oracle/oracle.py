@@ -611,6 +611,19 @@ def device_uniform(seed, slot, pos, step, V):
     return ((h >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
 
 
+def device_normal(seed, n):
+    """the noise of gsv_voc_decode (csrc/gsv_voc.hip dec_normal): element i of the stream `seed` (uint64) -- Box-Muller over two
+    counter-based uniforms; returned in float64 (the device evaluates log / cos / sqrt in float32: compare with a tolerance)"""
+    lo, hi = np.uint32(seed & 0xffffffff), np.uint32((seed >> 32) & 0xffffffff)
+    i = np.arange(n, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        a = _lowbias32(_lowbias32(i * np.uint32(0x9E3779B1) ^ lo) + hi)
+        b = _lowbias32(_lowbias32(i * np.uint32(0x85EBCA77) ^ hi ^ np.uint32(0x68E31DA4)) + lo)
+    u1 = ((a >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
+    u2 = ((b >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
 def _device_top_p(logits, top_p):
     """the device sampler's top-p: keep v iff sum_{p_u >= p_v} p_u <= top_p, or v is the arg-max (== the reference's
     sort + cumsum rule, GPT/utils.py:29-40, with ties kept or dropped together)"""

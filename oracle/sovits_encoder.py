@@ -1,9 +1,8 @@
-"""SoVITS text/ssl encoder `enc_p` (TextEncoder) and codebook lookup, in plain torch.
-
-This is the stage in front of the HIP flow+Generator inside `SynthesizerTrn.decode`.  It is a
-"next" row of the scope table (~10 % of vocoder time, runs once per
-utterance), so it is functional torch on the GPU rather than hand-written HIP.  Semantics follow
-the reference:
+"""TEST INFRASTRUCTURE (a checker, like the rest of oracle/): SoVITS text/ssl encoder `enc_p` (TextEncoder), codebook lookup
+and the `decode()` wrapper around them, restated in plain torch.  Only tests/ import it; the product's `decode()` is one
+C-ABI call (gsv_voc_decode) and never touches this file.  The restatement is pinned to the reference by
+tests/golden/decode.npz (tests/test_hip_tts.py::test_decode_end_to_end_matches_reference runs the product against the
+reference's own outputs; tests/test_hip_encp.py holds the device enc_p to this restatement).  Semantics follow the reference:
 
   TextEncoder.infer            gsv_tts/GPT_SoVITS/SoVITS/models.py:196-224
   attentions.Encoder / FFN     SoVITS/module/attentions.py:10-77, 221-277
@@ -204,3 +203,31 @@ class TextEncoder:
         stats = F.conv1d(y, *self.proj) * y_mask
         m, logs = torch.split(stats, self.out_channels, dim=1)
         return m, logs, y_mask
+
+
+class DecodeRestatement:
+    """SynthesizerTrn.decode (SoVITS/models.py:385-429) around a `flow_dec(z_p, y_mask, ge)` callable (the product's HIP
+    flow + Generator, pinned separately by vocoder.npz): what tests compare the one-call gsv_voc_decode with -- speed != 1
+    (features resampled BEFORE proj, :217-219), the streaming slice + cross-fade on the features (:209-215), per-token ge."""
+
+    def __init__(self, hps_model, weights, device, flow_dec, round_fn=None):
+        self.w = weights
+        self.enc_p = TextEncoder(hps_model, weights, device, round_fn=round_fn)
+        self.flow_dec = flow_dec
+        self.is_v2pro = hps_model["version"] in ("v2Pro", "v2ProPlus")
+        self.device = device
+
+    @torch.inference_mode()
+    def __call__(self, codes, text, ge, noise=None, noise_scale=0.0, speed=1, stream_mode=False, valid_start_idx=None,
+                 overlap_len=None, slice_indices=None):
+        ge = ge.to(device=self.device, dtype=torch.float32)
+        if ge.shape[-1] != 1:
+            ge = F.interpolate(ge, size=ge.shape[-1] * 2, mode="nearest")
+        ge_in = self.enc_p.ge_to512(ge) if self.is_v2pro else ge
+        q = codebook_decode(self.w, codes.to(self.device))
+        q = F.interpolate(q, size=q.shape[-1] * 2, mode="nearest")
+        m_p, logs_p, y_mask = self.enc_p.infer(q, text.to(self.device), ge_in, speed, stream_mode, valid_start_idx, overlap_len, slice_indices)
+        if speed != 1 and ge.shape[-1] != 1:
+            ge = F.interpolate(ge, size=m_p.shape[-1], mode="nearest")
+        z_p = m_p if not noise_scale else m_p + noise.to(m_p) * torch.exp(logs_p) * noise_scale
+        return self.flow_dec(z_p, y_mask, ge), self.enc_p.mrte.cross_attention.attn[0], (m_p, logs_p)

@@ -1,5 +1,6 @@
-"""GPU parity of enc_p on device (csrc/encp.h + tapgemm, bf16) against the torch restatement of
-TextEncoder.infer (sovits_encoder.py), which the decode() golden fixtures pin to the reference."""
+"""GPU parity of enc_p on device (csrc/encp.h + tapgemm) and of the one-call decode (gsv_voc_decode) against the torch
+restatement of TextEncoder.infer / SynthesizerTrn.decode (oracle/sovits_encoder.py: test infrastructure), which the
+decode() golden fixtures pin to the reference."""
 import numpy as np
 import pytest
 import torch
@@ -22,6 +23,10 @@ def _vq(ver, seed, dev, dtype=torch.bfloat16):
     vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
     vq.load_state_dict(synth.sovits_weights(hps, seed=seed))
     vq.initialize_runtime(dtype, dev, [64])
+    from oracle.sovits_encoder import TextEncoder, DecodeRestatement, codebook_decode
+    vq.ref_enc = TextEncoder(vq.hps_model, vq._weights, dev)
+    vq.ref_decode = DecodeRestatement(vq.hps_model, vq._weights, dev, vq.flow_dec)
+    vq.ref_codebook = codebook_decode
     return vq
 
 
@@ -46,12 +51,12 @@ def test_enc_p_fp32_parity_mode_on_device(dev, ver):
         if mode == "slice":
             cut_t, cut_p = T // 2, P // 2
             sl = torch.tensor([[0, cut_p]] * cut_t + [[cut_p, P]] * (T - cut_t), device=dev)
-        ge_in = vq.enc_p.ge_to512(ge) if vq.is_v2pro else ge
+        ge_in = vq.ref_enc.ge_to512(ge) if vq.is_v2pro else ge
         with torch.inference_mode():
-            q = vq._codebook_decode(vq._weights, codes)
+            q = vq.ref_codebook(vq._weights, codes)
             q = F.interpolate(q, size=q.shape[-1] * 2, mode="nearest")
-            m_ref, logs_ref, _ = vq.enc_p.infer(q, text, ge_in, 1, slice_indices=sl)
-            a_ref = vq.enc_p.mrte.cross_attention.attn[0].clone()
+            m_ref, logs_ref, _ = vq.ref_enc.infer(q, text, ge_in, 1, slice_indices=sl)
+            a_ref = vq.ref_enc.mrte.cross_attention.attn[0].clone()
             m, logs, attn = vq._voc.enc_p(codes[0, 0], text[0], ge_in, sl)
         for got, ref, name in ((m, m_ref, "m_p"), (logs, logs_ref, "logs_p"), (attn, a_ref, "attn")):
             err = (got - ref).abs().max().item()
@@ -70,7 +75,7 @@ def test_enc_p_bf16_vs_torch_restatement(dev, ver):
     time-concatenated batch form with slice_indices (mrte_model.py:27-33)."""
     vq = _vq(ver, 7, dev)
     assert vq._voc.has_enc_p
-    from gsv_tts_lite_amd.sovits_encoder import TextEncoder
+    from oracle.sovits_encoder import TextEncoder
     enc16 = TextEncoder(vq.hps_model, vq._weights, dev, round_fn=lambda t: t.to(torch.bfloat16).to(torch.float32))
     rng = np.random.default_rng(3)
     gin = 1024 if ver == "v2Pro" else 512
@@ -85,12 +90,12 @@ def test_enc_p_bf16_vs_torch_restatement(dev, ver):
         if mode == "slice":
             cut_t, cut_p = T // 2, P // 2
             sl = torch.tensor([[0, cut_p]] * cut_t + [[cut_p, P]] * (T - cut_t), device=dev)
-        ge_in = vq.enc_p.ge_to512(ge) if vq.is_v2pro else ge
+        ge_in = vq.ref_enc.ge_to512(ge) if vq.is_v2pro else ge
         with torch.inference_mode():
-            q = vq._codebook_decode(vq._weights, codes)
+            q = vq.ref_codebook(vq._weights, codes)
             q = F.interpolate(q, size=q.shape[-1] * 2, mode="nearest")
-            m_ref, logs_ref, _ = vq.enc_p.infer(q, text, ge_in, 1, slice_indices=sl)
-            a_ref = vq.enc_p.mrte.cross_attention.attn[0].clone()
+            m_ref, logs_ref, _ = vq.ref_enc.infer(q, text, ge_in, 1, slice_indices=sl)
+            a_ref = vq.ref_enc.mrte.cross_attention.attn[0].clone()
             m16, logs16, _ = enc16.infer(q, text, ge_in, 1, slice_indices=sl)
             m, logs, attn = vq._voc.enc_p(codes[0, 0], text[0], ge_in, sl)
         assert m.shape == m_ref.shape and attn.shape == a_ref.shape
@@ -116,10 +121,52 @@ def test_decode_bf16_uses_device_enc_p_and_stays_close_to_reference(dev, golden_
     vq = _vq("v2Pro", int(g["seed"]), dev)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     o, attn = vq.decode(T(g["v2Pro_codes"]), T(g["v2Pro_text"]), T(g["v2Pro_ge"]), noise_scale=0.0)
-    vq.native_enc_p = False
-    o2, attn2 = vq.decode(T(g["v2Pro_codes"]), T(g["v2Pro_text"]), T(g["v2Pro_ge"]), noise_scale=0.0)
+    o2, attn2, _ = vq.ref_decode(T(g["v2Pro_codes"]), T(g["v2Pro_text"]), T(g["v2Pro_ge"]))      # fp32 torch enc_p -> bf16 flow_dec
     ref = g["v2Pro_o"]
     for out in (o, o2):
         err = np.abs(out[0, 0].cpu().numpy() - ref)
         assert err.max() < 0.15 and err.mean() < 0.015, (err.max(), err.mean())
     assert np.abs(attn.cpu().numpy() - g["v2Pro_attn"]).max() < 6e-3
+
+
+def test_decode_noise_is_the_counter_based_stream_and_per_token_ge_is_an_index_map(dev):
+    """gsv_voc_decode end to end in the fp32 parity mode against the restatement: (i) noise_scale != 0 with the library's noise
+    (oracle.device_normal restates it: z_p = m_p + n * exp(logs_p) * noise_scale, models.py:404), replayable from the generator
+    seed; (ii) per-TOKEN ge of a time-concatenated batch (x2 nearest upsampling, models.py:389) with slice_indices and speed != 1
+    (nearest resize to the resampled length, :402)."""
+    from oracle import oracle as orc
+    vq = _vq("v2Pro", 7, dev, torch.float32)
+    rng = np.random.default_rng(9)
+    n, P = 37, 29
+    codes = torch.from_numpy(rng.integers(0, 1024, (1, 1, n))).to(dev)
+    text = torch.from_numpy(rng.integers(1, 700, (1, P))).to(dev)
+    ge = torch.from_numpy(synth.synth_ge(1, 1024, 7)).to(dev)
+    g = torch.Generator(device="cpu"); g.manual_seed(77)
+    vq._noise_calls = 0
+    o1, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
+    seed = (77 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    noise = torch.from_numpy(orc.device_normal(seed, 192 * 2 * n).astype(np.float32)).reshape(1, 192, 2 * n).to(dev)
+    assert abs(float(noise.mean())) < 0.03 and abs(float(noise.std()) - 1.0) < 0.03
+    o_ref, _, _ = vq.ref_decode(codes, text, ge, noise=noise, noise_scale=0.5)
+    e = (o1 - o_ref).abs()
+    print("decode with noise vs restatement + device_normal: max %.2e" % float(e.max()))
+    assert float(e.max()) < 1e-4
+    vq._noise_calls = 0
+    o1b, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
+    assert torch.equal(o1, o1b), "same generator seed, same call index: the same draw"
+    o1c, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
+    assert not torch.equal(o1, o1c), "the next call of a run draws fresh noise"
+    # per-token ge: two utterances concatenated, each with its own speaker
+    cut = 15
+    ge2 = torch.from_numpy(synth.synth_ge(2, 1024, 7)).to(dev)
+    ge_cat = torch.cat([ge.expand(-1, -1, cut), ge2.expand(-1, -1, n - cut)], 2)
+    sl = torch.tensor([[0, 12]] * (2 * cut) + [[12, P]] * (2 * (n - cut)), device=dev)
+    for speed in (1.0, 1.3):
+        o, attn = vq.decode(codes, text, ge_cat, noise_scale=0.0, speed=speed, cuda_graph=False, slice_indices=sl)
+        o_r, attn_r, _ = vq.ref_decode(codes, text, ge_cat, speed=speed, slice_indices=sl)
+        assert o.shape == o_r.shape
+        e = (o - o_r).abs()
+        print("per-token ge, speed %.1f: max %.2e" % (speed, float(e.max())))
+        assert float(e.max()) < 1e-4 and float((attn - attn_r).abs().max()) < 1e-5
+    with pytest.raises(ValueError):
+        vq.decode(codes.expand(2, -1, -1), text, ge)       # batched codes: the reference never passes them, the library refuses

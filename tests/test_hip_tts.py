@@ -109,14 +109,36 @@ def test_tts_infer_stream_chunks(dev, dtype):
     body_whole = len(whole.audio_data) - int(0.2 * 32000)
     body_stream = total - int(0.4 * 1.5 * 32000)
     assert abs(body_stream - body_whole) <= 320 * len(clips) + 640, (body_stream, body_whole, len(clips))
-    if dtype == "bfloat16":   # device enc_p streaming vs the torch streaming branch: same chunking, close audio
-        vq = next(iter(tts.sovits_models.values())).vq_model
-        assert vq._voc.has_enc_p
-        vq.native_enc_p = False
-        clips2 = list(tts.infer_stream("spk.wav", "prompt.wav", "prompt text.", text, top_k=1, noise_scale=0.0, stream_chunk=8,
-                                       overlap_len=2, is_cut_text=False, debug=False))
-        assert len(clips2) == len(clips)
-        assert abs(sum(len(c.audio_data) for c in clips2) - total) <= 320 * len(clips)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 0.2)])
+def test_decode_streaming_chunks_match_the_restatement(dev, dtype, tol):
+    """decode(stream_mode=True) (models.py:209-215: drop valid_start_idx frames, cross-fade overlap_len frames with the previous
+    chunk's tail): the one-call library path slices / cross-fades the projected statistics, the restatement
+    (oracle/sovits_encoder.py) the encoder features before `proj` as the reference does -- the same function, proj is affine.
+    Three chunks of one stream with growing context, as TTS.infer_stream issues them; then a second stream must start clean."""
+    from gsv_tts_lite_amd.sovits import SynthesizerTrn
+    from oracle.sovits_encoder import DecodeRestatement
+    hps = synth.sovits_hps("v2Pro")
+    vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
+    vq.load_state_dict(synth.sovits_weights(hps, seed=11))
+    vq.initialize_runtime(dtype, dev, [50, 55])
+    ref = DecodeRestatement(vq.hps_model, vq._weights, dev, vq.flow_dec)
+    rng = np.random.default_rng(5)
+    codes = torch.from_numpy(rng.integers(0, 1024, (1, 1, 60))).to(dev)
+    text = torch.from_numpy(rng.integers(1, 700, (1, 33))).to(dev)
+    ge = _T(synth.synth_ge(0, 1024, 11), dev)
+    for stream in range(2):
+        vq.enc_p.y_overlap = None
+        ref.enc_p.y_overlap = None
+        for n_tok, start in ((20, 0), (40, 30), (60, 70)):
+            o, attn = vq.decode(codes[:, :, :n_tok], text, ge, noise_scale=0.0, stream_mode=True, valid_start_idx=start, overlap_len=4)
+            o2, attn2, _ = ref(codes[:, :, :n_tok], text, ge, stream_mode=True, valid_start_idx=start, overlap_len=4)
+            assert o.shape == o2.shape == (1, 1, (2 * n_tok - start) * 640)
+            err = (o - o2).abs()
+            print("stream %d chunk %d (%s): max |diff| %.2e" % (stream, n_tok, dtype, float(err.max())))
+            assert float(err.max()) < tol, (stream, n_tok, float(err.max()))
+        assert tuple(vq.enc_p.y_overlap.shape) == (2 * 192, 4)
 
 
 def _word_frontend(text):
@@ -292,11 +314,11 @@ def test_decode_speed_on_device_matches_torch_encoder(dev):
     codes = torch.randint(0, 1024, (1, 1, 40), device=dev)
     text = torch.randint(1, 700, (1, 30), device=dev)
     ge = _T(synth.synth_ge(0, 1024, 11), dev)
+    from oracle.sovits_encoder import DecodeRestatement
+    ref = DecodeRestatement(vq.hps_model, vq._weights, dev, vq.flow_dec)
     for speed in (1.25, 0.8):
-        vq.native_enc_p = True
         o1, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=speed)
-        vq.native_enc_p = False
-        o2, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=speed)
+        o2, _, _ = ref(codes, text, ge, speed=speed)
         assert o1.shape == o2.shape == (1, 1, (int(80 / speed) + 1) * 640)
         err = (o1 - o2).abs()
         assert err.max() < 0.15 and err.mean() < 0.02, (speed, float(err.max()), float(err.mean()))   # bf16 enc_p vs fp32 torch enc_p
