@@ -18,6 +18,7 @@
 #include "tapgemm.h"
 #include "wconv.h"
 #include "wups.h"
+#include "cgemm.h"
 #include "voc_kernels.h"
 #include "gsv_error.h"
 
@@ -54,6 +55,7 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 // ---------------------------------------------------------------------------------------------
 struct PackedConv {
     void* w = nullptr;
+    void* cg = nullptr;        // the same weights in cgemm.h's plane order (wide resblock convs, bf16 handles), or null
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, k = 1, dil = 1, pad = 0, u = 0;
     int nphase = 1, ntaps = 1, mtiles = 1;
@@ -87,6 +89,8 @@ int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_
 
 void free_conv(PackedConv& pc) {
     if (pc.w) (void)hipFree(pc.w);
+    if (pc.cg) (void)hipFree(pc.cg);
+    pc.cg = nullptr;
     if (pc.bias) (void)hipFree(pc.bias);
     pc.w = nullptr; pc.bias = nullptr;
 }
@@ -184,6 +188,59 @@ int run_conv(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, in
 
 // The weights-in-registers path for the Generator's resblock convs (wconv.h).  Returns 1 when the
 // launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
+// wide resblock convs on the LDS-tiled GEMM (cgemm.h): 384 and 192 channels always, 256 channels from 16k rows on (below that
+// the weights-in-registers kernel's shorter block wins: measured 33 vs 39 us per launch at 5 000 rows, 267 vs 207 at 50 000)
+template <typename AT>
+int run_cgemm(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
+    (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
+    return -1;
+}
+template <>
+inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
+    static const bool off = getenv("GSV_NO_CGEMM") != nullptr;
+    const int C = brs[0].pc->cout;
+    if (off || !(C == 384 || C == 192 || (C == 256 && n_rows >= 16384)) || ld != C) return -1;
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) {
+        const PackedConv& q = *brs[i].pc;
+        if (!q.cg || q.cin != C || q.cout != C || q.u != 0 || q.k > 11 || (q.k - 1) * q.dil > 50 || q.pad != (q.k - 1) / 2 * q.dil) return -1;
+    }
+    if ((brs[0].res == nullptr) != (brs[1].res == nullptr) || (brs[0].res == nullptr) != (brs[2].res == nullptr)) return -1;
+    std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
+    const Branch &b0 = brs[order[0]], &b1 = brs[order[1]], &b2 = brs[order[2]];
+    CGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X0 = (const bf16_t*)b0.X; a.X1 = (const bf16_t*)b1.X; a.X2 = (const bf16_t*)b2.X;
+    a.W0 = (const uint4*)b0.pc->cg; a.W1 = (const uint4*)b1.pc->cg; a.W2 = (const uint4*)b2.pc->cg;
+    a.b0 = b0.pc->bias; a.b1 = b1.pc->bias; a.b2 = b2.pc->bias;
+    a.R0 = (const bf16_t*)b0.res; a.R1 = (const bf16_t*)b1.res; a.R2 = (const bf16_t*)b2.res;
+    a.Y0 = (bf16_t*)b0.Y; a.Y1 = (bf16_t*)b1.Y; a.Y2 = (bf16_t*)b2.Y;
+    a.k0 = b0.pc->k; a.k1 = b1.pc->k; a.k2 = b2.pc->k;
+    a.d0 = b0.pc->dil; a.d1 = b1.pc->dil; a.d2 = b2.pc->dil;
+    a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
+    auto launch = [&](auto kern, size_t lds, int bm, int tn, int nt) -> int {
+        const int tiles = cdiv(n_rows, bm) * tn;
+        a.nb0 = tiles; a.nb1 = tiles;
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(nt), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    };
+    if (C == 384) return launch(cgemm_kernel<384, 192, 128>, CgShape<384, 192, 128>::LDS, 128, CgShape<384, 192, 128>::TN, CgShape<384, 192, 128>::NT);
+    if (C == 256) return launch(cgemm_kernel<256, 128, 128>, CgShape<256, 128, 128>::LDS, 128, CgShape<256, 128, 128>::TN, CgShape<256, 128, 128>::NT);
+    return launch(cgemm_kernel<192, 192, 128>, CgShape<192, 192, 128>::LDS, 128, CgShape<192, 192, 128>::TN, CgShape<192, 192, 128>::NT);
+}
+// the plane-order copy of a wide resblock conv's weights (torch layout [C][C][k] fp32 in)
+inline int pack_cgemm(PackedConv& pc, const float* w, int C, int k, hipStream_t st) {
+    if (!(C == 384 || C == 256 || C == 192)) return GSV_OK;
+    if (!pc.cg) HIPCHK(hipMalloc(&pc.cg, sizeof(bf16_t) * (size_t)C * C * k));
+    if (C == 384) hipLaunchKernelGGL(cgemm_pack_kernel<384>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);
+    else if (C == 256) hipLaunchKernelGGL(cgemm_pack_kernel<256>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);
+    else hipLaunchKernelGGL(cgemm_pack_kernel<192>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
 inline bool wconv_channels(int C) {
     return C == 16 || C == 24 || C == 32 || C == 48 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256;
 }

@@ -253,7 +253,15 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
             }
             // bf16, 16..128 channels: weights-in-registers kernel; the first conv writes lrelu(t1), which is
             // the only form its consumer reads, so the second conv stages its input without arithmetic
-            int rw = run_wconv<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
+            int rw = run_cgemm<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
+            if (rw > 0) return rw;
+            if (rw == 0) {
+                rw = run_cgemm<AT>(b2, ldo, Tn, 1.0f, 1.0f, st);
+                if (rw != 0) return rw > 0 ? rw : fail(GSV_ERR_STATE, "cgemm accepted the first conv of a pair but not the second");
+                for (int j = 0; j < 3; ++j) cur[j] = (const AT*)b2[j].Y;
+                continue;
+            }
+            rw = run_wconv<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
             if (rw > 0) return rw;
             if (rw != 0 && wc && ldo != sg.cout) return fail(GSV_ERR_STATE, "wconv declined a padded stage whose buffers were not cleared");
             if (rw == 0) {
@@ -768,6 +776,7 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
                     const int dil = which ? 1 : c.resblock_dilations[d];
                     PackedConv& pc = which ? rb.c2[d] : rb.c1[d];
                     rc = pack_conv<CT>(pc, wsrc, co, cpad, rb.k, (int64_t)cpad * rb.k, rb.k, 1, dil, dil * (rb.k - 1) / 2, 0, b, 1.f, st);
+                    if (!rc && sizeof(CT) == 2 && cpad == co) rc = pack_cgemm(pc, w, co, rb.k, st);   // wide stages: also the cgemm.h order
                 }
             }
         }
