@@ -217,6 +217,7 @@ class Text2SemanticDecoder:
             for _, shp, dt in spec:
                 offs.append(pos)
                 pos += -(-(int(np.prod(shp)) * torch.empty(0, dtype=dt).element_size()) // al) * al
+            separate = os.environ.get("GSV_STATE_SEPARATE") == "1"      # tools/placement_ab.py: the pre-round-3 layout
             block = torch.zeros(pos + al, dtype=torch.uint8, device=device)
             base = (-block.data_ptr()) % al
             rt = {
@@ -226,7 +227,7 @@ class Text2SemanticDecoder:
             }
             for (name, shp, dt), o in zip(spec, offs):
                 nb = int(np.prod(shp)) * torch.empty(0, dtype=dt).element_size()
-                rt[name] = block[base + o: base + o + nb].view(dt).view(*shp)
+                rt[name] = torch.zeros(*shp, dtype=dt, device=device) if separate else block[base + o: base + o + nb].view(dt).view(*shp)
             rt["eos_at"].fill_(-1)
             rt["fctl"].fill_(1.0)
             st = N.T2SState(b, T, *[rt[k].data_ptr() for k in (

@@ -23,7 +23,8 @@ run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --lpt-budge
 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --no-cpu-baseline > $O/cb_bf16_bs64.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --dtype fp8 --no-cpu-baseline > $O/cb_fp8_bs64.json 2> /dev/null
-run timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $R/bench.py --gpus 2 --workload cb --share-gpu --dist-backend gloo --steps 1 --warmup 1 --requests 64 --no-cpu-baseline > $O/cb_2ranks_shared_gpu_gloo.json 2> $O/cb_2ranks.log
+# N > 1 through the bench's own launcher (no torchrun around it): two ranks on this box's one GPU, gloo
+run timeout 900 python $R/bench.py --gpus 2 --workload cb --share-gpu --dist-backend gloo --steps 1 --warmup 1 --requests 64 --no-cpu-baseline 2> $O/cb_2ranks.log | grep '^{' > $O/cb_2ranks_bare_launch.json
 rm -rf /tmp/p2; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python $R/bench.py --workload cb --version v2ProPlus --steps 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 f=$(find /tmp/p2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/rocprofv3_kernel_stats_cb_configs2.csv
 # 4. raw step times
@@ -38,4 +39,9 @@ for v in v2Pro v2ProPlus; do
   [ -n "$db" ] && python $R/tools/prof_timeline.py "$db" vocpass > $O/vocoder_timeline_$v.txt 2>&1
 done
 timeout 300 python $R/tools/sample_speed.py 2>&1 | grep token > $O/sample_speed.txt
+# 6. placement spread (ten model instances per setting), the fused-resblock and conv-GEMM micro-benchmarks
+( echo "arena (default), instances kept alive"; KEEP=1 timeout 300 python $R/tools/placement_ab.py 10 | grep step
+  echo "separate allocations (GSV_NO_ARENA=1)"; GSV_NO_ARENA=1 KEEP=1 timeout 300 python $R/tools/placement_ab.py 10 | grep step ) > $O/placement_ab.txt 2>&1
+[ -x $R/tools/rb_bench ] && ( $R/tools/rb_bench 16 5000; $R/tools/rb_bench 32 3000 24; $R/tools/rb_bench 16 320000; $R/tools/rb_bench 32 160000; $R/tools/rb_bench 16 3200000; $R/tools/rb_bench 32 1600000 ) 2>&1 | grep -v stamps > $O/rbfuse_bench.txt
+[ -x $R/tools/cg_bench ] && ( for c in 384 256 192 128; do $R/tools/cg_bench $c 5003 5 1 128; done; $R/tools/cg_bench 384 50000 5 1 128; $R/tools/cg_bench 256 50000 5 1 128; $R/tools/cg_bench 192 400000 5 1 128; $R/tools/cg_bench 128 400000 5 1 128 ) 2>&1 | grep -v "block 0" > $O/cgemm_bench.txt
 ls -la $O >&2
