@@ -227,7 +227,8 @@ inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slo
         return GSV_OK;
     };
     if (C == 384) return launch(cgemm_kernel<384, 192, 128>, CgShape<384, 192, 128>::LDS, 128, CgShape<384, 192, 128>::TN, CgShape<384, 192, 128>::NT);
-    if (C == 256) return launch(cgemm_kernel<256, 128, 128>, CgShape<256, 128, 128>::LDS, 128, CgShape<256, 128, 128>::TN, CgShape<256, 128, 128>::NT);
+    // 256 channels: 256-row tiles (4 waves of 128 rows x 64 channels): half the weight-tile traffic per row of the 128-row shape
+    if (C == 256) return launch(cgemm_kernel<256, 128, 256, 4>, CgShape<256, 128, 256, 4>::LDS, 256, CgShape<256, 128, 256, 4>::TN, CgShape<256, 128, 256, 4>::NT);
     return launch(cgemm_kernel<192, 192, 128>, CgShape<192, 192, 128>::LDS, 128, CgShape<192, 192, 128>::TN, CgShape<192, 192, 128>::NT);
 }
 // the plane-order copy of a wide resblock conv's weights (torch layout [C][C][k] fp32 in)

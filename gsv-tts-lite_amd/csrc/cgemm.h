@@ -6,7 +6,8 @@
 // has to be split between waves and the output slices between blocks that each re-stage the input), and the first stages have
 // few rows (5 000 per 10 s of audio at 256 / 384 channels): measured 300-600 TF/s.  A conv is a GEMM whose A operand is shared
 // by its taps: Y[r][co] = sum_tap sum_ci W[tap][co][ci] * X[r + (tap - hk) * d][ci].  So:
-//   * block tile = BM rows x BN output channels, 8 waves (4 along rows x 2 along channels), wave tile 64 rows x BN/2 channels,
+//   * block tile = BM rows x BN output channels, 4 waves (2 along rows x 2 along channels), wave tile 32 RT rows x BN/2 channels
+//     (RT = 2: 128-row tiles; RT = 4: 256-row tiles, half the weight traffic per row, used at 256 channels), two blocks per CU,
 //     v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (M = output channel) and the ROWS as N: a lane's 16 accumulator
 //     registers are 16 consecutive channels of one row (weight rows are permuted at pack time), stored as two 16-byte pieces;
 //   * the contraction runs over (64-channel chunk, tap): the activation rows of a chunk (BM + halo rows) are staged ONCE and
@@ -36,11 +37,11 @@ struct CGemmArgs {
     long long* dbg;               // null, or cycle stamps of block 0 / thread 0 (tools/cg_bench)
 };
 
-template <int C, int BN, int BM_ = 128>
+template <int C, int BN, int BM_ = 128, int RT_ = 2>
 struct CgShape {
-    static constexpr int BM = BM_, KC = 64, NPL = KC / 8, NW = 2 * (BM / 64), NT = NW * 64;
-    static constexpr int XB = BM >= 256 ? 2 : 1;  // activation chunk buffers: BM = 128 keeps ONE (74 KB of LDS: two blocks per CU, whose
-                                                  // barriers and latencies overlap) and re-stages behind a barrier at a chunk boundary
+    static constexpr int BM = BM_, RT = RT_, KC = 64, NPL = KC / 8, NW = 2 * (BM / (32 * RT)), NT = NW * 64;
+    static constexpr int XB = NW >= 8 ? 2 : 1;    // activation chunk buffers: the 4-wave shapes keep ONE (<= 80 KB of LDS: two blocks per CU,
+                                                  // whose barriers and latencies overlap) and re-stage behind a barrier at a chunk boundary
     static constexpr int WN = BN / 64;            // 32-channel MFMA tiles per wave (2 waves along channels)
     static constexpr int HALO = 64;               // staged rows beyond the tile: (k - 1) * d <= 50
     static constexpr int XROWS = BM + HALO;
@@ -50,7 +51,7 @@ struct CgShape {
     static constexpr int WBUF = NPL * WP;
     static constexpr int NCH = C / KC;
     static constexpr int TN = C / BN;             // channel tiles
-    static constexpr int NWB = BM >= 256 ? 3 : 2;
+    static constexpr int NWB = NW >= 8 ? 3 : 2;
     static constexpr size_t LDS = XB * (size_t)XBUF + NWB * (size_t)WBUF;
     static constexpr int XV = (NPL * XROWS + NT - 1) / NT;   // 16-byte activation pieces per thread per chunk
     static constexpr int WV = NPL * BN / NT;                  // 16-byte weight pieces per thread per tile
@@ -85,13 +86,14 @@ __global__ void cgemm_pack_kernel(const float* __restrict__ w, bf16_t* __restric
     }
 }
 
-template <int C, int BN, int BM = 128>
-__global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGemmArgs a) {
-    using S = CgShape<C, BN, BM>;
+template <int C, int BN, int BM = 128, int RT = 2>
+__global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(CGemmArgs a) {
+    using S = CgShape<C, BN, BM, RT>;
     constexpr int WN = S::WN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = lane & 31, hi = lane >> 5;
-    const int wm = wid % (S::BM / 64), wn = wid / (S::BM / 64);        // wave position: rows [64 wm, +64), channels [BN/2 * wn, + BN/2)
+    constexpr int WR = 32 * RT;                   // rows per wave
+    const int wm = wid % (S::BM / WR), wn = wid / (S::BM / WR);        // wave position: rows [WR wm, + WR), channels [BN/2 * wn, + BN/2)
     // ---- which conv, which tile
     int b = blockIdx.x;
     const int br = b < a.nb0 ? 0 : (b < a.nb0 + a.nb1 ? 1 : 2);
@@ -165,9 +167,9 @@ __global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGem
             __builtin_amdgcn_global_load_lds((gbl_void*)(base + woff[v]), (lds_void*)(dst + v * S::NT * 16), 16, 0, 0);
     };
 
-    f32x16 acc[2][WN];
+    f32x16 acc[RT][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int t = 0; t < WN; ++t)
 #pragma unroll
@@ -187,7 +189,7 @@ __global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGem
     __builtin_amdgcn_s_barrier();
     asm volatile("" : : : "memory");
     // fragment addresses: B (rows): plane 2 ks + hi, row 64 wm + 32 i + n + tap * d; A (weights): plane 2 ks + hi, channel BN/2 wn + 32 t + n
-    const unsigned xlane = (unsigned)(hi * S::XP + (64 * wm + n) * 16);
+    const unsigned xlane = (unsigned)(hi * S::XP + (WR * wm + n) * 16);
     const unsigned wlane = (unsigned)(hi * S::WP + ((BN / 2) * wn + n) * 16);
     stamp(1);
     for (int it = 0; it < nit; ++it) {
@@ -202,10 +204,10 @@ __global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGem
         const unsigned char* xb = xbuf + (ch % S::XB) * S::XBUF + xlane + (unsigned)(tap * d) * 16;
         const unsigned char* wb = wbuf + (it % S::NWB) * S::WBUF + wlane;
         // fragments of k-step ks + 1 are read before the MFMAs of k-step ks issue (two register sets)
-        u32x4 bf[2][2], af[2][WN];
-        auto ldf = [&](int ks, u32x4 (&b_)[2], u32x4 (&a_)[WN]) {
+        u32x4 bf[2][RT], af[2][WN];
+        auto ldf = [&](int ks, u32x4 (&b_)[RT], u32x4 (&a_)[WN]) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) b_[i] = *reinterpret_cast<const u32x4*>(xb + 2 * ks * S::XP + i * 32 * 16);
+            for (int i = 0; i < RT; ++i) b_[i] = *reinterpret_cast<const u32x4*>(xb + 2 * ks * S::XP + i * 32 * 16);
 #pragma unroll
             for (int t = 0; t < WN; ++t) a_[t] = *reinterpret_cast<const u32x4*>(wb + 2 * ks * S::WP + t * 32 * 16);
         };
@@ -214,7 +216,7 @@ __global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGem
         for (int ks = 0; ks < S::KC / 16; ++ks) {
             if (ks + 1 < S::KC / 16) ldf(ks + 1, bf[(ks + 1) & 1], af[(ks + 1) & 1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int t = 0; t < WN; ++t)
 #ifndef CG_SKIP_MFMA
@@ -248,8 +250,8 @@ __global__ __launch_bounds__((CgShape<C, BN, BM>::NT), 2) void cgemm_kernel(CGem
     stamp(2 + nit);
     // ---- epilogue: lane (row n of tile i, half hi) holds channels n0 + BN/2 wn + 32 t + 16 hi + r
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gr = r0 + 64 * wm + 32 * i + n;
+    for (int i = 0; i < RT; ++i) {
+        const int gr = r0 + WR * wm + 32 * i + n;
         if (gr >= a.n_rows) continue;
 #pragma unroll
         for (int t = 0; t < WN; ++t) {

@@ -18,9 +18,9 @@ static float b2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&
 static uint32_t rng = 777u;
 static float urand() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f; }
 
-template <int C, int BN, int BM>
+template <int C, int BN, int BM, int RT = 2>
 int run(int n_rows, int dil, int use_res) {
-    using S = CgShape<C, BN, BM>;
+    using S = CgShape<C, BN, BM, RT>;
     const int ks[3] = {11, 7, 3};
     const float in_slope = 0.1f, out_slope = use_res ? 1.0f : 0.1f;
     std::vector<std::vector<float>> w(3), bs(3);
@@ -52,7 +52,7 @@ int run(int n_rows, int dil, int use_res) {
     a.R0 = a.R1 = a.R2 = use_res ? dr : nullptr; a.Y0 = dy[0]; a.Y1 = dy[1]; a.Y2 = dy[2];
     a.k0 = 11; a.k1 = 7; a.k2 = 3; a.d0 = a.d1 = a.d2 = dil; a.nb0 = tiles; a.nb1 = tiles;
     a.ld = C; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
-    auto kern = cgemm_kernel<C, BN, BM>;
+    auto kern = cgemm_kernel<C, BN, BM, RT>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
     hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(S::NT), S::LDS, 0, a);
     CK(hipDeviceSynchronize());
@@ -106,7 +106,7 @@ int run(int n_rows, int dil, int use_res) {
         printf(" | epilogue %lld | total %lld\n", h[3 + nit] - h[2 + nit], h[3 + nit] - h[0]);
     }
     const double flops = 2.0 * 21 * (double)C * C * n_rows;
-    printf("C=%d BN=%d BM=%d n_rows=%d dil=%d res=%d blocks=%d LDS %zu: %.1f us per launch  %.1f TF/s   max |diff| %.3g  bad %zu\n", C, BN, BM, n_rows, dil, use_res,
+    printf("C=%d BN=%d BM=%d RT=%d n_rows=%d dil=%d res=%d blocks=%d LDS %zu: %.1f us per launch  %.1f TF/s   max |diff| %.3g  bad %zu\n", C, BN, BM, RT, n_rows, dil, use_res,
            3 * tiles, (size_t)S::LDS, us, flops / us * 1e-6, maxd, nbad);
     return 0;
 }
@@ -122,6 +122,9 @@ int main(int argc, char** argv) {
         if (C == 192) return run<192, 192, 128>(n, dil, res);
         if (C == 384) return run<384, 192, 128>(n, dil, res);
         if (C == 128) return run<128, 128, 128>(n, dil, res);
+    } else if (bm == 2564) {     // 256 rows, 4 waves of 128 rows
+        if (C == 256) return run<256, 128, 256, 4>(n, dil, res);
+        if (C == 128) return run<128, 128, 256, 4>(n, dil, res);
     } else {
         if (C == 256) return run<256, 128, 256>(n, dil, res);
         if (C == 192) return run<192, 192, 256>(n, dil, res);
