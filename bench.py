@@ -467,6 +467,16 @@ def run_single(a):
                 au, _ = vq.decode(tk, txt, ge, noise_scale=0.5)
                 torch.cuda.synchronize(dev); t_dec += time.perf_counter() - s1
             s2 = time.perf_counter()
+            ta = []
+            for _ in range(10):   # time to first audio through the REAL first-chunk path: prefill + 25 tokens + decode() of them (50 frames)
+                torch.cuda.synchronize(dev); q0 = time.perf_counter()
+                xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
+                t2s.prefill(1, 0, xy, xl, yl)
+                t2s._decode(1, 25)
+                vq.decode(tk[:, :, :25], txt, ge, noise_scale=0.5)
+                torch.cuda.synchronize(dev)
+                ta.append((time.perf_counter() - q0) * 1e3)
+            out["ttfa_decode_ms_p50"] = float(np.median(ta))
             out["value_with_enc_p"] = nrep * N_NEW / (s2 - s0)
             out["decode_ms"] = t_dec / nrep * 1e3
             out["value_with_enc_p_note"] = ("semantic tokens/s of GPT + SynthesizerTrn.decode (enc_p + noise + flow + Generator, noise_scale 0.5) on "
@@ -680,6 +690,10 @@ def run_cb(a):
             vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
             vq.load_state_dict(synth.sovits_weights(hps, seed=1234))
             vq.initialize_runtime(vdtype, dev, [])
+            # untimed: one batch through decode() (workspace allocation, kernel attributes, code load)
+            wl = [50 + 17 * i for i in range(10)]
+            vq.decode(torch.zeros(1, 1, sum(wl), dtype=torch.int64, device=dev), torch.cat([xs[i][40:] for i in range(10)])[None],
+                      ge.expand(-1, -1, sum(wl)), noise_scale=0.5, cuda_graph=False)
             torch.cuda.synchronize(dev)
             if dist is not None:
                 dist.barrier()

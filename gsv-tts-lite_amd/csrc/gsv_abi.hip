@@ -338,7 +338,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     T2SLayer& L = h->layers[l];
     AttnArgs<WT> a;
     a.xdirect = xsrc;
-    a.zpart = h->zpart;
+    a.zpart = (const typename Geo<WT>::PT*)h->zpart;
     a.b2 = l ? h->layers[l - 1].b2 : nullptr;
     a.x1 = h->x1buf;
     a.ln2g = l ? h->layers[l - 1].ln2g : nullptr;
@@ -347,7 +347,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     a.wqkv = (const WT*)L.wqkv_p; a.bqkv = L.bqkv_p; a.wo = (const WT*)L.wo_p;
     a.kc = (WT*)s.k_cache + (size_t)l * layer_elems;
     a.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
-    a.kv_len = s.kv_len; a.T = T; a.ypart = h->ypart; a.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
+    a.kv_len = s.kv_len; a.T = T; a.ypart = (typename Geo<WT>::PT*)h->ypart; a.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     if (l == 0 && fused_token) {
         StepTok& k = a.tk;
         k.tokpart = h->tokpart; k.tok_override = s.tok_override; k.ctl = s.ctl; k.x_len = s.x_len; k.pre_tokens = s.pre_tokens;
@@ -370,8 +370,8 @@ template <typename WT>
 void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     T2SLayer& L = h->layers[l];
     FfnArgs<WT> f;
-    f.ypart = h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
-    f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
+    f.ypart = (const typename Geo<WT>::PT*)h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
+    f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = (typename Geo<WT>::PT*)h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     const int B = s.batch;
     if (B > 16 && sizeof(WT) == 2) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B);
     else if (B > 8) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
@@ -406,7 +406,7 @@ int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirec
                int bump, hipStream_t st, const int32_t* slots = nullptr, const T2SBound* staged = nullptr) {
     const T2SLayer& L = h->layers.back();
     LogitsArgs<WT> a;
-    a.hdirect = hdirect; a.zpart = h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
+    a.hdirect = hdirect; a.zpart = (const typename Geo<WT>::PT*)h->zpart; a.b2 = L.b2; a.x1 = h->x1buf; a.ln2g = L.ln2g; a.ln2b = L.ln2b;
     a.wp = (const WT*)h->predict; a.V = h->cfg.vocab; a.eos = h->cfg.eos; a.vlimit = vlimit; a.slot0 = slot0; a.slots = slots;
     a.step = s.step; a.ctl = s.ctl; a.fctl = s.fctl; a.seen = s.seen; a.logits = s.logits; a.hidden = s.hidden;
     a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;

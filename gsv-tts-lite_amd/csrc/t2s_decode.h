@@ -83,9 +83,19 @@ template <> struct Unpack<bf16_t, 8> {
     }
 };
 
+// The partial 512-vectors that cross a kernel boundary (16 head partials of the out-proj, 32 slice partials of W2): fp32 on
+// fp32 handles (the parity mode sums exactly what the reference's GEMV sums, in slice order); IEEE half on bf16 handles -- a
+// consumer block reads 16 / 32 of them per sequence and that read is a third to a half of what it pulls.
+// Half, not bf16: 11 significant bits against 8, so a rounded partial carries an eighth of a bf16 operand's rounding error;
+// the values are O(1) sums behind a LayerNorm, far inside half's range.  The bf16-mode oracle rounds the same slices.
+template <typename WT> struct PartOf { using T = float; };
+template <> struct PartOf<bf16_t> { using T = _Float16; };
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
 template <typename WT> struct Geo {
     static constexpr int EPL = 16 / sizeof(WT);  // elements per 16-byte lane load
     static constexpr int CPR = kD / EPL / 64;    // 16-byte chunks per lane for one 512-wide row (1 bf16, 2 f32)
+    using PT = typename PartOf<WT>::T;
 };
 
 __device__ __forceinline__ raw16 ldg16(const void* p) { return *reinterpret_cast<const raw16*>(p); }
@@ -179,7 +189,8 @@ __device__ __forceinline__ float ln512(float v, bool owner, float g, float bta, 
 //            result in LDS stage[w][512];        -- issue() at kernel entry, park() after the pin
 //   stage B  thread t < 512 adds the 16 parked rows in index order, + bias + residual.
 // Fixed order everywhere => bit-reproducible.
-template <int NPART> struct PartialSum {
+template <int NPART, typename PT = float> struct PartialSum;
+template <int NPART> struct PartialSum<NPART, float> {
     static constexpr int NPW = NPART / kNW;     // rows per wave (2 for the 32 FFN slices, 1 for the 16 heads)
     static_assert(NPART % kNW == 0, "NPART");
     f32x4 p[NPW][2];
@@ -198,26 +209,6 @@ template <int NPART> struct PartialSum {
             bias = b[t]; resid = r[t]; lng = g[t]; lnb = beta[t];
         }
     }
-    // Same loads for payload another workgroup published INSIDE this launch: device-coherent
-    // (sc1) loads that cannot be served from a stale line of this CU's L1 / this XCD's L2.
-    __device__ __forceinline__ void issue_coherent(const float* part, const float* __restrict__ b, const float* r,
-                                                   const float* __restrict__ g, const float* __restrict__ beta,
-                                                   size_t part_bytes) {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(part), 0, (int)part_bytes, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NPW; ++j)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const unsigned off = (unsigned)(((wid * NPW + j) * kD + c * 256 + lane * 4) * sizeof(float));
-                p[j][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17));  // sc0 sc1
-            }
-        if (threadIdx.x < kD) {
-            const int t = threadIdx.x;
-            bias = b[t]; lng = g[t]; lnb = beta[t];
-            resid = __hip_atomic_load(r + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
     __device__ __forceinline__ void park(float* __restrict__ stage) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -227,6 +218,44 @@ template <int NPART> struct PartialSum {
             for (int j = 1; j < NPW; ++j) s += p[j][c];
             *reinterpret_cast<f32x4*>(stage + wid * kD + c * 256 + lane * 4) = s;
         }
+    }
+    __device__ __forceinline__ float finish(const float* __restrict__ stage) {  // owners only, after a barrier
+        const int t = threadIdx.x;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNW; ++w) s += stage[w * kD + t];
+        return s + bias + resid;
+    }
+};
+
+// half rows: ONE 1-KiB wave load per row (lane l holds elements 8 l .. 8 l + 7), summed in fp32
+template <int NPART> struct PartialSum<NPART, _Float16> {
+    static constexpr int NPW = NPART / kNW;
+    static_assert(NPART % kNW == 0, "NPART");
+    u32x4 p[NPW][1];
+    float bias, resid, lng, lnb;
+    __device__ __forceinline__ void issue(const _Float16* __restrict__ part, const float* __restrict__ b,
+                                          const float* __restrict__ r, const float* __restrict__ g,
+                                          const float* __restrict__ beta) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) p[j][0] = *reinterpret_cast<const u32x4*>(part + (size_t)(wid * NPW + j) * kD + lane * 8);
+        if (threadIdx.x < kD) {
+            const int t = threadIdx.x;
+            bias = b[t]; resid = r[t]; lng = g[t]; lnb = beta[t];
+        }
+    }
+    __device__ __forceinline__ void park(float* __restrict__ stage) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            const f16x8 h = __builtin_bit_cast(f16x8, p[j][0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = j == 0 ? (float)h[e] : s[e] + (float)h[e];
+        }
+        *reinterpret_cast<f32x4*>(stage + wid * kD + lane * 8) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(stage + wid * kD + lane * 8 + 4) = f32x4{s[4], s[5], s[6], s[7]};
     }
     __device__ __forceinline__ float finish(const float* __restrict__ stage) {  // owners only, after a barrier
         const int t = threadIdx.x;
@@ -264,7 +293,8 @@ template <typename WT, int K> struct Panel {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) w[it] = ldg16(panel + (size_t)(rsub + it * RPI) * K + part * EPL);
     }
-    __device__ __forceinline__ void finish(const float* __restrict__ vec_lds, float* __restrict__ out) {
+    template <typename OT>
+    __device__ __forceinline__ void finish(const float* __restrict__ vec_lds, OT* __restrict__ out) {
         const int tid = threadIdx.x;
         const int part = tid % LPR, rsub = tid / LPR;
         float vr[EPL];
@@ -278,7 +308,7 @@ template <typename WT, int K> struct Panel {
 #pragma unroll
             for (int i = 0; i < EPL; ++i) s = fmaf(wv[i], vr[i], s);
             s = group_sum<LPR>(s);
-            if (part == 0) out[rsub + it * RPI] = s;
+            if (part == 0) out[rsub + it * RPI] = (OT)s;
         }
     }
 };
@@ -340,7 +370,7 @@ template <typename WT>
 struct AttnArgs {
     // layer input: MODE 0 -> xdirect[B][512]; MODE 1 -> LN2(sum_j zpart + b2 + x1) of the previous layer
     const float* xdirect;
-    const float* zpart;  // [B][kNJ][512]
+    const typename PartOf<WT>::T* zpart;  // [B][kNJ][512]
     const float* b2;
     const float* x1;     // [B][512]
     const float* ln2g;
@@ -353,7 +383,7 @@ struct AttnArgs {
     WT* vc;
     const int64_t* kv_len;
     int T;
-    float* ypart;        // [B][16][512]
+    typename PartOf<WT>::T* ypart;        // [B][16][512]
     unsigned long long* dbg;
     StepTok tk;          // MODE 2 only
 };
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     const int part = tid % LPR, rsub = tid / LPR;
 
     // ---- issue everything whose address is known now, in consumption order
-    PartialSum<kNJ> ps;
+    PartialSum<kNJ, typename Geo<WT>::PT> ps;
     float xd = 0.f;
     StepTokLoads tl;
     tl.tp.v = 0.f;
@@ -581,7 +611,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 
 template <typename WT>
 struct FfnArgs {
-    const float* ypart;  // [B][16][512]
+    const typename PartOf<WT>::T* ypart;  // [B][16][512]
     const float* bo;
     const float* x;      // [B][512] layer input (residual)
     const float* ln1g;
@@ -590,7 +620,7 @@ struct FfnArgs {
     const WT* w1;        // [2048][512] (torch layout; slice j = rows j*64..)
     const float* b1;
     const WT* w2p;       // [32][512][64]  w2p[j][n][i] = W2[n][j*64+i]
-    float* zpart;        // [B][32][512]
+    typename PartOf<WT>::T* zpart;        // [B][32][512]
     unsigned long long* dbg;
 };
 
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     const bool owner = tid < kD;
     stamp(a.dbg, 8);
 
-    PartialSum<kH> ps;
+    PartialSum<kH, typename Geo<WT>::PT> ps;
     ps.issue(a.ypart + (size_t)b * kH * kD, a.bo, a.x + (size_t)b * kD, a.ln1g, a.ln1b);
     __builtin_amdgcn_s_barrier();  // all partial loads queued before any weight load (see attn kernel)
     asm volatile("" : : : "memory");
@@ -655,7 +685,7 @@ template <typename WT>
 struct LogitsArgs {
     // final hidden: MODE 1 -> LN2(sum zpart + b2 + x1) of the last layer; MODE 0 -> hdirect[B][512]
     const float* hdirect;
-    const float* zpart;
+    const typename PartOf<WT>::T* zpart;
     const float* b2;
     const float* x1;
     const float* ln2g;
@@ -692,7 +722,7 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     const int nrow = min(rpb, a.V - vbase);
     const bool owner = tid < kD;
 
-    PartialSum<kNJ> ps;
+    PartialSum<kNJ, typename Geo<WT>::PT> ps;
     float xd = 0.f;
     if constexpr (MODE == 0) {
         if (owner) xd = a.hdirect[(size_t)r_ * kD + tid];

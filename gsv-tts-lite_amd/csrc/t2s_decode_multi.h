@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
     }
 
     // ---- issue everything whose address is known now, in consumption order (t2s_decode.h, "latency discipline")
-    PartialSum<kNJ> ps[R];
+    PartialSum<kNJ, typename Geo<WT>::PT> ps[R];
     float xd[R];
     StepTokLoads tl[R];
 #pragma unroll
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_multi_kernel(FfnArgs<WT> a, int B
     constexpr int RW = kFJ / kNW;
     const bool owner = tid < kD;
 
-    PartialSum<kH> ps[R];
+    PartialSum<kH, typename Geo<WT>::PT> ps[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int b = min(b0 + r, B - 1);

@@ -58,6 +58,9 @@ ORC_API void orc_set_num_threads(int n) {
  *   ORC_R_ATTN    prompt attention: q and the un-normalised probabilities rounded to bf16 (MFMA flash attention)
  *   ORC_R_FP8     qkv / mlp.0 / mlp.2 inputs rounded to e4m3 at unit scale, saturating (batched fp8 step)
  *   ORC_R_VOC     flow + Generator: every stored activation rounded to bf16 where the bf16 HIP path stores bf16
+ *   ORC_R_PART    decode step of the partial-sum kernels (< batched_min sequences): the out-proj is summed from its 16
+ *                 per-head partial vectors and W2 from its 32 per-slice (64 hidden units) partials, each rounded to IEEE half --
+ *                 the form in which they cross the kernel boundary on bf16 handles (csrc/t2s_decode.h PartOf)
  *                 (conv outputs after bias / conditioning / residual; the leaky-ReLU'd conv operands; the branch mean;
  *                 the flow's h, gate output, skip operand and updated half), fp32 accumulation inside each op
  * 0 = the fp32 reference arithmetic. */
@@ -66,6 +69,7 @@ ORC_API void orc_set_num_threads(int n) {
 #define ORC_R_ATTN 4
 #define ORC_R_FP8 8
 #define ORC_R_VOC 16
+#define ORC_R_PART 32
 static int g_round = 0;
 ORC_API void orc_set_rounding(int flags) { g_round = flags; }
 ORC_API int orc_get_rounding(void) { return g_round; }
@@ -96,6 +100,28 @@ static inline float e4m3r(float f) {
     }
     return copysignf(a, f);
 }
+/* round-to-nearest-even through IEEE binary16 (normal and subnormal range; overflow saturates to +-inf as v_cvt_f16_f32 does) */
+static float f16r(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    const uint32_t sign = v.u & 0x80000000u;
+    v.u &= 0x7fffffffu;
+    if (v.u >= 0x7f800000u) return f;                       /* inf / nan */
+    if (v.f >= 65520.0f) { v.u = sign | 0x7f800000u; return v.f; }
+    if (v.f < 6.103515625e-05f) {                            /* subnormal half: multiples of 2^-24 */
+        const float q = rintf(v.f * 16777216.0f);            /* rintf: round-half-even in the default mode */
+        v.f = q * 5.9604644775390625e-08f;
+        v.u |= sign;
+        return v.f;
+    }
+    uint32_t u = v.u;
+    u += 0xfffu + ((u >> 13) & 1u);                           /* keep 10 mantissa bits, ties to even */
+    u &= ~0x1fffu;
+    v.u = u | sign;
+    return v.f;
+}
+ORC_API void orc_round_f16(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = f16r(x[i]); }
+
 ORC_API void orc_round_bf16(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = bf16r(x[i]); }
 static void voc_round(float* x, size_t n) {
     if (!(g_round & ORC_R_VOC)) return;
@@ -193,14 +219,27 @@ static void linear_r(const float* x, int M, int K, const float* w, const float* 
 }
 
 /* tail of a block shared by prefill and decode: x = LN1(x + attn@Wo^T + bo); x = LN2(x + MLP(x)) */
-static void block_tail(const layer_t* L, int M, int D, float* x, const float* attn, float* tmp_d,
+/* y[m][n] = sum over slices s of f16r( sum_{k in slice s} x[m][k] w[n][k] ) + b[n]: the partial-sum kernels' kernel-boundary form */
+static void linear_sliced(const float* x, int M, int K, const float* w, const float* b, int N, int slice, float* y) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            float acc = 0.f;
+            for (int k0 = 0; k0 < K; k0 += slice) acc += f16r(dotf(x + (size_t)m * K + k0, w + (size_t)n * K + k0, slice));
+            y[(size_t)m * N + n] = acc + b[n];
+        }
+}
+
+static void block_tail(const layer_t* L, int M, int D, int H, int part, float* x, const float* attn, float* tmp_d,
                        float* tmp_f) {
     int F = 4 * D;
-    linear_r(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0, 0);
+    if (part) linear_sliced(attn, M, D, L->out_w, L->out_b, D, D / H, tmp_d);       /* 16 head partials */
+    else linear_r(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0, 0);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln1_g, L->ln1_b, 1e-5f, x);
     linear_r(x, M, D, L->w1, L->b1, F, tmp_f, 1, 1);
-    linear_r(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0, 1);
+    if (part) linear_sliced(tmp_f, M, F, L->w2, L->b2, D, 64, tmp_d);               /* 32 slices of 64 hidden units */
+    else linear_r(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0, 1);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln2_g, L->ln2_b, 1e-5f, x);
 }
@@ -259,7 +298,7 @@ ORC_API void orc_t2s_decode(const float* pack, int n_layer, int D, int H, int B,
                 }
                 free(s);
             }
-        block_tail(&L, B, D, x, attn, tmp_d, tmp_f);
+        block_tail(&L, B, D, H, (g_round & ORC_R_PART) != 0, x, attn, tmp_d, tmp_f);
     }
     free(qkv); free(attn); free(tmp_d); free(tmp_f);
 }
@@ -327,7 +366,7 @@ ORC_API void orc_t2s_prefill(const float* pack, int n_layer, int D, int H, int B
                 }
                 free(s);
             }
-        block_tail(&L, (int)M, D, x, attn, tmp_d, tmp_f);
+        block_tail(&L, (int)M, D, H, 0, x, attn, tmp_d, tmp_f);      /* the prompt pass is the GEMM chain: no partial rows */
     }
     free(qkv); free(attn); free(tmp_d); free(tmp_f);
 }

@@ -124,7 +124,7 @@ def sine_pe(n_pos: int, dim: int) -> np.ndarray:
     return pe
 
 
-R_KV, R_LIN, R_ATTN, R_FP8, R_VOC = 1, 2, 4, 8, 16     # gsv_oracle.c ORC_R_*
+R_KV, R_LIN, R_ATTN, R_FP8, R_VOC, R_PART = 1, 2, 4, 8, 16, 32     # gsv_oracle.c ORC_R_*
 
 
 def round_bf16(a):
@@ -270,6 +270,8 @@ class T2SOracle:
                 if self.numerics == "fp8":
                     flags |= R_FP8
                     pack = self.pack8
+            else:                                          # partial-sum kernels: head / slice partials cross the boundary as fp16
+                flags |= R_PART
         lib().orc_set_rounding(flags)
         try:
             lib().orc_t2s_decode(_fp(pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),
