@@ -128,6 +128,7 @@ int gsv::abi_fail(int code, const char* fmt, ...) {
 // =============================================================================================
 struct T2SLayer {
     void *wqkv_p = nullptr, *wo_p = nullptr, *w1 = nullptr, *w2_p = nullptr;  // decode panels (WT)
+    void* w2_p64 = nullptr;                                                    // W2 in 64 panels of 32 columns (bf16 handles, <= kFineMaxB sequences)
     float *bqkv_p = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr,
           *ln2g = nullptr, *ln2b = nullptr;
     PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill / batched step (MFMA fragments)
@@ -248,6 +249,10 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = want((int64_t)kD * kF)) return rc;
         if (!L.w2_p) HIPCHK(hipMalloc(&L.w2_p, sizeof(WT) * kD * kF));
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p, kNJ, kFJ);
+        if (sizeof(WT) == 2) {
+            if (!L.w2_p64) HIPCHK(hipMalloc(&L.w2_p64, sizeof(WT) * kD * kF));
+            hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p64, kNJFine, kF / kNJFine);
+        }
         free_conv(L.g_w2);
         if (int rc = pack_conv<WT>(L.g_w2, data, kD, kF, 1, kF, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, kD, kF, &L.f8_w2, &L.s_w2, st)) return rc;
@@ -363,6 +368,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     }
     if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
+    else if (ffn_slices<WT>(B) == kNJFine) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
 
@@ -375,7 +381,10 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     const int B = s.batch;
     if (B > 16 && sizeof(WT) == 2) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B);
     else if (B > 8) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
-    else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
+    else if (ffn_slices<WT>(B) == kNJFine) {
+        f.w2p = (const WT*)L.w2_p64;
+        hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
+    } else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
 }
 
 // the R-sequences-per-block kernels use more than 64 KB of dynamic LDS
@@ -412,6 +421,7 @@ int t2s_logits(gsv_t2s* h, const gsv_t2s_state& s, int mode, const float* hdirec
     a.tokpart = h->tokpart; a.kv_len = s.kv_len; a.bump = bump;
     if (staged) { a.step = staged->sg_step; a.logits = staged->sg_logits; a.hidden = staged->sg_hidden; a.tokpart = staged->sg_tok; a.kv_len = staged->sg_kv; }
     if (mode == 0) hipLaunchKernelGGL((t2s_logits_kernel<WT, 0>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
+    else if (ffn_slices<WT>(s.batch) == kNJFine) hipLaunchKernelGGL((t2s_logits_kernel<WT, 1, kNJFine>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
     else hipLaunchKernelGGL((t2s_logits_kernel<WT, 1>), dim3(kNP, nrows), dim3(kNT), 0, st, a);
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -738,7 +748,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
         t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
-        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
+        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
                         (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b, L.f8_qkv, L.f8_w1, L.f8_w2,
                         (void*)L.s_qkv, (void*)L.s_w1, (void*)L.s_w2})
             if (p) (void)hipFree(p);
@@ -957,6 +967,7 @@ int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped) {
 }
 
 int gsv_t2s_batched_min(gsv_t2s* h) { return h && h->cfg.dtype == GSV_BF16 ? h->batched_min : 0x7fffffff; }
+int gsv_t2s_ffn_slices(gsv_t2s* h, int batch) { return h && h->cfg.dtype == GSV_BF16 ? ffn_slices<bf16_t>(batch) : kNJ; }
 
 size_t gsv_t2s_device_bytes(gsv_t2s* h) {
     if (!h) return 0;

@@ -30,6 +30,13 @@ constexpr int kDh = 32;        // head dim
 constexpr int kF = 2048;       // MLP hidden
 constexpr int kNJ = 32;        // FFN slices (blocks) per sequence
 constexpr int kFJ = kF / kNJ;  // hidden units per slice
+// <= kFineMaxB sequences on a bf16 handle: 64 slices of 32 hidden units.  An FFN block then pulls 80 KB instead of 144 KB at the
+// per-CU fabric rate, an attention block 32 KB more of (half) partial rows: -5 % on the step at 1-4 sequences, +3..10 % from 8 on
+// (profiles/r03_ffn_64_slices.txt), hence the switch.  The slice count is part of the arithmetic (each slice partial is rounded
+// to half): gsv_t2s_ffn_slices reports it and the oracle sums the same slices.
+constexpr int kNJFine = 64;
+constexpr int kFineMaxB = 4;
+template <typename WT> inline int ffn_slices(int B) { return sizeof(WT) == 2 && B <= kFineMaxB ? kNJFine : kNJ; }
 constexpr int kNP = 16;        // logits slices per sequence
 constexpr float kEps = 1e-5f;
 
@@ -56,9 +63,10 @@ __device__ __forceinline__ void eos_publish(int32_t* eos_host, int slot, int val
 //    overlap (one wave issues ~1 VALU op per 4-5 cycles), so a block is 16 waves (1024 threads):
 //    4 waves per SIMD share the rows/keys, each wave's stream is a quarter of a 256-thread block's.
 
-// optional phase timestamps (bring-up aid): block (0,0) thread 0 writes clock64() into dbg[slot]
+// optional phase timestamps (bring-up aid): in block (0,0) the first lane of wave 0 writes clock64() into dbg[slot], the
+// first lane of the last wave into dbg[16 + slot] (32 slots)
 __device__ __forceinline__ void stamp(unsigned long long* dbg, int slot) {
-    if (dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dbg[slot] = clock64();
+    if (dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x == 0 || threadIdx.x == 960)) dbg[slot + (threadIdx.x ? 16 : 0)] = clock64();
 }
 
 constexpr int kNT = 1024;       // threads per decode block
@@ -134,6 +142,43 @@ __device__ __forceinline__ void lane_x(const float* xs, float (&xr)[8]) {
         for (int i = 0; i < EPL; ++i) xr[c * EPL + i] = xs[c * (kD / Geo<WT>::CPR) + lane * EPL + i];
 }
 
+// ---- bf16 handles: dots on v_dot2c_f32_bf16 ---------------------------------------------------------------------------------
+// With the data in registers the attention / FFN blocks are VALU-issue bound (4 waves per SIMD; profiles/r03_decode_phase_stamps.txt:
+// 11k of the attention block's 17k cycles are arithmetic after its last load has landed), and half of a bf16 row dot's
+// instructions only unpack weights.  v_dot2c_f32_bf16 takes the packed weights as they were loaded and does two MACs per
+// instruction; its other operand must be bf16 too, so an activation enters as the PAIR hi + lo (hi = the value truncated to bf16,
+// lo = bf16(value - hi), which is exact before its rounding): 16 significant bits, a relative error <= 2^-17 per term -- far inside
+// the half rounding of the partial rows -- for one instruction per MAC and no unpack.  fp32 handles keep the fp32 FMA chain.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2c(uint32_t w, uint32_t x, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
+}
+// value -> (hi, lo) bf16 bit patterns
+__device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) {
+    const uint32_t b = __float_as_uint(v);
+    hi = (uint16_t)(b >> 16);
+    lo = f32_to_bf16(v - __uint_as_float(b & 0xffff0000u));
+}
+// a lane's 8 activations (elements 8 lane .. 8 lane + 7 of a vector stored as two bf16 arrays) as packed pairs
+struct XPair { raw16 hi, lo; };
+__device__ __forceinline__ XPair xpair_load(const uint16_t* __restrict__ vh, const uint16_t* __restrict__ vl, int first) {
+    XPair x;
+    x.hi = *reinterpret_cast<const raw16*>(vh + first);
+    x.lo = *reinterpret_cast<const raw16*>(vl + first);
+    return x;
+}
+// 8 weights (one 16-byte load) . 8 activations
+__device__ __forceinline__ float dot8(const raw16& w, const XPair& x) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a = dot2c(w[j], x.hi[j], a); b = dot2c(w[j], x.lo[j], b); }
+    return a + b;
+}
+// e^x of the softmax: fp32 handles keep expf (the parity mode); bf16 handles work in the base-2 domain on v_exp_f32
+template <bool FAST> __device__ __forceinline__ float sm_exp(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_exp2f(x); else return expf(x);
+}
+
 // N per-lane partials -> N wave totals: halve the value count at each of the first log2(N)
 // butterfly levels (N-1 shuffles), then finish the remaining levels on one value.
 // Every lane returns the total of value index sumN_index<N>().
@@ -152,7 +197,11 @@ template <> __device__ __forceinline__ float wave_sumN<4>(const float (&v)[4]) {
     for (int i = 0; i < 2; ++i) b[i] = halve32_sum(v[i], v[i + 2]);
     return row16_sum(halve16_sum(b[0], b[1]));
 }
+template <> __device__ __forceinline__ float wave_sumN<2>(const float (&v)[2]) {
+    return xor16_sum(row16_sum(halve32_sum(v[0], v[1])));
+}
 template <int N> __device__ __forceinline__ int sumN_index();
+template <> __device__ __forceinline__ int sumN_index<2>() { return (threadIdx.x >> 5) & 1; }
 template <> __device__ __forceinline__ int sumN_index<8>() {
     const int lane = threadIdx.x & 63;
     return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
@@ -293,6 +342,19 @@ template <typename WT, int K> struct Panel {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) w[it] = ldg16(panel + (size_t)(rsub + it * RPI) * K + part * EPL);
     }
+    // bf16 handles: the K-vector as bf16 hi / lo arrays (xpair_load)
+    template <typename OT>
+    __device__ __forceinline__ void finish2(const uint16_t* __restrict__ vh, const uint16_t* __restrict__ vl, OT* __restrict__ out) {
+        static_assert(EPL == 8, "bf16 panels");
+        const int tid = threadIdx.x;
+        const int part = tid % LPR, rsub = tid / LPR;
+        const XPair x = xpair_load(vh, vl, part * 8);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float s = group_sum<LPR>(dot8(w[it], x));
+            if (part == 0) out[rsub + it * RPI] = (OT)s;
+        }
+    }
     template <typename OT>
     __device__ __forceinline__ void finish(const float* __restrict__ vec_lds, OT* __restrict__ out) {
         const int tid = threadIdx.x;
@@ -370,7 +432,7 @@ template <typename WT>
 struct AttnArgs {
     // layer input: MODE 0 -> xdirect[B][512]; MODE 1 -> LN2(sum_j zpart + b2 + x1) of the previous layer
     const float* xdirect;
-    const typename PartOf<WT>::T* zpart;  // [B][kNJ][512]
+    const typename PartOf<WT>::T* zpart;  // [B][NJ][512]
     const float* b2;
     const float* x1;     // [B][512]
     const float* ln2g;
@@ -390,7 +452,7 @@ struct AttnArgs {
 
 constexpr int kAttnLdsFloats = kD + 96 + 32 + 2 * kNW + kNW * 32 + 2 * kNW + kNW * kD;
 
-template <typename WT, int MODE>
+template <typename WT, int MODE, int NJ = kNJ>
 __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     __shared__ __attribute__((aligned(16))) float smem[kAttnLdsFloats];
     float* xs = smem;             // 512
@@ -409,6 +471,14 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     constexpr int KCH = 2;                 // iterations held in registers per chunk (512 positions bf16, 256 f32)
     constexpr int RW = 96 / kNW;           // 6 QKV rows per wave
     const bool owner = tid < kD;
+    constexpr bool BF = sizeof(WT) == 2;   // bf16 handle: dots on v_dot2c_f32_bf16, activations as bf16 (hi, lo) pairs in LDS
+    uint16_t* xh = reinterpret_cast<uint16_t*>(xs);      // [512] hi, [512] lo over xs
+    uint16_t* xl = xh + kD;
+    uint16_t* qh = reinterpret_cast<uint16_t*>(qkv);     // q hi [32], q lo [32], the new key [32] over qkv[0..47]; v stays fp32 at qkv[64..]
+    uint16_t* ql = qh + 32;
+    uint16_t* kn = qh + 64;
+    uint16_t* atth = reinterpret_cast<uint16_t*>(att);   // attention output hi [32], lo [32] over att
+    uint16_t* attl = atth + 32;
     stamp(a.dbg, 0);
 
     int n = (int)a.kv_len[b];
@@ -422,7 +492,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     const int part = tid % LPR, rsub = tid / LPR;
 
     // ---- issue everything whose address is known now, in consumption order
-    PartialSum<kNJ, typename Geo<WT>::PT> ps;
+    PartialSum<NJ, typename Geo<WT>::PT> ps;
     float xd = 0.f;
     StepTokLoads tl;
     tl.tp.v = 0.f;
@@ -431,7 +501,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     } else if constexpr (MODE == 2) {
         tl = steptok_issue(a.tk, b, lane);
     } else {
-        ps.issue(a.zpart + (size_t)b * kNJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
+        ps.issue(a.zpart + (size_t)b * NJ * kD, a.b2, a.x1 + (size_t)b * kD, a.ln2g, a.ln2b);
     }
     // partials first: a CU serves its waves' loads in issue order and waves start staggered, so
     // without this rendezvous the last wave's partial rows queue behind the first waves' weights
@@ -458,6 +528,10 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
     else if constexpr (MODE == 2) asm volatile("" : "+v"(tl.tp.v) : : "memory");
     else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
+#ifdef GSV_DBG_DRAIN   // measurement only: every load of the block has landed before any arithmetic starts
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    __syncthreads();
+#endif
     stamp(a.dbg, 1);
 
     // ---- layer input
@@ -472,7 +546,8 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     }
     if (owner) {
-        xs[tid] = v;
+        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
+        else xs[tid] = v;
         if (h == 0) a.xout[(size_t)b * kD + tid] = v;
     }
     __syncthreads();
@@ -481,21 +556,33 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // ---- q, k, v of this head: 96 rows, 6 per wave.  k and v are rounded through the cache type
     //      (this step must see exactly what later steps read back) and appended at position n.
     {
-        float xr[8];
-        lane_x<WT>(xs, xr);
         float acc[8];
+        if constexpr (BF) {
+            const XPair x = xpair_load(xh, xl, lane * 8);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = u < RW ? row_dot<WT>(wq[u < RW ? u : 0], xr) : 0.f;
+            for (int u = 0; u < 8; ++u) acc[u] = u < RW ? dot8(wq[u < RW ? u : 0][0], x) : 0.f;
+        } else {
+            float xr[8];
+            lane_x<WT>(xs, xr);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = u < RW ? row_dot<WT>(wq[u < RW ? u : 0], xr) : 0.f;
+        }
         const float tot = wave_sumN<8>(acc);
         if ((lane & 7) == 0 && oi < RW) {
             const int row = wid * RW + oi;
             float val = tot + bq;
+            WT s = from_f32<WT>(val);
             if (row >= 32) {
-                const WT s = from_f32<WT>(val);
                 val = to_f32<WT>(s);
                 if (row < 64) Kp[(size_t)nw * kDh + row - 32] = s; else Vp[(size_t)nw * kDh + row - 64] = s;
             }
-            qkv[row] = val;
+            if constexpr (BF) {
+                if (row < 32) { uint16_t vh, vl; split_bf16(val, vh, vl); qh[row] = vh; ql[row] = vl; }
+                else if (row < 64) kn[row - 32] = s;     // the new key is a bf16 value: it enters the score dot as it is
+                else qkv[row] = val;
+            } else {
+                qkv[row] = val;
+            }
         }
     }
     __syncthreads();
@@ -504,10 +591,16 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // ---- single-pass attention over [0, n]: every thread owns the same rows of K and of V, so the
     //      scores never leave registers; each wave keeps a running (max, sum, P.V) and the 16 waves
     //      are merged once at the end (flash-decoding style, deterministic order).
-    const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+    // 1/sqrt(32); bf16 handles keep the scores in the base-2 domain (x log2 e) for v_exp_f32
+    const float scale = BF ? 0.17677669529663687f * 1.4426950408889634f : 0.17677669529663687f;
     float qr[EPL];
+    XPair qp;
+    if constexpr (BF) {
+        qp = xpair_load(qh, ql, part * 8);
+    } else {
 #pragma unroll
-    for (int i = 0; i < EPL; ++i) qr[i] = qkv[part * EPL + i];
+        for (int i = 0; i < EPL; ++i) qr[i] = qkv[part * EPL + i];
+    }
     float m_run = -INFINITY, l_run = 0.f, acc[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
@@ -524,19 +617,27 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
             const int r = c0 + rsub + it * RPI;
-            float kk[EPL];
-            Unpack<WT, EPL>::run(kreg[it], kk);
             float s = 0.f;
+            if constexpr (BF) {
+                s = dot8(kreg[it], qp);
+            } else {
+                float kk[EPL];
+                Unpack<WT, EPL>::run(kreg[it], kk);
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], kk[i], s);
+                for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], kk[i], s);
+            }
             s = group_sum<LPR>(s);
             sv[it] = r < n ? s * scale : -INFINITY;
             cmax = fmaxf(cmax, sv[it]);
         }
         {   // the new token's own key/value (position n) rides with wave 0's first chunk
             float s = 0.f;
+            if constexpr (BF) {
+                s = dot8(*reinterpret_cast<const raw16*>(kn + part * 8), qp);
+            } else {
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], qkv[32 + part * EPL + i], s);
+                for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], qkv[32 + part * EPL + i], s);
+            }
             s = group_sum<LPR>(s);
             sv[KCH] = (c0 == 0 && tid < LPR) ? s * scale : -INFINITY;
             cmax = fmaxf(cmax, sv[KCH]);
@@ -544,22 +645,23 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         cmax = wave_max(cmax);
         const float m_new = fmaxf(m_run, cmax);
         const float mref = (m_new == -INFINITY) ? 0.f : m_new;
-        const float f = expf(m_run - mref);      // exp(-inf) = 0 on the first live chunk
+        const float f = sm_exp<BF>(m_run - mref);      // exp(-inf) = 0 on the first live chunk
         l_run *= f;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) acc[i] *= f;
 #pragma unroll
         for (int it = 0; it < KCH; ++it) {
-            const float p = expf(sv[it] - mref);  // 0 for masked rows
+            const float p = sm_exp<BF>(sv[it] - mref);  // 0 for masked rows
             const bool live = sv[it] != -INFINITY;
+            const raw16 vr = live ? vreg[it] : raw16{0u, 0u, 0u, 0u};   // a masked row may hold anything (0 x NaN)
             float vv[EPL];
-            Unpack<WT, EPL>::run(vreg[it], vv);
+            Unpack<WT, EPL>::run(vr, vv);
             if (part == 0) l_run += p;
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, live ? vv[i] : 0.f, acc[i]);
+            for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, vv[i], acc[i]);
         }
         {
-            const float p = expf(sv[KCH] - mref);
+            const float p = sm_exp<BF>(sv[KCH] - mref);
             if (part == 0) l_run += p;
 #pragma unroll
             for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, qkv[64 + part * EPL + i], acc[i]);
@@ -593,17 +695,21 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         // merge the 16 waves: lane l (mod 16) owns wave l's (max, sum); 2x32 lanes own the 32 dims
         const float mw = pm[lane & 15], lw = pl[lane & 15];
         const float M = row16_max(mw);
-        const float den = row16_sum(lw * expf(mw - M));      // waves with no live rows: exp(-inf) = 0
+        const float den = row16_sum(lw * sm_exp<BF>(mw - M));      // waves with no live rows: exp(-inf) = 0
         const int hf = lane >> 5, d = lane & 31;
         float num = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], expf(pm[hf * 8 + w] - M), num);
+        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], sm_exp<BF>(pm[hf * 8 + w] - M), num);
         num = xor32_sum(num);
-        if (lane < 32) att[d] = num / den;
+        if (lane < 32) {
+            if constexpr (BF) { uint16_t vh, vl; split_bf16(num / den, vh, vl); atth[d] = vh; attl[d] = vl; }
+            else att[d] = num / den;
+        }
     }
     __syncthreads();
     stamp(a.dbg, 5);
-    po.finish(att, a.ypart + ((size_t)b * kH + h) * kD);
+    if constexpr (BF) po.finish2(atth, attl, a.ypart + ((size_t)b * kH + h) * kD);
+    else po.finish(att, a.ypart + ((size_t)b * kH + h) * kD);
     stamp(a.dbg, 6);
 }
 
@@ -619,37 +725,47 @@ struct FfnArgs {
     float* x1out;        // [B][512] LN1 output, written by slice 0
     const WT* w1;        // [2048][512] (torch layout; slice j = rows j*64..)
     const float* b1;
-    const WT* w2p;       // [32][512][64]  w2p[j][n][i] = W2[n][j*64+i]
-    typename PartOf<WT>::T* zpart;        // [B][32][512]
+    const WT* w2p;       // [NJ][512][FJ]  w2p[j][n][i] = W2[n][j*FJ+i]
+    typename PartOf<WT>::T* zpart;        // [B][NJ][512]
     unsigned long long* dbg;
 };
 
-template <typename WT>
+template <typename WT, int NJ = kNJ>
 __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
-    __shared__ __attribute__((aligned(16))) float smem[kD + kFJ + 2 * kNW + kNW * kD];
+    constexpr int FJ = kF / NJ;    // hidden units of this slice
+    __shared__ __attribute__((aligned(16))) float smem[kD + FJ + 2 * kNW + kNW * kD];
     float* xs = smem;
     float* hb = xs + kD;
-    float* red = hb + kFJ;
+    float* red = hb + FJ;
     float* stage = red + 2 * kNW;
     const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int CPR = Geo<WT>::CPR;
-    constexpr int RW = kFJ / kNW;  // 4 W1 rows per wave
+    constexpr int RW = FJ / kNW;   // 4 (2) W1 rows per wave
     const bool owner = tid < kD;
+    constexpr bool BF = sizeof(WT) == 2;   // bf16 handle: dots on v_dot2c_f32_bf16 (see dot8)
+    uint16_t* xh = reinterpret_cast<uint16_t*>(xs);
+    uint16_t* xl = xh + kD;
+    uint16_t* hbh = reinterpret_cast<uint16_t*>(hb);     // hidden units hi [FJ], lo [FJ] over hb
+    uint16_t* hbl = hbh + FJ;
     stamp(a.dbg, 8);
 
     PartialSum<kH, typename Geo<WT>::PT> ps;
     ps.issue(a.ypart + (size_t)b * kH * kD, a.bo, a.x + (size_t)b * kD, a.ln1g, a.ln1b);
     __builtin_amdgcn_s_barrier();  // all partial loads queued before any weight load (see attn kernel)
     asm volatile("" : : : "memory");
-    const int row0 = j * kFJ + wid * RW;
+    const int row0 = j * FJ + wid * RW;
     raw16 w1r[RW][CPR];
 #pragma unroll
     for (int r = 0; r < RW; ++r) row_load<WT>(a.w1 + (size_t)(row0 + r) * kD, w1r[r]);
-    Panel<WT, kFJ> p2;
-    p2.issue(a.w2p + (size_t)j * kD * kFJ);
+    Panel<WT, FJ> p2;
+    p2.issue(a.w2p + (size_t)j * kD * FJ);
     const int oi = sumN_index<RW>();
     const float b1r = a.b1[row0 + oi];
     asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
+#ifdef GSV_DBG_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    __syncthreads();
+#endif
     stamp(a.dbg, 9);
 
     ps.park(stage);
@@ -659,23 +775,35 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     const float v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     stamp(a.dbg, 15);
     if (owner) {
-        xs[tid] = v;
+        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
+        else xs[tid] = v;
         if (j == 0) a.x1out[(size_t)b * kD + tid] = v;
     }
     __syncthreads();
     stamp(a.dbg, 10);
     {
-        float xr[8];
-        lane_x<WT>(xs, xr);
         float acc[RW];
+        if constexpr (BF) {
+            const XPair x = xpair_load(xh, xl, lane * 8);
 #pragma unroll
-        for (int u = 0; u < RW; ++u) acc[u] = row_dot<WT>(w1r[u], xr);
+            for (int u = 0; u < RW; ++u) acc[u] = dot8(w1r[u][0], x);
+        } else {
+            float xr[8];
+            lane_x<WT>(xs, xr);
+#pragma unroll
+            for (int u = 0; u < RW; ++u) acc[u] = row_dot<WT>(w1r[u], xr);
+        }
         const float tot = wave_sumN<RW>(acc);
-        if ((lane & 15) == 0) hb[wid * RW + oi] = fmaxf(tot + b1r, 0.f);
+        if ((lane & (64 / RW - 1)) == 0) {
+            const float hv = fmaxf(tot + b1r, 0.f);
+            if constexpr (BF) { uint16_t vh, vl; split_bf16(hv, vh, vl); hbh[wid * RW + oi] = vh; hbl[wid * RW + oi] = vl; }
+            else hb[wid * RW + oi] = hv;
+        }
     }
     __syncthreads();
     stamp(a.dbg, 11);
-    p2.finish(hb, a.zpart + ((size_t)b * kNJ + j) * kD);
+    if constexpr (BF) p2.finish2(hbh, hbl, a.zpart + ((size_t)b * NJ + j) * kD);
+    else p2.finish(hb, a.zpart + ((size_t)b * NJ + j) * kD);
     stamp(a.dbg, 12);
 }
 
@@ -706,7 +834,7 @@ struct LogitsArgs {
     int bump;
 };
 
-template <typename WT, int MODE>
+template <typename WT, int MODE, int NJ = kNJ>
 __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     __shared__ __attribute__((aligned(16))) float smem[kD + 2 * kNW + 128 + kNW * kD];
     float* xs = smem;
@@ -722,12 +850,12 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     const int nrow = min(rpb, a.V - vbase);
     const bool owner = tid < kD;
 
-    PartialSum<kNJ, typename Geo<WT>::PT> ps;
+    PartialSum<NJ, typename Geo<WT>::PT> ps;
     float xd = 0.f;
     if constexpr (MODE == 0) {
         if (owner) xd = a.hdirect[(size_t)r_ * kD + tid];
     } else {
-        ps.issue(a.zpart + (size_t)r_ * kNJ * kD, a.b2, a.x1 + (size_t)r_ * kD, a.ln2g, a.ln2b);
+        ps.issue(a.zpart + (size_t)r_ * NJ * kD, a.b2, a.x1 + (size_t)r_ * kD, a.ln2g, a.ln2b);
         __builtin_amdgcn_s_barrier();
     }
     asm volatile("" : : : "memory");

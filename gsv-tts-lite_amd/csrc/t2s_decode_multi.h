@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_multi_kernel(FfnArgs<WT> a, int B
 #pragma unroll
         for (int u = 0; u < RW; ++u) acc[u] = row_dot<WT>(w1r[u], xr);
         const float tot = wave_sumN<RW>(acc);
-        if ((lane & 15) == 0) hb[r * kFJ + wid * RW + oi] = fmaxf(tot + b1r, 0.f);
+        if ((lane & (64 / RW - 1)) == 0) hb[r * kFJ + wid * RW + oi] = fmaxf(tot + b1r, 0.f);
     }
     __syncthreads();
 #pragma unroll

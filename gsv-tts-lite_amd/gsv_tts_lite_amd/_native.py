@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsv_hip.so")
+LIB_PATH = os.environ.get("GSV_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libgsv_hip.so")   # GSV_HIP_LIB: an experimental build of the same ABI (tools/)
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 GSV_F32, GSV_BF16, GSV_FP8 = 0, 1, 2
@@ -19,7 +19,7 @@ EXPORTS = [
     "gsv_version", "gsv_last_error",
     "gsv_t2s_create", "gsv_t2s_destroy", "gsv_t2s_load_tensor", "gsv_t2s_finalize", "gsv_t2s_bind_state",
     "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_set_eos_mirror", "gsv_t2s_prefill_slots", "gsv_t2s_prefill_slots_staged", "gsv_t2s_commit_slots", "gsv_t2s_decode_hidden",
-    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min", "gsv_t2s_device_bytes",
+    "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min", "gsv_t2s_ffn_slices", "gsv_t2s_device_bytes",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow_dec_graph", "gsv_voc_resample_linear", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p", "gsv_voc_decode_workspace", "gsv_voc_decode",
     "gsv_align_workspace", "gsv_align_viterbi",
@@ -84,6 +84,7 @@ def lib():
         "gsv_t2s_flush": [vp, i, vp],
         "gsv_t2s_set_debug": [vp, vp],
         "gsv_t2s_batched_min": [vp],
+        "gsv_t2s_ffn_slices": [vp, ctypes.c_int],
         "gsv_t2s_time_kernels": [vp, i, i, ctypes.POINTER(ctypes.c_float), vp],
         "gsv_voc_create": [ctypes.POINTER(VocConfig), ctypes.POINTER(vp)],
         "gsv_voc_destroy": [vp],

@@ -168,6 +168,10 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
 /* Batch size from which gsv_t2s_decode runs the batched chain (INT_MAX on fp32 handles: never).  Tests mirror the
  * choice in the oracle, whose reduced-precision modes round the operands each path rounds. */
 int gsv_t2s_batched_min(gsv_t2s* h);
+/* FFN slices per sequence of the two-launches-per-layer step at this batch size: 32 slices of 64 hidden units, or -- bf16
+ * handles at <= 4 sequences -- 64 slices of 32.  Each slice's partial 512-vector crosses the kernel boundary rounded to half on
+ * bf16 handles, so the count is part of the arithmetic; the bf16-mode oracle sums the same slices (oracle.py). */
+int gsv_t2s_ffn_slices(gsv_t2s* h, int batch);
 /* Device memory the handle owns, in bytes (its arena's blocks: repacked weights, fragments, scratch, the staging of every
  * bound state).  Pieces given back inside the handle -- a state re-bound with gsv_t2s_bind_state, a tensor re-loaded with
  * gsv_t2s_load_tensor, scratch that grew -- are handed out again by size, so re-binding the same shapes or hot-swapping
@@ -182,8 +186,8 @@ size_t gsv_t2s_device_bytes(gsv_t2s* h);
  * token's pre_tokens / seen / eos_at entries and the partial-sum scratch, all of which the next real step
  * (or prefill) overwrites -- call it between utterances, not inside one. */
 int gsv_t2s_time_kernels(gsv_t2s* h, int batch, int iters, float* out_ms, void* stream);
-/* Bring-up aid: when `buf` (device, >= 16 x uint64) is non-null the LAST layer's attn/ffn kernels
- * write shader-clock timestamps of their phases into it (slots 0-6 attn, 8-12 ffn). */
+/* Bring-up aid: when `buf` (device, >= 32 x uint64) is non-null the LAST layer's attn/ffn kernels
+ * write shader-clock timestamps of their phases into it (slots 0-6 attn, 8-15 ffn: the block's first wave; + 16: its last). */
 int gsv_t2s_set_debug(gsv_t2s* h, void* buf);
 /* materialise the pending token of every slot into pre_tokens/seen/eos_at (idempotent) */
 int gsv_t2s_flush(gsv_t2s* h, int batch, void* stream);

@@ -61,6 +61,8 @@ ORC_API void orc_set_num_threads(int n) {
  *   ORC_R_PART    decode step of the partial-sum kernels (< batched_min sequences): the out-proj is summed from its 16
  *                 per-head partial vectors and W2 from its 32 per-slice (64 hidden units) partials, each rounded to IEEE half --
  *                 the form in which they cross the kernel boundary on bf16 handles (csrc/t2s_decode.h PartOf)
+ *   ORC_R_FINE    with ORC_R_PART: W2 from 64 slices of 32 hidden units (the library's choice at <= 4 sequences,
+ *                 gsv_t2s_ffn_slices)
  *                 (conv outputs after bias / conditioning / residual; the leaky-ReLU'd conv operands; the branch mean;
  *                 the flow's h, gate output, skip operand and updated half), fp32 accumulation inside each op
  * 0 = the fp32 reference arithmetic. */
@@ -70,6 +72,7 @@ ORC_API void orc_set_num_threads(int n) {
 #define ORC_R_FP8 8
 #define ORC_R_VOC 16
 #define ORC_R_PART 32
+#define ORC_R_FINE 64
 static int g_round = 0;
 ORC_API void orc_set_rounding(int flags) { g_round = flags; }
 ORC_API int orc_get_rounding(void) { return g_round; }
@@ -238,7 +241,7 @@ static void block_tail(const layer_t* L, int M, int D, int H, int part, float* x
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln1_g, L->ln1_b, 1e-5f, x);
     linear_r(x, M, D, L->w1, L->b1, F, tmp_f, 1, 1);
-    if (part) linear_sliced(tmp_f, M, F, L->w2, L->b2, D, 64, tmp_d);               /* 32 slices of 64 hidden units */
+    if (part) linear_sliced(tmp_f, M, F, L->w2, L->b2, D, (g_round & ORC_R_FINE) ? 32 : 64, tmp_d);   /* 32 slices of 64 hidden units, or 64 of 32 */
     else linear_r(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0, 1);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln2_g, L->ln2_b, 1e-5f, x);

@@ -124,7 +124,7 @@ def sine_pe(n_pos: int, dim: int) -> np.ndarray:
     return pe
 
 
-R_KV, R_LIN, R_ATTN, R_FP8, R_VOC, R_PART = 1, 2, 4, 8, 16, 32     # gsv_oracle.c ORC_R_*
+R_KV, R_LIN, R_ATTN, R_FP8, R_VOC, R_PART, R_FINE = 1, 2, 4, 8, 16, 32, 64     # gsv_oracle.c ORC_R_*
 
 
 def round_bf16(a):
@@ -156,9 +156,10 @@ class T2SOracle:
     "bf16" / "fp8" = the same restatement with the product's production roundings applied at the same places
     (weights, K/V, GEMM operands -- module header of gsv_oracle.c), so that only the summation order separates
     it from the HIP kernels: the tight pin of the kernels the bench times.  `batched_min` mirrors the library's
-    switch to the batched decode step (gsv_t2s_batched_min)."""
+    switch to the batched decode step (gsv_t2s_batched_min), `ffn_slices` its FFN slice count per batch size
+    (gsv_t2s_ffn_slices: 64 at <= 4 sequences, else 32)."""
 
-    def __init__(self, config, weights, gpt_cache, numerics="fp32", batched_min=12):
+    def __init__(self, config, weights, gpt_cache, numerics="fp32", batched_min=12, ffn_slices=None):
         m = config["model"]
         self.D, self.H, self.NL = m["hidden_dim"], m["head"], m["n_layer"]
         self.V, self.EOS = m["vocab_size"], m["EOS"]
@@ -166,6 +167,7 @@ class T2SOracle:
         assert numerics in ("fp32", "bf16", "fp8")
         self.numerics = numerics
         self.batched_min = batched_min
+        self.ffn_slices = ffn_slices or (lambda bsz: 64 if bsz <= 4 else 32)
         w = {k: _f32(v) for k, v in weights.items()}
         self.w8 = None
         if numerics != "fp32":
@@ -272,6 +274,10 @@ class T2SOracle:
                     pack = self.pack8
             else:                                          # partial-sum kernels: head / slice partials cross the boundary as fp16
                 flags |= R_PART
+                n_sl = int(self.ffn_slices(bsz))
+                assert n_sl in (32, 64)
+                if n_sl == 64:
+                    flags |= R_FINE
         lib().orc_set_rounding(flags)
         try:
             lib().orc_t2s_decode(_fp(pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),

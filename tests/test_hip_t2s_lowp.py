@@ -150,7 +150,7 @@ def test_continuous_batching_40_requests_32_slots(dev, dtype, numerics):
     shapes = [(int(rng.integers(2, 10)), int(rng.integers(3, 24)), int(rng.integers(4, 40))) for _ in range(40)]
     rs = [synth.synth_request(300 + i, p, t, n, seed=41, bert="random") for i, (p, t, n) in enumerate(shapes)]
     m = _model(cfg, w, cache, dtype, dev)
-    o = orc.T2SOracle(cfg, w, cache, numerics=numerics, batched_min=m.batched_min)
+    o = orc.T2SOracle(cfg, w, cache, numerics=numerics, batched_min=m.batched_min, ffn_slices=m.ffn_slices)
     ref, ref_idx = o.infer_batched([r[0] for r in rs], [r[1] for r in rs], [r[2] for r in rs], top_k=1)
     pred, idx = m.infer_batched([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs], top_k=1)
     assert sorted(idx.tolist()) == list(range(40))
@@ -191,7 +191,7 @@ def test_batched_step_hidden_vs_oracle_bf16_and_fp8(dev, B, n_layer):
         m = _model(cfg, w, cache, dtype, dev)
         if B < m.batched_min:
             pytest.skip("batch below the batched-step threshold")
-        o = orc.T2SOracle(cfg, w, cache, numerics=numerics, batched_min=m.batched_min)
+        o = orc.T2SOracle(cfg, w, cache, numerics=numerics, batched_min=m.batched_min, ffn_slices=m.ffn_slices)
         xy, xl, yl, xlh, ylh = m.embed_prompt([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs])
         m.prefill(B, 0, xy, xl, yl)
         kv = (xlh + ylh).numpy()
@@ -231,7 +231,7 @@ def test_fp8_batched_tokens_match_rate(dev):
     cache = [(B, T)]
     rs = [synth.synth_request(900 + i, 6, 10 + i % 7, 20 + i % 11, seed=77) for i in range(B)]
     m = _model(cfg, w, cache, torch.float8_e4m3fn, dev)
-    o8 = orc.T2SOracle(cfg, w, cache, numerics="fp8", batched_min=m.batched_min)
+    o8 = orc.T2SOracle(cfg, w, cache, numerics="fp8", batched_min=m.batched_min, ffn_slices=m.ffn_slices)
     o32 = orc.T2SOracle(cfg, w, cache)
     pred, idx = m.infer_batched([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs], top_k=1)
     got = {int(i): t.cpu().numpy() for i, t in zip(idx.tolist(), pred)}
