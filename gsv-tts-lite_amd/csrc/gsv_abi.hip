@@ -108,6 +108,7 @@ struct Scope {
 #include "t2s_decode.h"
 #include "t2s_decode_multi.h"
 #include "t2s_batch.h"
+#include "t2s_small.h"
 
 namespace {
 thread_local std::string g_err;
@@ -132,6 +133,7 @@ struct T2SLayer {
     float *bqkv_p = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr,
           *ln2g = nullptr, *ln2b = nullptr;
     PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill / batched step (MFMA fragments)
+    void *p16_qkv = nullptr, *p16_out = nullptr, *p16_w1 = nullptr, *p16_w2 = nullptr;   // bf16 handles: 16 x 16 x 32 fragments of the batched step at <= kSmallMaxM rows (t2s_small.h)
     void *f8_qkv = nullptr, *f8_w1 = nullptr, *f8_w2 = nullptr;    // GSV_FP8: e4m3 fragments of the batched step (t2s_batch.h)
     float *s_qkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;      // ... and their per-output-channel scales
     unsigned have = 0;
@@ -198,6 +200,16 @@ int t2s_pack_fp8(const float* data, int cout, int cin, void** frag, float** scal
     return GSV_OK;
 }
 
+// bf16 handles: the 16 x 16 x 32 fragment order of t2s_small.h beside the 32 x 32 x 16 one
+template <typename WT>
+int t2s_pack16(void** dst, const float* data, int N, int K, hipStream_t st) {
+    if (sizeof(WT) != 2) return GSV_OK;
+    if (!*dst) HIPCHK(hipMalloc(dst, sizeof(bf16_t) * (size_t)N * K));
+    hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, st, data, (bf16_t*)*dst, N, K);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
 template <typename WT>
 int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float* data, int64_t numel, hipStream_t st) {
     T2SLayer& L = h->layers[l];
@@ -218,6 +230,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = pack_conv<WT>(L.g_qkv, data, 3 * kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         L.g_qkv.bias = keep;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, 3 * kD, kD, &L.f8_qkv, &L.s_qkv, st)) return rc;
+        if (int rc = t2s_pack16<WT>(&L.p16_qkv, data, 3 * kD, kD, st)) return rc;
         L.have |= 1u << 0;
     } else if (key == "qkv.bias") {
         if (int rc = want(3 * kD)) return rc;
@@ -232,6 +245,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(512), dim3(256), 0, st, data, (WT*)L.wo_p, kH, kDh);
         free_conv(L.g_out);
         if (int rc = pack_conv<WT>(L.g_out, data, kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
+        if (int rc = t2s_pack16<WT>(&L.p16_out, data, kD, kD, st)) return rc;
         L.have |= 1u << 2;
     } else if (key == "out_proj.bias") {
         if (int rc = copy_f32(&L.bo, kD, 1u << 3)) return rc;
@@ -242,6 +256,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         free_conv(L.g_w1);
         if (int rc = pack_conv<WT>(L.g_w1, data, kF, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, kF, kD, &L.f8_w1, &L.s_w1, st)) return rc;
+        if (int rc = t2s_pack16<WT>(&L.p16_w1, data, kF, kD, st)) return rc;
         L.have |= 1u << 4;
     } else if (key == "mlp.0.bias") {
         if (int rc = copy_f32(&L.b1, kF, 1u << 5)) return rc;
@@ -256,6 +271,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         free_conv(L.g_w2);
         if (int rc = pack_conv<WT>(L.g_w2, data, kD, kF, 1, kF, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, kD, kF, &L.f8_w2, &L.s_w2, st)) return rc;
+        if (int rc = t2s_pack16<WT>(&L.p16_w2, data, kD, kF, st)) return rc;
         L.have |= 1u << 6;
     } else if (key == "mlp.2.bias") {
         if (int rc = copy_f32(&L.b2, kD, 1u << 7)) return rc;
@@ -440,14 +456,16 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 }
 
 // batched step (bf16, B >= kBatchedMin): the prompt GEMM chain on B rows + one attention block per (head, sequence)
-// From this many sequences on, the bf16 / fp8 step is the batched chain (t2s_batch.h: weights streamed once per step,
-// five launches per layer) instead of the two-launches-per-layer kernels (t2s_decode.h up to 16 sequences,
-// t2s_decode_multi.h with 2 / 4 sequences per block up to 32).  Measured step time, bf16, kv 200-300 (ms):
-//   sequences         8      16     24     32     40     64     256
-//   2 launches/layer  0.38   0.45   0.65   0.66   1.13   --     --
-//   batched chain     --     0.67   0.75   0.83   0.85   0.89   1.51
+// From this many sequences on, the bf16 / fp8 step is the batched chain (weights streamed once per step, five launches per
+// layer: t2s_small.h's 16 x 16 tiles up to 64 rows, t2s_batch.h's 32 x 32 tiles above and for fp8) instead of the
+// two-launches-per-layer kernels of t2s_decode.h.  Measured step time, bf16, kv 150-250 (ms; profiles/r03_chain_small.txt):
+//   sequences                     8      16     17     24     32     33     48     64     128    256
+//   2 launches/layer              0.36   0.41   0.59   0.62   0.64   --     --     --     --     --      (17-32: 2 / 4 sequences per block)
+//   chain, 32 x 32 tiles (r02)    --     --     0.82   0.83   0.85   0.85   0.87   0.91   1.09   1.55
+//   chain, 16 x 16 tiles          --     --     0.54   0.57   0.59   0.61   0.62   0.65   --     --
 // GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
-constexpr int kBatchedMinDefault = 33;
+constexpr int kBatchedMinDefault = 17;
+constexpr int kBatchedMinFp8 = 33;        // fp8 handles keep the 32 x 32 chain (its e4m3 fragments): it pays from 33 sequences on
 constexpr size_t kPrefillLdsMax = 160 * 1024;
 
 // The 5-launches-per-layer chain of t2s_batch.h on M rows (decode: one row per sequence; prompt pass: nrows * l_max
@@ -475,8 +493,43 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
         ba.cpb = cpb;
         hipLaunchKernelGGL(kern, dim3(rtiles, cdiv(ba.mtiles, cpb)), dim3(nthreads), 0, st, ba);
     };
+    // few rows (the decode step at 17 .. kSmallMaxM sequences, bf16 operands): 16 x 16 tiles, one wave per channel tile (t2s_small.h)
+    static const bool no_small = getenv("GSV_NO_SMALL_CHAIN") != nullptr;   // A/B switch
+    const bool small = !prompt && !f8 && !no_small && M <= kSmallMaxM && h->layers[0].p16_qkv != nullptr;
+    const int rt16 = cdiv(M, 16);
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
+        if (small) {
+            if (!(skip & 1)) {   // K1
+                SGemmArgs g{};
+                g.M = M; g.W = (const uint4*)L.p16_qkv; g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
+                if (l == 0) {
+                    g.X = x0;
+                    hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2>), dim3(rt16, 3 * kD / 32), dim3(128), 0, st, g);
+                } else {
+                    g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
+                    hipLaunchKernelGGL((sgemm_kernel<PRO_LN, float, 2>), dim3(rt16, 3 * kD / 32), dim3(128), 0, st, g);
+                }
+            }
+            if (!(skip & 2)) attn_launch(l);
+            if (!(skip & 4)) {   // K3
+                SGemmArgs g{};
+                g.M = M; g.X = c.attn; g.W = (const uint4*)L.p16_out; g.bias = L.bo; g.res = x0; g.Y = c.y1; g.ldy = kD;
+                hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2>), dim3(rt16, kD / 32), dim3(128), 0, st, g);
+            }
+            if (!(skip & 8)) {   // K4
+                SGemmArgs g{};
+                g.M = M; g.X = c.y1; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = c.x1; g.W = (const uint4*)L.p16_w1; g.bias = L.b1; g.relu = 1;
+                g.Y = c.hid; g.ldy = kF;
+                hipLaunchKernelGGL((sgemm_kernel<PRO_LN, bf16_t, 2>), dim3(rt16, kF / 32), dim3(128), 0, st, g);
+            }
+            if (!(skip & 16)) {  // K5
+                SGemmArgs g{};
+                g.M = M; g.X = c.hid; g.W = (const uint4*)L.p16_w2; g.bias = L.b2; g.res = c.x1; g.Y = c.y2; g.ldy = kD;
+                hipLaunchKernelGGL(sgemm_k_kernel, dim3(rt16, kD / 16), dim3(256), 0, st, g);
+            }
+            continue;
+        }
         if (!(skip & 1)) {   // K1: [LayerNorm2 of layer l-1] -> QKV
             BGemmArgs g{};
             g.M = M; g.ldx = kD; g.W = (const uint4*)(f8 ? L.f8_qkv : L.g_qkv.w); g.wscale = L.s_qkv; g.mtiles = 3 * kD / 32; g.cout = 3 * kD;
@@ -534,9 +587,16 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
         BatchAttnArgs<WT> ba;
         ba.qkv = c.qkv; ba.kc = (WT*)s.k_cache + (size_t)l * layer_elems; ba.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
         ba.kv_len = s.kv_len; ba.T = T; ba.out = c.attn;
-        if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn_kernel<4, false>), dim3(kH, B), dim3(256), 0, st, ba);
-        else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn_kernel<8, false>), dim3(kH, B), dim3(256), 0, st, ba);
-        else hipLaunchKernelGGL((t2s_batch_attn_kernel<16, false>), dim3(kH, B), dim3(256), 0, st, ba);
+        static const bool old_attn = getenv("GSV_OLD_BATTN") != nullptr;   // A/B switch: the first form (t2s_batch.h)
+        static const int dup = getenv("GSV_BATTN_DUP") ? atoi(getenv("GSV_BATTN_DUP")) : 0;   // timing aid: launch it 1 + dup times (the repeats read warm K/V)
+        for (int rep = 0; rep <= dup; ++rep)
+        if (old_attn) {
+            if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn_kernel<4, false>), dim3(kH, B), dim3(256), 0, st, ba);
+            else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn_kernel<8, false>), dim3(kH, B), dim3(256), 0, st, ba);
+            else hipLaunchKernelGGL((t2s_batch_attn_kernel<16, false>), dim3(kH, B), dim3(256), 0, st, ba);
+        } else if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn2_kernel<4>), dim3(kH, B), dim3(256), 0, st, ba);
+        else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn2_kernel<8>), dim3(kH, B), dim3(256), 0, st, ba);
+        else hipLaunchKernelGGL((t2s_batch_attn2_kernel<16>), dim3(kH, B), dim3(256), 0, st, ba);
     };
     // x0 = xcur: the token kernel rewrites it at the start of every step, so the chain may use it as its residual buffer
     if (int rc = t2s_gemm_chain(h, B, h->xcur, c, h->fp8, attn, st)) return rc;
@@ -726,7 +786,7 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
     gsv_t2s* h = new gsv_t2s();
     h->cfg = *cfg;
     if (cfg->dtype == GSV_FP8) { h->fp8 = true; h->cfg.dtype = GSV_BF16; }   // bf16 everywhere but the batched step's QKV / FFN
-    h->batched_min = kBatchedMinDefault;
+    h->batched_min = h->fp8 ? kBatchedMinFp8 : kBatchedMinDefault;
     if (const char* e = getenv("GSV_BATCHED_MIN")) h->batched_min = std::max(1, atoi(e));
     if (const char* e = getenv("GSV_BSTEP_SKIP")) h->dbg_skip = (unsigned)atoi(e);
     if (getenv("GSV_NO_ARENA")) h->use_arena = false;
@@ -748,7 +808,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
         t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
-        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
+        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, L.p16_qkv, L.p16_out, L.p16_w1, L.p16_w2, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
                         (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b, L.f8_qkv, L.f8_w1, L.f8_w2,
                         (void*)L.s_qkv, (void*)L.s_w1, (void*)L.s_w2})
             if (p) (void)hipFree(p);
