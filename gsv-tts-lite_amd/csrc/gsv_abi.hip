@@ -133,6 +133,7 @@ struct T2SLayer {
     float *bqkv_p = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr, *ln1g = nullptr, *ln1b = nullptr,
           *ln2g = nullptr, *ln2b = nullptr;
     PackedConv g_qkv, g_out, g_w1, g_w2;  // prefill / batched step (MFMA fragments)
+    void *p8_qkv = nullptr, *p8_w1 = nullptr, *p8_w2 = nullptr;   // GSV_FP8: the e4m3 form of the same (scales: s_qkv / s_w1 / s_w2)
     void *p16_qkv = nullptr, *p16_out = nullptr, *p16_w1 = nullptr, *p16_w2 = nullptr;   // bf16 handles: 16 x 16 x 32 fragments of the batched step at <= kSmallMaxM rows (t2s_small.h)
     void *f8_qkv = nullptr, *f8_w1 = nullptr, *f8_w2 = nullptr;    // GSV_FP8: e4m3 fragments of the batched step (t2s_batch.h)
     float *s_qkv = nullptr, *s_w1 = nullptr, *s_w2 = nullptr;      // ... and their per-output-channel scales
@@ -200,6 +201,14 @@ int t2s_pack_fp8(const float* data, int cout, int cin, void** frag, float** scal
     return GSV_OK;
 }
 
+// GSV_FP8 handles: the paired 16 x 16 x 32 e4m3 fragments of t2s_small.h (scales from t2s_pack_fp8, which runs first)
+int t2s_pack16_f8(void** dst, const float* data, const float* scale, int N, int K, hipStream_t st) {
+    if (!*dst) HIPCHK(hipMalloc(dst, (size_t)N * K));
+    hipLaunchKernelGGL(pack16_f8_kernel, dim3(1024), dim3(256), 0, st, data, scale, (uint32_t*)*dst, N, K);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
 // bf16 handles: the 16 x 16 x 32 fragment order of t2s_small.h beside the 32 x 32 x 16 one
 template <typename WT>
 int t2s_pack16(void** dst, const float* data, int N, int K, hipStream_t st) {
@@ -230,6 +239,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = pack_conv<WT>(L.g_qkv, data, 3 * kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         L.g_qkv.bias = keep;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, 3 * kD, kD, &L.f8_qkv, &L.s_qkv, st)) return rc;
+        if (h->fp8) if (int rc = t2s_pack16_f8(&L.p8_qkv, data, L.s_qkv, 3 * kD, kD, st)) return rc;
         if (int rc = t2s_pack16<WT>(&L.p16_qkv, data, 3 * kD, kD, st)) return rc;
         L.have |= 1u << 0;
     } else if (key == "qkv.bias") {
@@ -256,6 +266,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         free_conv(L.g_w1);
         if (int rc = pack_conv<WT>(L.g_w1, data, kF, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, kF, kD, &L.f8_w1, &L.s_w1, st)) return rc;
+        if (h->fp8) if (int rc = t2s_pack16_f8(&L.p8_w1, data, L.s_w1, kF, kD, st)) return rc;
         if (int rc = t2s_pack16<WT>(&L.p16_w1, data, kF, kD, st)) return rc;
         L.have |= 1u << 4;
     } else if (key == "mlp.0.bias") {
@@ -271,6 +282,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         free_conv(L.g_w2);
         if (int rc = pack_conv<WT>(L.g_w2, data, kD, kF, 1, kF, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
         if (h->fp8) if (int rc = t2s_pack_fp8(data, kD, kF, &L.f8_w2, &L.s_w2, st)) return rc;
+        if (h->fp8) if (int rc = t2s_pack16_f8(&L.p8_w2, data, L.s_w2, kD, kF, st)) return rc;
         if (int rc = t2s_pack16<WT>(&L.p16_w2, data, kD, kF, st)) return rc;
         L.have |= 1u << 6;
     } else if (key == "mlp.2.bias") {
@@ -465,7 +477,6 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 //   chain, 16 x 16 tiles          --     --     0.54   0.57   0.59   0.61   0.62   0.65   --     --
 // GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
 constexpr int kBatchedMinDefault = 17;
-constexpr int kBatchedMinFp8 = 33;        // fp8 handles keep the 32 x 32 chain (its e4m3 fragments): it pays from 33 sequences on
 constexpr size_t kPrefillLdsMax = 160 * 1024;
 
 // The 5-launches-per-layer chain of t2s_batch.h on M rows (decode: one row per sequence; prompt pass: nrows * l_max
@@ -495,38 +506,44 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     };
     // few rows (the decode step at 17 .. kSmallMaxM sequences, bf16 operands): 16 x 16 tiles, one wave per channel tile (t2s_small.h)
     static const bool no_small = getenv("GSV_NO_SMALL_CHAIN") != nullptr;   // A/B switch
-    const bool small = !prompt && !f8 && !no_small && M <= kSmallMaxM && h->layers[0].p16_qkv != nullptr;
+    static const int small_max = getenv("GSV_SMALL_MAX_M") ? atoi(getenv("GSV_SMALL_MAX_M")) : kSmallMaxM;   // tuning aid
+    const bool small = !prompt && !no_small && M <= small_max && h->layers[0].p16_qkv != nullptr && (!f8 || h->layers[0].p8_qkv != nullptr);
     const int rt16 = cdiv(M, 16);
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
         if (small) {
             if (!(skip & 1)) {   // K1
                 SGemmArgs g{};
-                g.M = M; g.W = (const uint4*)L.p16_qkv; g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
+                g.M = M; g.W = (const uint4*)(f8 ? L.p8_qkv : L.p16_qkv); g.wscale = L.s_qkv; g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
+                const dim3 grid(rt16, 3 * kD / 32);
                 if (l == 0) {
                     g.X = x0;
-                    hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2>), dim3(rt16, 3 * kD / 32), dim3(128), 0, st, g);
+                    if (f8) hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2, true>), grid, dim3(128), 0, st, g);
+                    else hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2>), grid, dim3(128), 0, st, g);
                 } else {
                     g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
-                    hipLaunchKernelGGL((sgemm_kernel<PRO_LN, float, 2>), dim3(rt16, 3 * kD / 32), dim3(128), 0, st, g);
+                    if (f8) hipLaunchKernelGGL((sgemm_kernel<PRO_LN, float, 2, true>), grid, dim3(128), 0, st, g);
+                    else hipLaunchKernelGGL((sgemm_kernel<PRO_LN, float, 2>), grid, dim3(128), 0, st, g);
                 }
             }
             if (!(skip & 2)) attn_launch(l);
-            if (!(skip & 4)) {   // K3
+            if (!(skip & 4)) {   // K3 (bf16 on fp8 handles too)
                 SGemmArgs g{};
                 g.M = M; g.X = c.attn; g.W = (const uint4*)L.p16_out; g.bias = L.bo; g.res = x0; g.Y = c.y1; g.ldy = kD;
                 hipLaunchKernelGGL((sgemm_kernel<PRO_NONE, float, 2>), dim3(rt16, kD / 32), dim3(128), 0, st, g);
             }
             if (!(skip & 8)) {   // K4
                 SGemmArgs g{};
-                g.M = M; g.X = c.y1; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = c.x1; g.W = (const uint4*)L.p16_w1; g.bias = L.b1; g.relu = 1;
-                g.Y = c.hid; g.ldy = kF;
-                hipLaunchKernelGGL((sgemm_kernel<PRO_LN, bf16_t, 2>), dim3(rt16, kF / 32), dim3(128), 0, st, g);
+                g.M = M; g.X = c.y1; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = c.x1; g.W = (const uint4*)(f8 ? L.p8_w1 : L.p16_w1); g.wscale = L.s_w1;
+                g.bias = L.b1; g.relu = 1; g.Y = c.hid; g.ldy = kF;
+                if (f8) hipLaunchKernelGGL((sgemm_kernel<PRO_LN, fp8_t, 2, true>), dim3(rt16, kF / 32), dim3(128), 0, st, g);
+                else hipLaunchKernelGGL((sgemm_kernel<PRO_LN, bf16_t, 2>), dim3(rt16, kF / 32), dim3(128), 0, st, g);
             }
             if (!(skip & 16)) {  // K5
                 SGemmArgs g{};
-                g.M = M; g.X = c.hid; g.W = (const uint4*)L.p16_w2; g.bias = L.b2; g.res = c.x1; g.Y = c.y2; g.ldy = kD;
-                hipLaunchKernelGGL(sgemm_k_kernel, dim3(rt16, kD / 16), dim3(256), 0, st, g);
+                g.M = M; g.X = c.hid; g.W = (const uint4*)(f8 ? L.p8_w2 : L.p16_w2); g.wscale = L.s_w2; g.bias = L.b2; g.res = c.x1; g.Y = c.y2; g.ldy = kD;
+                if (f8) hipLaunchKernelGGL(sgemm_k_kernel<true>, dim3(rt16, kD / 16), dim3(256), 0, st, g);
+                else hipLaunchKernelGGL(sgemm_k_kernel<false>, dim3(rt16, kD / 16), dim3(256), 0, st, g);
             }
             continue;
         }
@@ -786,7 +803,7 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
     gsv_t2s* h = new gsv_t2s();
     h->cfg = *cfg;
     if (cfg->dtype == GSV_FP8) { h->fp8 = true; h->cfg.dtype = GSV_BF16; }   // bf16 everywhere but the batched step's QKV / FFN
-    h->batched_min = h->fp8 ? kBatchedMinFp8 : kBatchedMinDefault;
+    h->batched_min = kBatchedMinDefault;
     if (const char* e = getenv("GSV_BATCHED_MIN")) h->batched_min = std::max(1, atoi(e));
     if (const char* e = getenv("GSV_BSTEP_SKIP")) h->dbg_skip = (unsigned)atoi(e);
     if (getenv("GSV_NO_ARENA")) h->use_arena = false;
@@ -808,7 +825,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
         t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
-        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, L.p16_qkv, L.p16_out, L.p16_w1, L.p16_w2, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
+        for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, L.p16_qkv, L.p16_out, L.p16_w1, L.p16_w2, L.p8_qkv, L.p8_w1, L.p8_w2, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
                         (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b, L.f8_qkv, L.f8_w1, L.f8_w2,
                         (void*)L.s_qkv, (void*)L.s_w1, (void*)L.s_w2})
             if (p) (void)hipFree(p);
