@@ -333,6 +333,7 @@ struct BatchAttnArgs {
     const int64_t* kv_len;   // [B]
     int T;
     float* out;              // [B][512]
+    unsigned long long* dbg; // bring-up aid (gsv_t2s_set_debug): block (0, 0) stamps its phases into slots 0-6
 };
 
 template <int NIT, bool BLIND>   // iterations of 64 rows: T <= 64 * NIT; BLIND: load every chunk, mask after (else: kv_len first)

@@ -301,6 +301,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
 #pragma unroll
     for (int it = 2; it < NCH; ++it) vr[it] = ldg16(Vp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
     asm volatile("" : "+v"(rq) : : "memory");
+    stamp(a.dbg, 2);
     if (tid < 32) {
         uint16_t vh, vl;
         split_bf16(rq, vh, vl);
@@ -311,6 +312,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
         Kp[(size_t)nw * kDh + tid] = kq; Vp[(size_t)nw * kDh + tid] = vq;
     }
     __syncthreads();
+    stamp(a.dbg, 3);
     const XPair qp = xpair_load(qh, ql, part * 8);
     const float scale = 0.17677669529663687f * 1.4426950408889634f;   // 1/sqrt(32) x log2 e
     float sc[NCH + 1];
@@ -330,6 +332,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
         mx = fmaxf(mx, sc[NCH]);
     }
     mx = wave_max(mx);
+    stamp(a.dbg, 4);
     const float mref = mx == -INFINITY ? 0.f : mx;               // a wave without live rows
     float l = 0.f, acc[8];
 #pragma unroll
@@ -364,6 +367,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
     r1 += lane_xor<4>(r1);
     if ((lane & 4) == 0) pacc[wid][part * 8 + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)] = r1;
     if (lane == 0) { pm[wid] = mx; pl[wid] = l; }
+    stamp(a.dbg, 5);
     __syncthreads();
     if (tid < 32) {
         const float M = fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]));
@@ -376,6 +380,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
         }
         a.out[(size_t)b * kD + h * 32 + tid] = num / den;
     }
+    stamp(a.dbg, 6);
 }
 
 template <int NIT>
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16
     const float* row = a.qkv + (size_t)b * 1536 + h * 32;
     const bf16_t* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
     const bf16_t* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
+    stamp(a.dbg, 0);
     // kv_len FIRST: the in-order load counter then lets the chunk count wait for it alone
     const int64_t n64 = a.kv_len[b];
     float rq = 0.f, rk = 0.f, rv = 0.f;
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16
     // lanes hit one line or sixteen (0.27 us per dead 64-position chunk per launch at 64 sequences), and loading only the live
     // chunks behind per-chunk branches made hipcc drain the load counter in every branch (0.654 -> 0.729 ms per step).
     const int nch = __builtin_amdgcn_readfirstlane((n + 63) >> 6);
+    stamp(a.dbg, 1);
 #define GSV_BATTN_REST(N) battn2_rest<N>(a, h, b, n, n64, kb, vb, rq, rk, rv, qh, ql, knb, vn, pacc, pm, pl)
     if (nch <= 2) GSV_BATTN_REST(2);
     else if (nch <= 3) GSV_BATTN_REST(3);
