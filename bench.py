@@ -741,7 +741,7 @@ def run_cb(a):
         gbs = by / acc["t_ar"] / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                            "traffic": None,
-                           "kernel": ("batched decode step (5 launches per layer, csrc/t2s_batch.h)" if a.slots >= t2s.batched_min else
+                           "kernel": ("batched decode step (5 launches per layer: GEMMs on 16 x 16 x 32 MFMA tiles + attention per (head, sequence), csrc/t2s_small.h)" if a.slots >= t2s.batched_min else
                                       "decode step, 2 launches per layer with 2 / 4 sequences per block (csrc/t2s_decode_multi.h)" if a.slots > 16
                                       else "decode step, 2 launches per layer (csrc/t2s_decode.h)"),
                            "ms_per_step_of_the_slot_loop": acc["t_ar"] / max(1, acc["steps"]) * 1e3,

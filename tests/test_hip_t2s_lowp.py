@@ -171,7 +171,9 @@ def test_continuous_batching_40_requests_32_slots(dev, dtype, numerics):
     assert exact >= 30, exact
 
 
-@pytest.mark.parametrize("B,n_layer", [(40, 1), (64, 1), (64, 24)])
+# 17: the first batch size on the chain (one row in its second row tile); 40: a half-empty tile; 64 / 100 / 256: four channel tiles
+# per block (csrc/t2s_small.h), a ragged last tile, the largest batch
+@pytest.mark.parametrize("B,n_layer", [(17, 1), (40, 1), (64, 1), (100, 1), (256, 1), (64, 24)])
 def test_batched_step_hidden_vs_oracle_bf16_and_fp8(dev, B, n_layer):
     """one decode step of the batched chain (5 launches per layer) on B sequences with ragged cache lengths: final
     hidden states against the oracle in the matching numerics mode.  ONE layer is the arithmetic check (fragment
@@ -253,3 +255,49 @@ def test_fp8_batched_tokens_match_rate(dev):
           % (same8 / tot, same32 / tot))
     assert same8 / tot > 0.25     # every divergence above was at a margin below FP8_MARGIN; this only guards against garbage
     assert same32 / tot > 0.15
+
+
+def test_ffn_slice_count_is_reported_and_part_of_the_arithmetic(dev):
+    """gsv_t2s_ffn_slices: 64 slices of 32 hidden units on bf16 handles at <= 4 sequences, 32 of 64 otherwise and on fp32
+    handles.  The slice partials are rounded to half, so the count is part of the bf16 arithmetic: one decode step of 4 and of 5
+    sequences (either side of the switch) against the bf16-mode oracle summing the SAME slices, and against the other count --
+    which must be further away than the matching one on at least one of the two (the check would be vacuous otherwise)."""
+    from oracle import oracle as orc
+    cfg = synth.gpt_config(n_layer=2)
+    w = synth.gpt_weights(cfg, seed=5)
+    m32 = _model(cfg, w, [(1, 64)], torch.float32, dev)
+    assert [m32.ffn_slices(b) for b in (1, 4, 5, 16)] == [32, 32, 32, 32]
+    del m32
+    dist = {}
+    for B in (4, 5):
+        cache = [(B, 64)]
+        m = _model(cfg, w, cache, torch.bfloat16, dev)
+        assert m.ffn_slices(B) == (64 if B <= 4 else 32) and m.ffn_slices(1) == 64 and m.ffn_slices(16) == 32
+        rng = np.random.default_rng(B)
+        rs = [synth.synth_request(700 + i, 4, 6 + i, 8 + i, seed=5, bert="random") for i in range(B)]
+        xin = rng.normal(size=(B, 512)).astype(np.float32)
+        xy, xl, yl, xlh, ylh = m.embed_prompt([_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs])
+        m.prefill(B, 0, xy, xl, yl)
+        kv = (xlh + ylh).numpy()
+        got = None
+        for name, fn in (("same", m.ffn_slices), ("other", lambda b: 96 - m.ffn_slices(b))):
+            o = orc.T2SOracle(cfg, w, cache, numerics="bf16", batched_min=m.batched_min, ffn_slices=fn)
+            Lm = int(kv.max())
+            xyo = np.zeros((B, Lm, 512), np.float32)
+            mask = np.zeros((B, Lm, Lm), np.uint8)
+            for b, r in enumerate(rs):
+                lx, ly = len(r[0]), len(r[1])
+                xyo[b, :lx] = o.embed_text(r[0], r[2]); xyo[b, lx:lx + ly] = o.embed_audio(r[1])
+                mask[b, :lx + ly, :lx + ly] = o.single_mask(lx, ly)
+            o.prefill(xyo, mask, B, 0)
+            if got is None:
+                rt = m._rt[B]
+                with torch.inference_mode():
+                    for t, oc in ((rt["k"], o.cache[B][0]), (rt["v"], o.cache[B][1])):
+                        t.copy_(torch.from_numpy(oc).to(dev).to(t.dtype))
+                got = m.decode_hidden(B, _T(xin, dev)).cpu().numpy()
+            dist[(B, name)] = float(np.abs(got - o.decode(xin, B, kv)).mean())
+        assert dist[(B, "same")] < 2e-4, dist
+        del m
+    print("mean |hidden - bf16 oracle| with the library's slice count / with the other one:", dist)
+    assert any(dist[(B, "other")] > 1.2 * dist[(B, "same")] for B in (4, 5)), dist
