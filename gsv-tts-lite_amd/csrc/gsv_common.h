@@ -16,12 +16,10 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding torch uses for float -> bfloat16)
+// round-to-nearest-even (the rounding torch uses for float -> bfloat16), in hardware: v_cvt_pk_bf16_f32 on gfx950 (a NaN
+// comes out quiet); the bit-twiddled form cost a compare + branch per value in the decode kernels' serial phases
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 // two floats -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32, gfx950)
@@ -84,11 +82,14 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f32<0x140>(v);
     return v;
 }
+// max of two non-NaN values as ONE instruction: fmaxf quiets a signalling NaN first (a v_max x, x per operand), v_med3 with
+// +inf as the third operand does not
+__device__ __forceinline__ float max_nn(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, __builtin_inff()); }
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f32<0xB1>(v));
-    v = fmaxf(v, dpp_f32<0x4E>(v));
-    v = fmaxf(v, dpp_f32<0x141>(v));
-    v = fmaxf(v, dpp_f32<0x140>(v));
+    v = max_nn(v, dpp_f32<0xB1>(v));
+    v = max_nn(v, dpp_f32<0x4E>(v));
+    v = max_nn(v, dpp_f32<0x141>(v));
+    v = max_nn(v, dpp_f32<0x140>(v));
     return v;
 }
 // sums over aligned groups of 4 / 8 lanes, result in every lane of the group
@@ -115,7 +116,7 @@ __device__ __forceinline__ float wave_max(float v) {
     const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
     const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
     const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+    return max_nn(max_nn(a, b), max_nn(c, d));
 }
 
 // ---- cross-lane exchanges without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32: an LDS instruction

@@ -215,19 +215,27 @@ template <> __device__ __forceinline__ int sumN_index<4>() {
 // squares) = ONE barrier; var = E[x^2] - mean^2 in fp32 is within ~1e-6 of torch's two-pass form
 // for these O(1) activations (tests hold it to 2e-5 against the reference's outputs).
 // `red` must hold 2*kNW floats and not be in use by another reduction.
+// FAST (bf16 handles): 1/sqrt on v_rsq_f32 (1 ulp) instead of the correctly rounded sqrt + IEEE division (35 dependent
+// instructions in the serial chain of every decode kernel), and only the eight owner waves reduce and are summed -- the other
+// eight just meet the barrier.  fp32 handles keep the exact form (the parity mode).
+template <bool FAST = false>
 __device__ __forceinline__ float ln512(float v, bool owner, float g, float bta, float* red) {
-    float s = owner ? v : 0.f, q = s * s;
-    s = wave_sum(s);
-    q = wave_sum(q);
+    constexpr int NOW = kD / 64;            // owner waves
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[2 * w] = s; red[2 * w + 1] = q; }
+    if (!FAST || w < NOW) {
+        float s = owner ? v : 0.f, q = s * s;
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if ((threadIdx.x & 63) == 0) { red[2 * w] = s; red[2 * w + 1] = q; }
+    }
     __syncthreads();
+    if (FAST && w >= NOW) return 0.f;
     float ts = 0.f, tq = 0.f;
 #pragma unroll
-    for (int i = 0; i < kNW; ++i) { ts += red[2 * i]; tq += red[2 * i + 1]; }
+    for (int i = 0; i < (FAST ? NOW : kNW); ++i) { ts += red[2 * i]; tq += red[2 * i + 1]; }
     const float mean = ts * (1.0f / kD);
     const float var = fmaxf(tq * (1.0f / kD) - mean * mean, 0.f);
-    const float rs = 1.0f / sqrtf(var + kEps);
+    const float rs = FAST ? __builtin_amdgcn_rsqf(var + kEps) : 1.0f / sqrtf(var + kEps);
     return (v - mean) * rs * g + bta;
 }
 
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     } else {
         ps.park(stage);
         __syncthreads();
-        v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+        v = ln512<BF>(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     }
     if (owner) {
         if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
             }
             s = group_sum<LPR>(s);
             sv[it] = r < n ? s * scale : -INFINITY;
-            cmax = fmaxf(cmax, sv[it]);
+            cmax = max_nn(cmax, sv[it]);
         }
         {   // the new token's own key/value (position n) rides with wave 0's first chunk
             float s = 0.f;
@@ -640,10 +648,10 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
             }
             s = group_sum<LPR>(s);
             sv[KCH] = (c0 == 0 && tid < LPR) ? s * scale : -INFINITY;
-            cmax = fmaxf(cmax, sv[KCH]);
+            cmax = max_nn(cmax, sv[KCH]);
         }
         cmax = wave_max(cmax);
-        const float m_new = fmaxf(m_run, cmax);
+        const float m_new = max_nn(m_run, cmax);
         const float mref = (m_new == -INFINITY) ? 0.f : m_new;
         const float f = sm_exp<BF>(m_run - mref);      // exp(-inf) = 0 on the first live chunk
         l_run *= f;
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], sm_exp<BF>(pm[hf * 8 + w] - M), num);
         num = xor32_sum(num);
         if (lane < 32) {
-            if constexpr (BF) { uint16_t vh, vl; split_bf16(num / den, vh, vl); atth[d] = vh; attl[d] = vl; }
+            if constexpr (BF) { uint16_t vh, vl; split_bf16(num * __builtin_amdgcn_rcpf(den), vh, vl); atth[d] = vh; attl[d] = vl; }
             else att[d] = num / den;
         }
     }
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     stamp(a.dbg, 13);
     __syncthreads();
     stamp(a.dbg, 14);
-    const float v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+    const float v = ln512<BF>(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     stamp(a.dbg, 15);
     if (owner) {
         if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
@@ -882,7 +890,7 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     } else {
         ps.park(stage);
         __syncthreads();
-        v = ln512(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
+        v = ln512<sizeof(WT) == 2>(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     }
     if (owner) {
         xs[tid] = v;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NWV * 64) void sgemm_kernel(SGemmArgs a) {
             const float rq_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tq), sumN_lane<RPW>(r)));
             const float mean = rs_ * (1.0f / K);
             const float var = fmaxf(rq_ * (1.0f / K) - mean * mean, 0.f);   // E[x^2] - mean^2 as the decode kernels (ln512)
-            const float rstd = 1.0f / sqrtf(var + kEps);
+            const float rstd = __builtin_amdgcn_rsqf(var + kEps);            // v_rsq_f32 (1 ulp): these kernels serve the bf16 / e4m3 modes only
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -378,7 +378,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
             num = fmaf(pacc[w][tid], f, num);
             den = fmaf(pl[w], f, den);
         }
-        a.out[(size_t)b * kD + h * 32 + tid] = num / den;
+        a.out[(size_t)b * kD + h * 32 + tid] = num * __builtin_amdgcn_rcpf(den);
     }
     stamp(a.dbg, 6);
 }

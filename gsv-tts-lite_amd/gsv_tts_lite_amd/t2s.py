@@ -400,6 +400,7 @@ class Text2SemanticDecoder:
                 self._eos_pipe = [torch.cuda.Event() for _ in range(2)]
             mirror = rt["eos_host"]
             pending = None
+            pending_done = 0
             k = 0
             while done < n_iter:
                 n = min(check_interval, n_iter - done)
@@ -416,9 +417,14 @@ class Text2SemanticDecoder:
                             pass
                     else:
                         pending.synchronize()
-                    if int(mirror[0]) >= 0:
+                    # the mirror may already hold an EOS of the window enqueued AFTER the one just waited for (the GPU runs
+                    # ahead of this read): only an EOS recorded by a step of the waited-for windows counts, so the number of
+                    # windows a run executes -- and with it the state it leaves behind -- does not depend on timing
+                    e = int(mirror[0])
+                    if 0 <= e < pending_done:
                         break
                 pending = ev
+                pending_done = done
             torch.cuda.current_stream(self.device).synchronize()
             eos_at = int(mirror[0])
         else:
