@@ -507,6 +507,9 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     // few rows (the decode step at 17 .. kSmallMaxM sequences, bf16 operands): 16 x 16 tiles, one wave per channel tile (t2s_small.h)
     static const bool no_small = getenv("GSV_NO_SMALL_CHAIN") != nullptr;   // A/B switch
     static const int small_max = getenv("GSV_SMALL_MAX_M") ? atoi(getenv("GSV_SMALL_MAX_M")) : kSmallMaxM;   // tuning aid
+    // NOT for a prompt pass, however few its rows (one 200-row prompt: TTFT 1.22 -> 0.98 ms on these kernels): the two tile shapes
+    // sum k in different orders, and a request's K/V rows must not depend on how many prompts were packed into its pass
+    // (tests/test_hip_t2s.py::test_prefill_into_scattered_slots_equals_one_by_one; the engine's ranks pack different sets)
     const bool small = !prompt && !no_small && M <= small_max && h->layers[0].p16_qkv != nullptr && (!f8 || h->layers[0].p8_qkv != nullptr);
     const int rt16 = cdiv(M, 16);
     const bool nwv4 = M > 48;
