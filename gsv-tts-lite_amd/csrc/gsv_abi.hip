@@ -565,11 +565,11 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             if (l == 0) {
                 g.X = x0;
                 if (f8) run(bgemm_kernel<PRO_NONE, float, float, 4, true>, 256, g);
-                else run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
+                else run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
             } else {
                 g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
                 if (f8) run(bgemm_kernel<PRO_LN, float, float, 4, true>, 256, g);
-                else run(bgemm_kernel<PRO_LN, float, float, 4, false>, 256, g);
+                else run(bgemm_kernel<PRO_LN, float, float, 4, false, true>, 256, g);
             }
         }
         if (!(skip & 2)) attn_launch(l);
@@ -577,7 +577,7 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             BGemmArgs g{};
             g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
             g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
-            run(bgemm_kernel<PRO_NONE, float, float, 4, false>, 256, g);
+            run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
         }
         if (!(skip & 8)) {   // K4: [LayerNorm1] -> W1 + bias + ReLU
             BGemmArgs g{};
@@ -585,7 +585,7 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             g.W = (const uint4*)(f8 ? L.f8_w1 : L.g_w1.w); g.wscale = L.s_w1; g.mtiles = kF / 32; g.cout = kF; g.bias = L.b1; g.relu = 1;
             g.Y = c.hid; g.ldy = kF;
             if (f8) run(bgemm_kernel<PRO_LN, float, fp8_t, 4, true>, 256, g);
-            else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false>, 256, g);
+            else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g);
         }
         if (!(skip & 16)) {   // K5: W2 over the full K + bias + residual -> pre-LN2
             BGemmArgs g{};

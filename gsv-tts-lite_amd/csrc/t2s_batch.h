@@ -71,9 +71,16 @@ template <bool F8> __device__ __forceinline__ int bg_chan(int wid, int g, int hf
     else return wid * 128 + g * 16 + hf * 8;
 }
 
-template <int PRO, typename XT, typename OT, int NW, bool F8>
+// STG (fp32 rows, 4 waves, bf16 operands): the block's 32 X rows are loaded COALESCED -- a wave reads eight whole rows, 1 KiB per
+// instruction -- their LayerNorm statistics are wave-local, and the normalised rows are staged once in LDS as bf16, from where every
+// lane takes its B fragments (ds_read_b128, rows 1040 bytes apart).  Without it a lane loads 16 bytes of its own row per
+// instruction (32-64 cache lines each on the texture-address path).  Same k order per output as the unstaged form.
+template <int PRO, typename XT, typename OT, int NW, bool F8, bool STG = false>
 __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
+    static_assert(!STG || (sizeof(XT) == 4 && NW == 4 && !F8), "staged form: fp32 rows, 4 waves, bf16 operands");
     constexpr int NRED = NW == 4 ? 3 * 16 * 64 : NW * 16 * 64;
+    constexpr int LDXS = kD + 8;                             // bf16 per staged row
+    __shared__ __attribute__((aligned(16))) bf16_t xstage[STG ? 32 * LDXS : 8];
     __shared__ __attribute__((aligned(16))) float red[NRED];
     __shared__ __attribute__((aligned(16))) float gsm[PRO == PRO_LN ? 2 * kD : 4];
     __shared__ float stat[PRO == PRO_LN ? NW * 32 * 2 : 2];
@@ -125,7 +132,67 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
     };
     load_w(mt);
     uint32_t xb[8][4];   // bf16: xb[g][0..3] = 8 bf16 of group g; fp8: xb[g][0..1] = 8 e4m3 of group g
-    if constexpr (sizeof(XT) == 4) {
+    if constexpr (STG) {
+        const float* X = reinterpret_cast<const float*>(a.X);
+        f32x4 xr[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int grow = min(rt * 32 + wid * 8 + r, a.M - 1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) xr[r][c] = *reinterpret_cast<const f32x4*>(X + (size_t)grow * a.ldx + c * 256 + lane * 4);
+        }
+        if constexpr (PRO == PRO_LN) {
+            f32x4 lg[2], lb[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                lg[c] = *reinterpret_cast<const f32x4*>(a.lng + c * 256 + lane * 4);
+                lb[c] = *reinterpret_cast<const f32x4*>(a.lnb + c * 256 + lane * 4);
+            }
+            float s8[8], q8[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                s8[r] = 0.f; q8[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { s8[r] += xr[r][c][i]; q8[r] = fmaf(xr[r][c][i], xr[r][c][i], q8[r]); }
+            }
+            const float ts = wave_sumN<8>(s8), tq = wave_sumN<8>(q8);       // lane 32 b2 + 16 b1 + 8 b0 holds row (b2 b1 b0)'s totals
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int src = ((r >> 2) & 1) * 32 + ((r >> 1) & 1) * 16 + (r & 1) * 8;
+                const float rs_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts), src));
+                const float rq_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tq), src));
+                const float mean = rs_ * (1.0f / kD);
+                const float var = fmaxf(rq_ * (1.0f / kD) - mean * mean, 0.f);
+                const float rstd = __builtin_amdgcn_rsqf(var + kEps);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xr[r][c][i] = (xr[r][c][i] - mean) * rstd * lg[c][i] + lb[c][i];
+                const int grow = rt * 32 + wid * 8 + r;
+                if (mt0 == 0 && a.xout != nullptr && grow < a.M) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(a.xout + (size_t)grow * kD + c * 256 + lane * 4) = xr[r][c];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                uint2 pk;
+                pk.x = pack_bf16x2(xr[r][c][0], xr[r][c][1]);
+                pk.y = pack_bf16x2(xr[r][c][2], xr[r][c][3]);
+                *reinterpret_cast<uint2*>(xstage + (wid * 8 + r) * LDXS + c * 256 + lane * 4) = pk;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(xstage + j * LDXS + bg_chan<false>(wid, g, hf));
+            xb[g][0] = t[0]; xb[g][1] = t[1]; xb[g][2] = t[2]; xb[g][3] = t[3];
+        }
+    } else if constexpr (sizeof(XT) == 4) {
         const float* xp = reinterpret_cast<const float*>(a.X) + (size_t)rowc * a.ldx;
         f32x4 lo[8], hi[8];
 #pragma unroll
