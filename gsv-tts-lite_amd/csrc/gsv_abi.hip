@@ -174,6 +174,7 @@ struct gsv_t2s {
     bool finalized = false;
     bool fp8 = false;              // GSV_FP8: e4m3 QKV / FFN weights in the batched step (everything else as GSV_BF16)
     int batched_min = 0;           // batch size from which the step is the batched chain
+    int nt_from_layer = 0x7fffffff; // fp32 handles: layers from this one on load their weights non-temporally (t2s_attn_kernel's NT note)
     unsigned dbg_skip = 0;         // GSV_BSTEP_SKIP (tuning aid): bit i drops launch K(i+1) of the batched chain -- timing only
     std::map<int, T2SBound> bound;
     // scratch sized for the largest bound batch
@@ -397,6 +398,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (ffn_slices<WT>(B) == kNJFine) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine>), dim3(kH, B), dim3(kNT), lds, st, a);
+    else if (sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJ, sizeof(WT) == 4>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
 }
 
@@ -412,7 +414,8 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     else if (ffn_slices<WT>(B) == kNJFine) {
         f.w2p = (const WT*)L.w2_p64;
         hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
-    } else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
+    } else if (sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJ, sizeof(WT) == 4>), dim3(kNJ, B), dim3(kNT), 0, st, f);
+    else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
 }
 
 // the R-sequences-per-block kernels use more than 64 KB of dynamic LDS
@@ -478,6 +481,7 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 // GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
 constexpr int kBatchedMinDefault = 17;
 constexpr size_t kPrefillLdsMax = 160 * 1024;
+constexpr int kNtFromLayerF32 = 10;    // fp32 handles: 10 layers (127 MB) + the K/V rows of a step stay in the Infinity Cache: 0.490 -> 0.440 ms per step (profiles/r03_f32_nontemporal_layers.txt)
 
 // The 5-launches-per-layer chain of t2s_batch.h on M rows (decode: one row per sequence; prompt pass: nrows * l_max
 // rows).  x0 [M][512] fp32 is the input of layer 0 and is overwritten with each layer's input (the residual of the
@@ -817,6 +821,8 @@ int gsv_t2s_create(const gsv_t2s_config* cfg, gsv_t2s** out) {
     h->batched_min = kBatchedMinDefault;
     if (const char* e = getenv("GSV_BATCHED_MIN")) h->batched_min = std::max(1, atoi(e));
     if (const char* e = getenv("GSV_BSTEP_SKIP")) h->dbg_skip = (unsigned)atoi(e);
+    if (h->cfg.dtype == GSV_F32) h->nt_from_layer = kNtFromLayerF32;
+    if (const char* e = getenv("GSV_NT_FROM_LAYER")) h->nt_from_layer = atoi(e);   // tuning aid
     if (getenv("GSV_NO_ARENA")) h->use_arena = false;
     h->layers.resize(cfg->n_layer);
     if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {

@@ -107,6 +107,10 @@ template <typename WT> struct Geo {
 };
 
 __device__ __forceinline__ raw16 ldg16(const void* p) { return *reinterpret_cast<const raw16*>(p); }
+// streamed once per step and NOT to be kept in the Infinity Cache (see the NT note at t2s_attn_kernel)
+template <bool NT> __device__ __forceinline__ raw16 ldg16w(const void* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const raw16*>(p)); else return ldg16(p);
+}
 // Weight loads keep the DEFAULT cache policy: measured on MI355X, the non-temporal hint (global_load ... nt)
 // made the bs=1 step 10 % slower (0.404 vs 0.370 ms/token) -- the 152 MB weight set lives in the 256 MiB
 // Infinity Cache between tokens and nt lines are not retained there.
@@ -126,11 +130,11 @@ __device__ __forceinline__ float row_dot(const raw16 (&w)[Geo<WT>::CPR], const f
     }
     return a;
 }
-template <typename WT>
+template <typename WT, bool NT = false>
 __device__ __forceinline__ void row_load(const WT* row, raw16 (&w)[Geo<WT>::CPR]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < Geo<WT>::CPR; ++c) w[c] = ldg16(row + c * (kD / Geo<WT>::CPR) + lane * Geo<WT>::EPL);
+    for (int c = 0; c < Geo<WT>::CPR; ++c) w[c] = ldg16w<NT>(row + c * (kD / Geo<WT>::CPR) + lane * Geo<WT>::EPL);
 }
 template <typename WT>
 __device__ __forceinline__ void lane_x(const float* xs, float (&xr)[8]) {
@@ -344,11 +348,12 @@ template <typename WT, int K> struct Panel {
     static constexpr int RPI = kNT / LPR;
     static constexpr int NIT = kD / RPI;
     raw16 w[NIT];
+    template <bool NT = false>
     __device__ __forceinline__ void issue(const WT* __restrict__ panel) {
         const int tid = threadIdx.x;
         const int part = tid % LPR, rsub = tid / LPR;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) w[it] = ldg16(panel + (size_t)(rsub + it * RPI) * K + part * EPL);
+        for (int it = 0; it < NIT; ++it) w[it] = ldg16w<NT>(panel + (size_t)(rsub + it * RPI) * K + part * EPL);
     }
     // bf16 handles: the K-vector as bf16 hi / lo arrays (xpair_load)
     template <typename OT>
@@ -460,7 +465,12 @@ struct AttnArgs {
 
 constexpr int kAttnLdsFloats = kD + 96 + 32 + 2 * kNW + kNW * 32 + 2 * kNW + kNW * kD;
 
-template <typename WT, int MODE, int NJ = kNJ>
+// NT: this layer's weights are loaded non-temporally (fp32 handles, the upper layers).  A step of an fp32 handle streams 304 MB of
+// weights + its K/V rows; the 256 MiB Infinity Cache holds a cyclic set of up to ~208 MB (profiles/r03_l2_prefetch_probe.txt), so
+// under the default policy EVERY load of every layer misses it (per layer 20.1 us at 24 layers against 15.6 at 8, which fit).
+// With the upper layers passing through without allocating, the lower ones stay resident.  bf16 handles fit as a whole: the
+// hint made their step 10 % slower (round 1) and is off.
+template <typename WT, int MODE, int NJ = kNJ, bool NT = false>
 __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     __shared__ __attribute__((aligned(16))) float smem[kAttnLdsFloats];
     float* xs = smem;             // 512
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     const WT* wp = a.wqkv + ((size_t)h * 96 + wid * RW) * kD;
     raw16 wq[RW][CPR];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) row_load<WT>(wp + (size_t)r * kD, wq[r]);
+    for (int r = 0; r < RW; ++r) row_load<WT, NT>(wp + (size_t)r * kD, wq[r]);
     // K/V rows are loaded UNCONDITIONALLY from a clamped (always valid) row and masked at use: a
     // per-element "load or zero" select makes hipcc branch around each load and drain vmcnt(0)
     raw16 kreg[KCH], vreg[KCH];
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
     for (int it = 0; it < KCH; ++it) vreg[it] = ldg16(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
     Panel<WT, kDh> po;
-    po.issue(a.wo + (size_t)h * kD * kDh);
+    po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
     const int oi = sumN_index<8>();
     const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
     // Pin "all loads issued, THEN arithmetic": the opaque asm redefines the head of the partial-sum
@@ -738,7 +748,7 @@ struct FfnArgs {
     unsigned long long* dbg;
 };
 
-template <typename WT, int NJ = kNJ>
+template <typename WT, int NJ = kNJ, bool NT = false>
 __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     constexpr int FJ = kF / NJ;    // hidden units of this slice
     __shared__ __attribute__((aligned(16))) float smem[kD + FJ + 2 * kNW + kNW * kD];
@@ -764,9 +774,9 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     const int row0 = j * FJ + wid * RW;
     raw16 w1r[RW][CPR];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) row_load<WT>(a.w1 + (size_t)(row0 + r) * kD, w1r[r]);
+    for (int r = 0; r < RW; ++r) row_load<WT, NT>(a.w1 + (size_t)(row0 + r) * kD, w1r[r]);
     Panel<WT, FJ> p2;
-    p2.issue(a.w2p + (size_t)j * kD * FJ);
+    p2.template issue<NT>(a.w2p + (size_t)j * kD * FJ);
     const int oi = sumN_index<RW>();
     const float b1r = a.b1[row0 + oi];
     asm volatile("" : "+v"(ps.p[0][0]) : : "memory");

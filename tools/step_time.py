@@ -6,7 +6,7 @@ from gsv_tts_lite_amd import synth
 from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
 B = int(sys.argv[1]); dev = torch.device("cuda:0")
 dt = {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn, "fp32": torch.float32}[sys.argv[2] if len(sys.argv) > 2 else "bf16"]
-cfg = synth.gpt_config()
+cfg = synth.gpt_config(n_layer=int(os.environ.get('GSV_NLAYER', '24')))
 m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1, eos_gain=-8.0))
 m.initialize_runtime(dt, dev, [(B, int(os.environ.get('GSV_T', '512')))])
 rs = [synth.synth_request(i, 40, 60, 100, seed=1) for i in range(B)]
