@@ -395,6 +395,17 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
         else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
         return;
     }
+    // K/V rows non-temporal from 5 sequences on: weights (152 MB) + a step's K/V rows (B x 49 KB x kv) then exceed what the Infinity
+    // Cache holds; measured at kv ~200 (profiles/r03_kv_nontemporal.txt): 0.283 -> 0.300 ms at 1 sequence (worse: everything fits),
+    // 0.354 -> 0.334 at 8, 0.411 -> 0.380 at 16.  GSV_SEQ_KV_NT_MIN_B moves the switch.
+    static const int kvnt_b = getenv("GSV_SEQ_KV_NT_MIN_B") ? atoi(getenv("GSV_SEQ_KV_NT_MIN_B")) : kFineMaxB + 1;
+    if (sizeof(WT) == 2 && B >= kvnt_b) {
+        if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2, kNJ, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
+        else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0, kNJ, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
+        else if (ffn_slices<WT>(B) == kNJFine) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
+        else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJ, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
+        return;
+    }
     if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (ffn_slices<WT>(B) == kNJFine) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine>), dim3(kH, B), dim3(kNT), lds, st, a);
@@ -516,6 +527,8 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     // (tests/test_hip_t2s.py::test_prefill_into_scattered_slots_equals_one_by_one; the engine's ranks pack different sets)
     const bool small = !prompt && !no_small && M <= small_max && h->layers[0].p16_qkv != nullptr && (!f8 || h->layers[0].p8_qkv != nullptr);
     const int rt16 = cdiv(M, 16);
+    // (the prompt pass's weight fragments non-temporal, so that they do not evict the decode step's copy: measured, no gain in the
+    // cb workload, TTFT 1.11 -> 1.37 ms: not adopted)
     const bool nwv4 = M > 48;
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
@@ -619,6 +632,9 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
         BatchAttnArgs<WT> ba;
         ba.qkv = c.qkv; ba.kc = (WT*)s.k_cache + (size_t)l * layer_elems; ba.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
         ba.kv_len = s.kv_len; ba.T = T; ba.out = c.attn; ba.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
+        // K/V rows non-temporal: measured better at every batch size the chain serves (0.567 -> 0.517 ms per step at 32 sequences,
+        // 0.645 -> 0.595 at 64, 1.235 -> 1.168 at 256: profiles/r03_chain_small.txt); GSV_KV_NT_MIN_B moves the switch
+        static const int kv_nt_min_b = getenv("GSV_KV_NT_MIN_B") ? atoi(getenv("GSV_KV_NT_MIN_B")) : 0;
         static const bool old_attn = getenv("GSV_OLD_BATTN") != nullptr;   // A/B switch: the first form (t2s_batch.h)
         static const int dup = getenv("GSV_BATTN_DUP") ? atoi(getenv("GSV_BATTN_DUP")) : 0;   // timing aid: launch it 1 + dup times (the repeats read warm K/V)
         for (int rep = 0; rep <= dup; ++rep)
@@ -626,6 +642,10 @@ int t2s_batched_layers(gsv_t2s* h, const gsv_t2s_state& s, hipStream_t st) {
             if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn_kernel<4, false>), dim3(kH, B), dim3(256), 0, st, ba);
             else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn_kernel<8, false>), dim3(kH, B), dim3(256), 0, st, ba);
             else hipLaunchKernelGGL((t2s_batch_attn_kernel<16, false>), dim3(kH, B), dim3(256), 0, st, ba);
+        } else if (B >= kv_nt_min_b) {
+            if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn2_kernel<4, true>), dim3(kH, B), dim3(256), 0, st, ba);
+            else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn2_kernel<8, true>), dim3(kH, B), dim3(256), 0, st, ba);
+            else hipLaunchKernelGGL((t2s_batch_attn2_kernel<16, true>), dim3(kH, B), dim3(256), 0, st, ba);
         } else if (T <= 256) hipLaunchKernelGGL((t2s_batch_attn2_kernel<4>), dim3(kH, B), dim3(256), 0, st, ba);
         else if (T <= 512) hipLaunchKernelGGL((t2s_batch_attn2_kernel<8>), dim3(kH, B), dim3(256), 0, st, ba);
         else hipLaunchKernelGGL((t2s_batch_attn2_kernel<16>), dim3(kH, B), dim3(256), 0, st, ba);

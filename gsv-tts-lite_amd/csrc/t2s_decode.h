@@ -470,7 +470,9 @@ constexpr int kAttnLdsFloats = kD + 96 + 32 + 2 * kNW + kNW * 32 + 2 * kNW + kNW
 // under the default policy EVERY load of every layer misses it (per layer 20.1 us at 24 layers against 15.6 at 8, which fit).
 // With the upper layers passing through without allocating, the lower ones stay resident.  bf16 handles fit as a whole: the
 // hint made their step 10 % slower (round 1) and is off.
-template <typename WT, int MODE, int NJ = kNJ, bool NT = false>
+// NTKV: the K/V rows non-temporal too -- from a few sequences on a step's K/V rows + weights exceed what the Infinity Cache holds
+// and the K/V stream (read once per step) evicts the weights every other launch wants back.
+template <typename WT, int MODE, int NJ = kNJ, bool NT = false, bool NTKV = false>
 __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     __shared__ __attribute__((aligned(16))) float smem[kAttnLdsFloats];
     float* xs = smem;             // 512
@@ -533,9 +535,9 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // per-element "load or zero" select makes hipcc branch around each load and drain vmcnt(0)
     raw16 kreg[KCH], vreg[KCH];
 #pragma unroll
-    for (int it = 0; it < KCH; ++it) kreg[it] = ldg16(Kp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
+    for (int it = 0; it < KCH; ++it) kreg[it] = ldg16w<NTKV>(Kp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
 #pragma unroll
-    for (int it = 0; it < KCH; ++it) vreg[it] = ldg16(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
+    for (int it = 0; it < KCH; ++it) vreg[it] = ldg16w<NTKV>(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
     Panel<WT, kDh> po;
     po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
     const int oi = sumN_index<8>();
@@ -626,8 +628,8 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         if (c0 > 0) {
 #pragma unroll
             for (int it = 0; it < KCH; ++it) {
-                kreg[it] = ldg16(Kp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
-                vreg[it] = ldg16(Vp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
+                kreg[it] = ldg16w<NTKV>(Kp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
+                vreg[it] = ldg16w<NTKV>(Vp + (size_t)min(c0 + rsub + it * RPI, n) * kDh + part * EPL);
             }
         }
         float sv[KCH + 1];

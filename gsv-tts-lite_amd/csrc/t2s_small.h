@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void sgemm_k_kernel(SGemmArgs a) {
 //   * a chunk with no live position costs no arithmetic (block-uniform branch), a live one half of it: scores on
 //     v_dot2c_f32_bf16 with q as a (hi, lo) bf16 pair (t2s_decode.h dot8), softmax in the base-2 domain on v_exp_f32.
 // everything behind kv_len for a block with at most NCH live chunks of 64 positions (chunks 0 and 1 arrive loaded)
-template <int NCH>
+template <int NCH, bool NTKV>
 __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int h, int b, int n, int64_t n64, const raw16 (&kb)[2], const raw16 (&vb)[2],
                                             float rq, float rk, float rv, uint16_t* qh, uint16_t* ql, uint16_t* knb, float* vn, float (*pacc)[32],
                                             float* pm, float* pl) {
@@ -297,9 +297,9 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
     kr[0] = kb[0]; vr[0] = vb[0];
     if constexpr (NCH > 1) { kr[1] = kb[1]; vr[1] = vb[1]; }
 #pragma unroll
-    for (int it = 2; it < NCH; ++it) kr[it] = ldg16(Kp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
+    for (int it = 2; it < NCH; ++it) kr[it] = ldg16w<NTKV>(Kp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
 #pragma unroll
-    for (int it = 2; it < NCH; ++it) vr[it] = ldg16(Vp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
+    for (int it = 2; it < NCH; ++it) vr[it] = ldg16w<NTKV>(Vp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
     asm volatile("" : "+v"(rq) : : "memory");
     stamp(a.dbg, 2);
     if (tid < 32) {
@@ -383,7 +383,9 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
     stamp(a.dbg, 6);
 }
 
-template <int NIT>
+// NTKV: the K/V rows are loaded non-temporally (they are read once per step and, from a few dozen sequences on, are larger than
+// the Infinity Cache: without the hint they evict the step's weights, which every GEMM launch then fetches from HBM)
+template <int NIT, bool NTKV = false>
 __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16_t> a) {
     __shared__ __attribute__((aligned(16))) uint16_t qh[32], ql[32], knb[32];
     __shared__ __attribute__((aligned(16))) float vn[32], pacc[4][32];
@@ -400,16 +402,16 @@ __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16
     if (tid < 32) { rq = row[tid]; rk = row[512 + tid]; rv = row[1024 + tid]; }
     raw16 kb[2], vb[2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) kb[it] = ldg16(Kp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
+    for (int it = 0; it < 2; ++it) kb[it] = ldg16w<NTKV>(Kp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
 #pragma unroll
-    for (int it = 0; it < 2; ++it) vb[it] = ldg16(Vp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
+    for (int it = 0; it < 2; ++it) vb[it] = ldg16w<NTKV>(Vp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
     const int n = (int)(n64 < 0 ? 0 : (n64 > a.T - 1 ? a.T - 1 : n64));     // position of the new token
     // One straight-line body per live-chunk count: a load instruction costs its kibibyte on the texture-address path whether its
     // lanes hit one line or sixteen (0.27 us per dead 64-position chunk per launch at 64 sequences), and loading only the live
     // chunks behind per-chunk branches made hipcc drain the load counter in every branch (0.654 -> 0.729 ms per step).
     const int nch = __builtin_amdgcn_readfirstlane((n + 63) >> 6);
     stamp(a.dbg, 1);
-#define GSV_BATTN_REST(N) battn2_rest<N>(a, h, b, n, n64, kb, vb, rq, rk, rv, qh, ql, knb, vn, pacc, pm, pl)
+#define GSV_BATTN_REST(N) battn2_rest<N, NTKV>(a, h, b, n, n64, kb, vb, rq, rk, rv, qh, ql, knb, vn, pacc, pm, pl)
     if (nch <= 2) GSV_BATTN_REST(2);
     else if (nch <= 3) GSV_BATTN_REST(3);
     else if (NIT <= 4 || nch <= 4) GSV_BATTN_REST(4);
