@@ -9,7 +9,7 @@ dt = {"bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn, "fp32": torch.float32}
 cfg = synth.gpt_config(n_layer=int(os.environ.get('GSV_NLAYER', '24')))
 m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1, eos_gain=-8.0))
 m.initialize_runtime(dt, dev, [(B, int(os.environ.get('GSV_T', '512')))])
-rs = [synth.synth_request(i, 40, 60, 100, seed=1) for i in range(B)]
+rs = [synth.synth_request(i, 40, 60, int(os.environ.get('GSV_PROMPT_TOK', '100')), seed=1) for i in range(B)]   # kv ~ 100 + this + the steps run
 with torch.inference_mode():
     xy, xl, yl, _, _ = m.embed_prompt([torch.from_numpy(r[0]).to(dev) for r in rs], [torch.from_numpy(r[1]).to(dev) for r in rs], [torch.from_numpy(r[2]).to(dev) for r in rs])
     m.prefill(B, 0, xy, xl, yl)
