@@ -395,10 +395,11 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
         else hipLaunchKernelGGL((t2s_attn_multi_kernel<WT, 1, 2>), dim3(kH, cdiv(B, 2)), dim3(kNT), ml, st, a, B);
         return;
     }
-    // K/V rows non-temporal from 5 sequences on: weights (152 MB) + a step's K/V rows (B x 49 KB x kv) then exceed what the Infinity
-    // Cache holds; measured at kv ~200 (profiles/r03_kv_nontemporal.txt): 0.283 -> 0.300 ms at 1 sequence (worse: everything fits),
-    // 0.354 -> 0.334 at 8, 0.411 -> 0.380 at 16.  GSV_SEQ_KV_NT_MIN_B moves the switch.
-    static const int kvnt_b = getenv("GSV_SEQ_KV_NT_MIN_B") ? atoi(getenv("GSV_SEQ_KV_NT_MIN_B")) : kFineMaxB + 1;
+    // K/V rows non-temporal from 4 sequences on: weights (152 MB) + a step's K/V rows (B x 49 KB x kv) then exceed what the Infinity
+    // Cache holds (profiles/r03_kv_nontemporal.txt: at 1 sequence the hint costs 6 % at any kv -- everything fits; at 2 it pays only
+    // beyond kv ~900; at 4 it is neutral at kv 250 and worth 3-5 % at kv 550-950; 0.354 -> 0.334 ms at 8, 0.411 -> 0.380 at 16).
+    // GSV_SEQ_KV_NT_MIN_B moves the switch.
+    static const int kvnt_b = getenv("GSV_SEQ_KV_NT_MIN_B") ? atoi(getenv("GSV_SEQ_KV_NT_MIN_B")) : 4;
     if (sizeof(WT) == 2 && B >= kvnt_b) {
         if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2, kNJ, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
         else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0, kNJ, false, true>), dim3(kH, B), dim3(kNT), lds, st, a);
