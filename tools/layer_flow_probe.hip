@@ -2,7 +2,7 @@
 // real block pulls (partial rows the previous launch just wrote on other XCDs + its weights from the Infinity Cache) and
 // writes its own partial row?  Separates "bytes per CU" from the dependency chain of the real kernels.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/layer_flow_probe.hip -o tools/layer_flow_probe
-//   layer_flow_probe [order 0|1] [NJ 32|64] [half 0|1]
+//   layer_flow_probe [order 0|1] [NJ 32|64] [half 0|1] [store flavour 0 plain | 1 nt | 2 sc1 | 3 sc0 sc1]   (flavours with order 0)
 // A-launch ("attention"): 16 blocks x 1024 threads: NJ partial rows of Z (1 KB each as half, 2 KB as float) + 171 KB of weights,
 //                         writes row b of Y.            F-launch ("ffn"): NJ blocks: 16 rows of Y + 4096/NJ KB of weights, writes
 // row b of Z.   order 0: partial rows are issued first (what the kernels do); 1: weights first, partial rows last.
@@ -15,7 +15,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 1024;
 
 // rows: partial rows to read (row bytes = 64 lanes x 16 B = 1 KB per wave-load; `wpr` wave-loads per row); NW: weight wave-loads per wave
-template <int PR, int NW, int ORDER>
+template <int PR, int NW, int ORDER, int ST = 0>   // ST: flavour of the partial-row store (0 plain, 1 nt, 2 sc1, 3 sc0 sc1)
 __global__ __launch_bounds__(NT) void flow(const u32x4* __restrict__ part, int wpr, const u32x4* __restrict__ W, size_t w_block_u4,
                                            u32x4* __restrict__ out, int out_wpr, long long* __restrict__ cyc) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -49,7 +49,13 @@ __global__ __launch_bounds__(NT) void flow(const u32x4* __restrict__ part, int w
     asm volatile("" : "+v"(s) : : "memory");
     const long long t3 = clock64();     // everything landed
     // the block's own partial row(s): wave 0 .. out_wpr-1 write 1 KB each
-    if (wid < out_wpr) out[((size_t)b * out_wpr + wid) * 64 + lane] = s;
+    if (wid < out_wpr) {
+        u32x4* dst = out + ((size_t)b * out_wpr + wid) * 64 + lane;
+        if (ST == 0) *dst = s;
+        else if (ST == 1) __builtin_nontemporal_store(s, dst);
+        else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(s) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(s) : "memory");
+    }
     if (cyc && b == 0 && (tid == 0 || tid == 960)) {
         long long* c = cyc + (tid ? 4 : 0);
         c[0] = t1 - t0; c[1] = t2 - t0; c[2] = t3 - t0; c[3] = clock64() - t0;
@@ -60,6 +66,7 @@ int main(int argc, char** argv) {
     const int order = argc > 1 ? atoi(argv[1]) : 0;
     const int NJ = argc > 2 ? atoi(argv[2]) : 64;
     const int half = argc > 3 ? atoi(argv[3]) : 1;
+    const int stf = argc > 4 ? atoi(argv[4]) : 0;
     const int n_layers = 24;
     const int wpr = half ? 1 : 2;                    // wave-loads (KB) per partial row
     const size_t a_w_u4 = 176 * 64, f_w_u4 = (size_t)(4096 / NJ) * 64;   // per-block weight bytes / 16: 176 KB, 64 or 128 KB
@@ -74,15 +81,19 @@ int main(int argc, char** argv) {
     // A: NJ*wpr partial wave-loads over 16 waves; 176 weight wave-loads over 16 waves = 11.  F: 16*wpr over 16 waves; 4096/NJ over 16 waves
     auto launchA = [&](int l, long long* c) {
         const u32x4* w = WA + (size_t)l * 16 * a_w_u4;
-#define LA(PR) do { if (order == 0) hipLaunchKernelGGL((flow<PR, 11, 0>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
-                    else hipLaunchKernelGGL((flow<PR, 11, 1>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); } while (0)
+#define LA(PR) do { if (stf == 0) hipLaunchKernelGGL((flow<PR, 11, 0, 0>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
+                    else if (stf == 1) hipLaunchKernelGGL((flow<PR, 11, 0, 1>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
+                    else if (stf == 2) hipLaunchKernelGGL((flow<PR, 11, 0, 2>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
+                    else hipLaunchKernelGGL((flow<PR, 11, 0, 3>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); } while (0)
         const int pr = NJ * wpr / 16;
         if (pr == 2) LA(2); else if (pr == 4) LA(4); else LA(8);
     };
     auto launchF = [&](int l, long long* c) {
         const u32x4* w = WF + (size_t)l * NJ * f_w_u4;
-#define LF(PR, NW) do { if (order == 0) hipLaunchKernelGGL((flow<PR, NW, 0>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
-                        else hipLaunchKernelGGL((flow<PR, NW, 1>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); } while (0)
+#define LF(PR, NW) do { if (stf == 0) hipLaunchKernelGGL((flow<PR, NW, 0, 0>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
+                        else if (stf == 1) hipLaunchKernelGGL((flow<PR, NW, 0, 1>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
+                        else if (stf == 2) hipLaunchKernelGGL((flow<PR, NW, 0, 2>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
+                        else hipLaunchKernelGGL((flow<PR, NW, 0, 3>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); } while (0)
         if (NJ == 64) { if (wpr == 1) LF(1, 4); else LF(2, 4); }
         else { if (wpr == 1) LF(1, 8); else LF(2, 8); }
     };
@@ -101,7 +112,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         long long h[16]; CK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
-        printf("order %d NJ %d %s rows, %s: %.2f us per layer\n", order, NJ, half ? "half" : "float", which == 0 ? "A + F" : (which == 1 ? "A only (partials not fresh)" : "F only (partials not fresh)"),
+        printf("order %d store %d NJ %d %s rows, %s: %.2f us per layer\n", order, stf, NJ, half ? "half" : "float", which == 0 ? "A + F" : (which == 1 ? "A only (partials not fresh)" : "F only (partials not fresh)"),
                ms * 1e3 / reps / n_layers);
         if (which == 0) {
             printf("   A block 0 cycles since entry (first load landed, partial rows landed, all landed, row written): wave 0 %lld %lld %lld %lld | wave 15 %lld %lld %lld %lld\n",
