@@ -493,7 +493,7 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 // GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
 constexpr int kBatchedMinDefault = 17;
 constexpr size_t kPrefillLdsMax = 160 * 1024;
-constexpr int kNtFromLayerF32 = 10;    // fp32 handles: 10 layers (127 MB) + the K/V rows of a step stay in the Infinity Cache: 0.490 -> 0.440 ms per step (profiles/r03_f32_nontemporal_layers.txt)
+constexpr int kNtFromLayerF32 = 9;     // fp32 handles: 9 layers (114 MB; best of 6..14 at kv ~400, within 1 % of the best at kv ~200) + the K/V rows of a step stay in the Infinity Cache: 0.490 -> 0.440 ms per step (profiles/r03_f32_nontemporal_layers.txt)
 
 // The 5-launches-per-layer chain of t2s_batch.h on M rows (decode: one row per sequence; prompt pass: nrows * l_max
 // rows).  x0 [M][512] fp32 is the input of layer 0 and is overwritten with each layer's input (the residual of the
