@@ -2,7 +2,7 @@
 // real block pulls (partial rows the previous launch just wrote on other XCDs + its weights from the Infinity Cache) and
 // writes its own partial row?  Separates "bytes per CU" from the dependency chain of the real kernels.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/layer_flow_probe.hip -o tools/layer_flow_probe
-//   layer_flow_probe [order 0|1] [NJ 32|64] [half 0|1] [store flavour 0 plain | 1 nt | 2 sc1 | 3 sc0 sc1]   (flavours with order 0)
+//   layer_flow_probe [order 0|1] [NJ 32|64] [half 0|1] [store flavour 0 plain | 1 nt | 2 sc1 | 3 sc0 sc1 | 4 two-byte pieces from every wave, as the decode kernels store]   (flavours with order 0)
 // A-launch ("attention"): 16 blocks x 1024 threads: NJ partial rows of Z (1 KB each as half, 2 KB as float) + 171 KB of weights,
 //                         writes row b of Y.            F-launch ("ffn"): NJ blocks: 16 rows of Y + 4096/NJ KB of weights, writes
 // row b of Z.   order 0: partial rows are issued first (what the kernels do); 1: weights first, partial rows last.
@@ -49,7 +49,14 @@ __global__ __launch_bounds__(NT) void flow(const u32x4* __restrict__ part, int w
     asm volatile("" : "+v"(s) : : "memory");
     const long long t3 = clock64();     // everything landed
     // the block's own partial row(s): wave 0 .. out_wpr-1 write 1 KB each
-    if (wid < out_wpr) {
+    if (ST == 4) {
+        // what the decode kernels do: every wave writes 32 two-byte results of the block's 1-KiB row, 16 per store instruction
+        unsigned short* rowp = reinterpret_cast<unsigned short*>(out + (size_t)b * out_wpr * 64);
+        if ((lane & 3) == 0) {
+            rowp[wid * 16 + (lane >> 2)] = (unsigned short)s[0];
+            rowp[256 + wid * 16 + (lane >> 2)] = (unsigned short)s[1];
+        }
+    } else if (wid < out_wpr) {
         u32x4* dst = out + ((size_t)b * out_wpr + wid) * 64 + lane;
         if (ST == 0) *dst = s;
         else if (ST == 1) __builtin_nontemporal_store(s, dst);
@@ -84,7 +91,8 @@ int main(int argc, char** argv) {
 #define LA(PR) do { if (stf == 0) hipLaunchKernelGGL((flow<PR, 11, 0, 0>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
                     else if (stf == 1) hipLaunchKernelGGL((flow<PR, 11, 0, 1>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
                     else if (stf == 2) hipLaunchKernelGGL((flow<PR, 11, 0, 2>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
-                    else hipLaunchKernelGGL((flow<PR, 11, 0, 3>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); } while (0)
+                    else if (stf == 3) hipLaunchKernelGGL((flow<PR, 11, 0, 3>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
+                    else hipLaunchKernelGGL((flow<PR, 11, 0, 4>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); } while (0)
         const int pr = NJ * wpr / 16;
         if (pr == 2) LA(2); else if (pr == 4) LA(4); else LA(8);
     };
@@ -93,7 +101,8 @@ int main(int argc, char** argv) {
 #define LF(PR, NW) do { if (stf == 0) hipLaunchKernelGGL((flow<PR, NW, 0, 0>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
                         else if (stf == 1) hipLaunchKernelGGL((flow<PR, NW, 0, 1>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
                         else if (stf == 2) hipLaunchKernelGGL((flow<PR, NW, 0, 2>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
-                        else hipLaunchKernelGGL((flow<PR, NW, 0, 3>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); } while (0)
+                        else if (stf == 3) hipLaunchKernelGGL((flow<PR, NW, 0, 3>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
+                        else hipLaunchKernelGGL((flow<PR, NW, 0, 4>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); } while (0)
         if (NJ == 64) { if (wpr == 1) LF(1, 4); else LF(2, 4); }
         else { if (wpr == 1) LF(1, 8); else LF(2, 8); }
     };
