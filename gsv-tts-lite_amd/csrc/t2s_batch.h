@@ -111,6 +111,8 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             for (int s = 0; s < 8; ++s)
                 wf[s] = __builtin_bit_cast(u32x4, a.W[((size_t)m * KS + wid * 8 + s) * 64 + lane]);
         }
+    };
+    auto load_epi = [&](int m) {
         const int ech = NW == 4 ? m * 32 + 16 * hf : m * 32 + (tid & 7) * 4;
 #pragma unroll
         for (int g = 0; g < NEP; ++g) { e_bias[g] = f32x4{0.f, 0.f, 0.f, 0.f}; e_scale[g] = f32x4{1.f, 1.f, 1.f, 1.f}; e_res[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -130,7 +132,11 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             }
         }
     };
+    constexpr bool EPI_LATE = sizeof(XT) == 2;   // bf16 rows (W2): the epilogue operands go behind the X loads -- hipcc copies a component of
+                                                 // the freshly loaded bias at once and drains the load counter for it, so with the X loads still
+                                                 // to come the writer waves issued them a memory latency late
     load_w(mt);
+    if constexpr (!EPI_LATE) load_epi(mt);
     uint32_t xb[8][4];   // bf16: xb[g][0..3] = 8 bf16 of group g; fp8: xb[g][0..1] = 8 e4m3 of group g
     if constexpr (STG) {
         const float* X = reinterpret_cast<const float*>(a.X);
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
             const u32x4 t = *reinterpret_cast<const u32x4*>(xp + bg_chan<false>(wid, g, hf));
             xb[g][0] = t[0]; xb[g][1] = t[1]; xb[g][2] = t[2]; xb[g][3] = t[3];
         }
+        load_epi(mt);
     } else {
         static_assert(sizeof(XT) != 1 || F8, "fp8 rows feed the fp8 contraction");
         const fp8_t* xp = reinterpret_cast<const fp8_t*>(a.X) + (size_t)rowc * a.ldx;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
     }
 
     for (int ct = 0; ct < cpb && mt < a.mtiles; ++ct, ++mt) {
-    if (ct > 0) load_w(mt);
+    if (ct > 0) { load_w(mt); load_epi(mt); }
     // all loads issued, THEN arithmetic: hipcc otherwise re-uses operand registers and interleaves the later loads
     // with the MFMAs (measured in the ISA: 8 of 16 loads up front), i.e. two exposed memory latencies instead of one
     asm volatile("" : "+v"(wf[0]) : : "memory");

@@ -501,12 +501,10 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     uint16_t* attl = atth + 32;
     stamp(a.dbg, 0);
 
-    int n = (int)a.kv_len[b];
-    // kv_len < 0 = a PARKED slot (include/gsv_tts_hip.h, staged refill): its K/V row goes to the last row of the cache,
-    // which no prompt pass writes, and it attends over row 0 only -- it must not touch rows a concurrent refill fills
-    const int nw = n < 0 ? a.T - 1 : (n > a.T - 1 ? a.T - 1 : n);
-    if (n > a.T - 1) n = a.T - 1;  // memory safety only; the host never steps a full cache
-    if (n < 0) n = 0;
+    // kv_len is loaded FIRST and used LAST: only the K/V row addresses need it.  (Clamping right here made hipcc wait for this --
+    // cold -- load before it issued a single weight load: the whole weight stream started 1.5k cycles late.)
+    // (its LOW dword only: hipcc re-used the unused upper half of a 64-bit destination as a temporary and put the wait there)
+    int kvl_raw = reinterpret_cast<const int*>(a.kv_len)[2 * b];
     WT* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
     WT* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
     const int part = tid % LPR, rsub = tid / LPR;
@@ -531,6 +529,18 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     raw16 wq[RW][CPR];
 #pragma unroll
     for (int r = 0; r < RW; ++r) row_load<WT, NT>(wp + (size_t)r * kD, wq[r]);
+    Panel<WT, kDh> po;
+    po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
+    const int oi = sumN_index<8>();
+    const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
+    // ... and now kv_len (the opaque asm keeps its first use -- and with it the wait -- down here, behind the weight loads)
+    asm volatile("" : "+v"(kvl_raw) : : "memory");
+    int n = kvl_raw;
+    // kv_len < 0 = a PARKED slot (include/gsv_tts_hip.h, staged refill): its K/V row goes to the last row of the cache,
+    // which no prompt pass writes, and it attends over row 0 only -- it must not touch rows a concurrent refill fills
+    const int nw = n < 0 ? a.T - 1 : (n > a.T - 1 ? a.T - 1 : n);
+    if (n > a.T - 1) n = a.T - 1;  // memory safety only; the host never steps a full cache
+    if (n < 0) n = 0;
     // K/V rows are loaded UNCONDITIONALLY from a clamped (always valid) row and masked at use: a
     // per-element "load or zero" select makes hipcc branch around each load and drain vmcnt(0)
     raw16 kreg[KCH], vreg[KCH];
@@ -538,10 +548,6 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     for (int it = 0; it < KCH; ++it) kreg[it] = ldg16w<NTKV>(Kp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
 #pragma unroll
     for (int it = 0; it < KCH; ++it) vreg[it] = ldg16w<NTKV>(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
-    Panel<WT, kDh> po;
-    po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
-    const int oi = sumN_index<8>();
-    const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
     // Pin "all loads issued, THEN arithmetic": the opaque asm redefines the head of the partial-sum
     // chain, so no add can be scheduled above it, while the memory clobber keeps every load above
     // it.  It only needs the FIRST-issued load to have landed.
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     if constexpr (MODE == 0) {
         v = xd;
     } else if constexpr (MODE == 2) {
-        v = steptok_finish(a.tk, tl, b, lane, tid, owner, a.kv_len[b], a.T, h == 0 && tid == 0);
+        v = steptok_finish(a.tk, tl, b, lane, tid, owner, (int64_t)kvl_raw, a.T, h == 0 && tid == 0);   // (a second load of kv_len here drained the load counter)
     } else {
         ps.park(stage);
         __syncthreads();
@@ -870,6 +876,10 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     const int nrow = min(rpb, a.V - vbase);
     const bool owner = tid < kD;
 
+    // the control words are loaded FIRST and used LAST (as scalars): loaded behind the weight rows, their first use drained the
+    // whole load counter before the LayerNorm could start
+    int c_step = a.step[b], c_sup = a.ctl[1], c_first = a.ctl[7], c_rep = a.ctl[2];
+    float c_rp = a.fctl[0];
     PartialSum<NJ, typename Geo<WT>::PT> ps;
     float xd = 0.f;
     if constexpr (MODE == 0) {
@@ -887,12 +897,13 @@ __global__ __launch_bounds__(kNT) void t2s_logits_kernel(LogitsArgs<WT> a) {
     }
     // the first sample (the prefill's logits: vlimit < V) is suppressed unconditionally by infer / infer_stream
     // (t2s_model.py:415-416; ctl[7] set by the host), later samples while step < initial_suppression_steps (:444-445)
-    const bool sup = a.step[b] < a.ctl[1] || (a.vlimit < a.V && a.ctl[7] != 0);
-    const bool rep = a.ctl[2] != 0;
-    const float rp = a.fctl[0];
     const int oi = sumN_index<8>();
     const int myr = wid * rww + oi;             // slice row this lane will emit (if oi < rww)
     const uint8_t sn = a.seen[(size_t)b * a.V + min(vbase + myr, a.V - 1)];
+    asm volatile("" : "+v"(c_step), "+v"(c_sup), "+v"(c_first), "+v"(c_rep), "+v"(c_rp) : : "memory");
+    const bool sup = c_step < c_sup || (a.vlimit < a.V && c_first != 0);
+    const bool rep = c_rep != 0;
+    const float rp = c_rp;
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd) : : "memory");
     else asm volatile("" : "+v"(ps.p[0][0]) : : "memory");
 

@@ -300,7 +300,9 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
     for (int it = 2; it < NCH; ++it) kr[it] = ldg16w<NTKV>(Kp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
 #pragma unroll
     for (int it = 2; it < NCH; ++it) vr[it] = ldg16w<NTKV>(Vp + (size_t)min(it * 64 + rsub, lastrow) * kDh + part * 8);
-    asm volatile("" : "+v"(rq) : : "memory");
+    // q, k AND v pinned here: with only q pinned hipcc hoisted the bf16 rounding of k / v -- and the wait for their cold row -- above
+    // the blind K/V loads, which then left a microsecond late
+    asm volatile("" : "+v"(rq), "+v"(rk), "+v"(rv) : : "memory");
     stamp(a.dbg, 2);
     if (tid < 32) {
         uint16_t vh, vl;
@@ -396,8 +398,10 @@ __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16
     const bf16_t* Kp = a.kc + (((size_t)b * kH + h) * a.T) * kDh;
     const bf16_t* Vp = a.vc + (((size_t)b * kH + h) * a.T) * kDh;
     stamp(a.dbg, 0);
-    // kv_len FIRST: the in-order load counter then lets the chunk count wait for it alone
-    const int64_t n64 = a.kv_len[b];
+    // kv_len FIRST (its low dword: the value fits, and hipcc re-uses an unused upper half as a temporary and waits for it): the
+    // in-order load counter then lets the chunk count wait for it alone -- and that wait is pinned BEHIND the blind loads (left
+    // to itself hipcc put it right behind the kv_len load: nothing was in flight while the block waited for a cold line)
+    int kvl_raw = reinterpret_cast<const int*>(a.kv_len)[2 * b];
     float rq = 0.f, rk = 0.f, rv = 0.f;
     if (tid < 32) { rq = row[tid]; rk = row[512 + tid]; rv = row[1024 + tid]; }
     raw16 kb[2], vb[2];
@@ -405,6 +409,8 @@ __global__ __launch_bounds__(256) void t2s_batch_attn2_kernel(BatchAttnArgs<bf16
     for (int it = 0; it < 2; ++it) kb[it] = ldg16w<NTKV>(Kp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
 #pragma unroll
     for (int it = 0; it < 2; ++it) vb[it] = ldg16w<NTKV>(Vp + (size_t)min(it * 64 + rsub, a.T - 1) * kDh + part * 8);
+    asm volatile("" : "+v"(kvl_raw) : : "memory");
+    const int64_t n64 = kvl_raw;
     const int n = (int)(n64 < 0 ? 0 : (n64 > a.T - 1 ? a.T - 1 : n64));     // position of the new token
     // One straight-line body per live-chunk count: a load instruction costs its kibibyte on the texture-address path whether its
     // lanes hit one line or sixteen (0.27 us per dead 64-position chunk per launch at 64 sequences), and loading only the live
