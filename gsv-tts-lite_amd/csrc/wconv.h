@@ -82,17 +82,22 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     const int ntiles = (n_rows + BN - 1) / BN;
     if (blk >= ntiles) return;
 
-    // the wave's weights: every (tap, k-step) fragment of its 32-channel slice
+    // the wave's weights: every (tap, k-step) fragment of its 32-channel slice.  Issued BEHIND the first tile's rows and the bias
+    // (issue_x below): in front of them, the bias store to LDS drained the load counter -- all of the block's 90-350 KB of weights --
+    // before a single row of the first tile was requested (hipcc places the wait at the first use of the LAST load issued)
     u32x4 w[NT][KSW];
     const int msw = live ? gs : 0;
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KSW; ++ks)
-            w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + msw) * KSTEPS + kh * KSW + ks) * 64 + lane]);
+            for (int ks = 0; ks < KSW; ++ks)
+                w[t][ks] = __builtin_bit_cast(u32x4, W[(((size_t)t * MT + msw) * KSTEPS + kh * KSW + ks) * 64 + lane]);
+    };
     // bias sits in LDS (registers are for weights): [MS*32] floats behind the patches
     float* bl = reinterpret_cast<float*>(lds + 2 * XBYTES + 4 * ROBYTES);
-    if (tid < MS * 32) bl[tid] = (bias && mg * MS * 32 + tid < cout) ? bias[mg * MS * 32 + tid] : 0.f;
+    float bias_raw = 0.f;                       // loaded from a clamped address now, masked at its use (a select here is a use)
+    if (bias != nullptr) bias_raw = bias[min(mg * MS * 32 + (tid < MS * 32 ? tid : 0), cout - 1)];
     // KSP = 2: the second half's partial tiles, [MS*RG waves][WN][16][64] floats behind the bias
     float* kred = reinterpret_cast<float*>(lds + 2 * XBYTES + 4 * ROBYTES + MS * 32 * sizeof(float)) + (size_t)(rg * MS + ms) * WN * 16 * 64;
 
@@ -133,6 +138,8 @@ __device__ __forceinline__ void wconv_body(const bf16_t* __restrict__ X, const u
     const bool epi = live && kh == 0;             // the wave that owns the tile's epilogue
 
     issue_x(blk);
+    load_weights();
+    if (tid < MS * 32) bl[tid] = mg * MS * 32 + tid < cout ? bias_raw : 0.f;
     commit_x(blk, xbuf0);
     __syncthreads();
     int cur = 0, nst = 0;
