@@ -71,17 +71,22 @@ __global__ __launch_bounds__(256, 1) void wups_kernel(WUpsArgs a) {
         smin = min(smin, sb[p] - (NTAPS - 1));
     }
 
+    // the wave's weights are requested BEHIND the first tile's rows and the bias (as in wconv.h: in front of them, the bias store
+    // to LDS drained every weight load before a single row was requested)
     u32x4 w[NF];
     const int gsw = live ? gs : 0;
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int p = 0; p < PG; ++p)
+        for (int p = 0; p < PG; ++p)
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
+            for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks)
-                w[(p * NTAPS + t) * KSTEPS + ks] =
-                    __builtin_bit_cast(u32x4, a.W[((((size_t)(pg * PG + p) * NTAPS + t) * a.mtiles + gsw) * KSTEPS + ks) * 64 + lane]);
-    if (tid < MS * 32) bl[tid] = (a.bias && mg * MS * 32 + tid < a.cout) ? a.bias[mg * MS * 32 + tid] : 0.f;
+                for (int ks = 0; ks < KSTEPS; ++ks)
+                    w[(p * NTAPS + t) * KSTEPS + ks] =
+                        __builtin_bit_cast(u32x4, a.W[((((size_t)(pg * PG + p) * NTAPS + t) * a.mtiles + gsw) * KSTEPS + ks) * 64 + lane]);
+    };
+    float bias_raw = 0.f;                       // clamped address now, masked at its use
+    if (a.bias != nullptr) bias_raw = a.bias[min(mg * MS * 32 + (tid < MS * 32 ? tid : 0), a.cout - 1)];
 
     u32x4 xraw[NVX];
     auto issue_x = [&](int tile) {
@@ -107,6 +112,8 @@ __global__ __launch_bounds__(256, 1) void wups_kernel(WUpsArgs a) {
     auto piece_ok = [&](int pc) { return gs * 32 + pc * 8 < a.cvalid; };
 
     issue_x(walker);
+    load_weights();
+    if (tid < MS * 32) bl[tid] = mg * MS * 32 + tid < a.cout ? bias_raw : 0.f;
     commit_x(walker, xbuf0);
     __syncthreads();
     int cur = 0;
