@@ -194,36 +194,57 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
     const float* base = a.qkv + (size_t)r * a.l_max * 1536;
     bf16_t* Kp = a.kc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
     bf16_t* Vp = a.vc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
-    // ---- stage K (rows), V (transposed, permuted), Q (rows): one float4 of 4 d per item
-    for (int e = tid; e < nkt * 32 * 8; e += 256) {
-        const int t = e >> 3, d4 = (e & 7) * 4;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (t < L) {
-            kv = *reinterpret_cast<const f32x4*>(base + (size_t)t * 1536 + 512 + h * 32 + d4);
-            vv = *reinterpret_cast<const f32x4*>(base + (size_t)t * 1536 + 1024 + h * 32 + d4);
+    // ---- stage K (rows), V (transposed, permuted), Q (rows): one float4 of 4 d per item.  Four items' loads are in flight before the
+    //      first is used, from clamped (always valid) addresses and masked afterwards: one item per iteration was one memory round
+    //      trip per iteration (load, wait, convert, store: 7 in a row for a 200-position prompt)
+    constexpr int SU = 4;
+    const int n_items = nkt * 32 * 8;
+    for (int e0 = tid; e0 < n_items; e0 += 256 * SU) {
+        f32x4 kv[SU], vv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int e = e0 + u * 256, t = e >> 3, d4 = (e & 7) * 4;
+            const int tc = min(t, max(L - 1, 0));
+            kv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)tc * 1536 + 512 + h * 32 + d4);
+            vv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)tc * 1536 + 1024 + h * 32 + d4);
         }
-        uint2 kp, vp;
-        kp.x = pack_bf16x2(kv[0], kv[1]); kp.y = pack_bf16x2(kv[2], kv[3]);
-        vp.x = pack_bf16x2(vv[0], vv[1]); vp.y = pack_bf16x2(vv[2], vv[3]);
-        *reinterpret_cast<uint2*>(Ks + (size_t)t * KRS + d4 * 2) = kp;
-        const int pos = (t & ~31) + vpos(t & 31);
-        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 0) * vrs + pos * 2) = (bf16_t)(vp.x & 0xffff);
-        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 1) * vrs + pos * 2) = (bf16_t)(vp.x >> 16);
-        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 2) * vrs + pos * 2) = (bf16_t)(vp.y & 0xffff);
-        *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 3) * vrs + pos * 2) = (bf16_t)(vp.y >> 16);
-        if (t >= qb0 && t < qb0 + 128 && t < L && t < a.T) {   // each block writes the cache rows of its own queries: once each
-            *reinterpret_cast<uint2*>(Kp + (size_t)t * kDh + d4) = kp;
-            *reinterpret_cast<uint2*>(Vp + (size_t)t * kDh + d4) = vp;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int e = e0 + u * 256, t = e >> 3, d4 = (e & 7) * 4;
+            if (e < n_items) {
+                const bool ok = t < L;
+                uint2 kp, vp;
+                kp.x = ok ? pack_bf16x2(kv[u][0], kv[u][1]) : 0u; kp.y = ok ? pack_bf16x2(kv[u][2], kv[u][3]) : 0u;
+                vp.x = ok ? pack_bf16x2(vv[u][0], vv[u][1]) : 0u; vp.y = ok ? pack_bf16x2(vv[u][2], vv[u][3]) : 0u;
+                *reinterpret_cast<uint2*>(Ks + (size_t)t * KRS + d4 * 2) = kp;
+                const int pos = (t & ~31) + vpos(t & 31);
+                *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 0) * vrs + pos * 2) = (bf16_t)(vp.x & 0xffff);
+                *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 1) * vrs + pos * 2) = (bf16_t)(vp.x >> 16);
+                *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 2) * vrs + pos * 2) = (bf16_t)(vp.y & 0xffff);
+                *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 3) * vrs + pos * 2) = (bf16_t)(vp.y >> 16);
+                if (t >= qb0 && t < qb0 + 128 && ok && t < a.T) {   // each block writes the cache rows of its own queries: once each
+                    *reinterpret_cast<uint2*>(Kp + (size_t)t * kDh + d4) = kp;
+                    *reinterpret_cast<uint2*>(Vp + (size_t)t * kDh + d4) = vp;
+                }
+            }
         }
     }
-    for (int e = tid; e < 128 * 8; e += 256) {
-        const int qi = e >> 3, d4 = (e & 7) * 4;
-        const int i = qb0 + qi;
-        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-        if (i < L) qv = *reinterpret_cast<const f32x4*>(base + (size_t)i * 1536 + h * 32 + d4);
-        uint2 qp;
-        qp.x = pack_bf16x2(qv[0], qv[1]); qp.y = pack_bf16x2(qv[2], qv[3]);
-        *reinterpret_cast<uint2*>(Qs + (size_t)qi * KRS + d4 * 2) = qp;
+    {
+        f32x4 qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                            // 128 x 8 items = 4 per thread, all in flight
+            const int e = tid + u * 256, qi = e >> 3, d4 = (e & 7) * 4;
+            const int ic = min(qb0 + qi, max(L - 1, 0));
+            qv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)ic * 1536 + h * 32 + d4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * 256, qi = e >> 3, d4 = (e & 7) * 4;
+            const bool ok = qb0 + qi < L;
+            uint2 qp;
+            qp.x = ok ? pack_bf16x2(qv[u][0], qv[u][1]) : 0u; qp.y = ok ? pack_bf16x2(qv[u][2], qv[u][3]) : 0u;
+            *reinterpret_cast<uint2*>(Qs + (size_t)qi * KRS + d4 * 2) = qp;
+        }
     }
     __syncthreads();
     if (q0 >= a.l_max) return;
