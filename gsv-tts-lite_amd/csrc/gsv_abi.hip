@@ -421,8 +421,9 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     f.ypart = (const typename Geo<WT>::PT*)h->ypart; f.bo = L.bo; f.x = h->xbuf; f.ln1g = L.ln1g; f.ln1b = L.ln1b; f.x1out = h->x1buf;
     f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = (typename Geo<WT>::PT*)h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     const int B = s.batch;
+    static const int ffn_single_max_b = getenv("GSV_FFN_SINGLE_MAX_B") ? atoi(getenv("GSV_FFN_SINGLE_MAX_B")) : 8;   // tuning aid
     if (B > 16 && sizeof(WT) == 2) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B);
-    else if (B > 8) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
+    else if (B > ffn_single_max_b) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
     else if (ffn_slices<WT>(B) == kNJFine) {
         f.w2p = (const WT*)L.w2_p64;
         hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
