@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sampling / time-to-first-audio / fp32 extras")
+    ap.add_argument("--no-cb32", action="store_true", help="single: skip the cb32 sub-record (32-slot continuous batching through the engine, "
+                    "vocoder stage and rank-0 gather inside its timed steps; ~6 s)")
+    ap.add_argument("--cb32-steps", type=int, default=2, help="single: timed passes over the 256-requests-per-GPU queue of the cb32 sub-record (after 1 warm-up pass)")
     ap.add_argument("--ttft-runs", type=int, default=50)
     ap.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CI on a 1-GPU box)")
@@ -204,21 +207,41 @@ def _torch_dtype(name):
     return {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}[name]
 
 
+def csrc_sha16():
+    """sha256 over the kernel sources (csrc/*.h, *.hip, sorted by name): what a PMC pass in profiles/ is valid for.  The GPU box
+    has no .git, so the stamp is content-based; profiles/traffic.json carries the same hash plus the commit it was taken at."""
+    import hashlib
+    d = os.path.join(ROOT, "gsv-tts-lite_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _profile_traffic(out, a):
-    """HBM traffic per launch from the committed PMC passes (profiles/traffic.json): counters cannot be read in-process"""
+    """HBM traffic per launch from the committed PMC passes (profiles/traffic.json): counters cannot be read in-process.  The file
+    is stamped with the commit and the csrc hash it was measured at; when the kernels changed since, traffic stays null."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tfile):
         return
     try:
         tr = json.load(open(tfile))
+        meta = tr.get("_meta", {})
+        out["roofline"]["traffic_commit"] = meta.get("commit")
+        out["roofline"]["traffic_csrc_sha16"] = meta.get("csrc_sha16")
+        if meta.get("csrc_sha16") != csrc_sha16():
+            out["roofline"]["traffic_source"] = ("profiles/traffic.json was measured at commit %s (csrc %s); the kernels changed since (csrc %s): "
+                                                 "no traffic figure is claimed for this build" % (meta.get("commit"), meta.get("csrc_sha16"), csrc_sha16()))
+            return
         for k in out.get("roofline_kernels", []):
             if k["kernel"] in tr:
                 k["traffic"] = tr[k["kernel"]]
         if "kernel" in out["roofline"]:
             out["roofline"]["traffic"] = tr.get(out["roofline"]["kernel"])
             out["roofline"]["traffic_source"] = ("profiles/traffic.json: per-launch mean of two rocprofv3 --pmc passes (FETCH_SIZE x2 per the "
-                                                 "micro-architecture guide, WRITE_SIZE) over this command with --steps 2 --no-extras, "
-                                                 "tools/sweep.sh of this round; hardware counters cannot be read from inside the process")
+                                                 "micro-architecture guide, WRITE_SIZE) over this command with --steps 2 --no-extras --no-cb32, "
+                                                 "tools/sweep.sh at the commit above; hardware counters cannot be read from inside the process")
         if a.version == "v2Pro" and a.dtype == "bf16" and "roofline_vocoder" in out:
             out["roofline_vocoder"]["traffic"] = tr.get("vocoder_pass")
     except Exception:
@@ -252,9 +275,14 @@ def setup_dist(a):
         raise SystemExit("bench.py --gpus %d is running with WORLD_SIZE=%d: launch it bare (it starts its own ranks) or under "
                          "torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
     dist = None
-    if world > 1:
+    # GSV_FORCE_COLLECTIVES=1: a one-rank run still initialises the process group and sends every exchange through the backend's
+    # collectives (engine.py) -- how a 1-GPU box proves that RCCL comes up under this exact command (tests/test_hip_rccl.py)
+    if world > 1 or os.environ.get("GSV_FORCE_COLLECTIVES") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
         torch.cuda.set_device(local)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -266,7 +294,8 @@ def setup_dist(a):
 
 
 def dist_info(a, world, book):
-    return {"world_size": world, "backend": (a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else "")) if world > 1 else None,
+    import torch.distributed as td
+    return {"world_size": world, "backend": (td.get_backend() + (" (RCCL)" if td.get_backend() == "nccl" else "")) if td.is_initialized() else None,
             "speaker_broadcasts": book.broadcasts, "ranks_share_one_gpu": bool(a.share_gpu)}
 
 
@@ -367,6 +396,28 @@ def run_single(a):
         "ar_ms_per_token": t_ar / tokens_per_step * 1e3,
         "vocoder_ms": t_voc * 1e3,
     }
+
+    # ---- cb32: BASELINE's "bs=1/32" second half, on every line.  v2Pro, 32 slots and 256 mixed-length requests per GPU through
+    # ContinuousBatchingEngine (shared request cursor, token exchange, vocoder stage dealt over the ranks, every request's
+    # samples gathered on rank 0 INSIDE the timed step); at --gpus 8 this record is configs[3].  Every rank takes part.
+    cb32 = None
+    if not a.no_cb32:
+        try:
+            w = CBWorkload(a, world, rank, dev, dist, a.version, a.dtype, CB_SLOTS, CB_REQUESTS_PER_GPU, voc=voc, book=book, ge=ge)
+            el = timed_region(a.cb32_steps, 1, w.step, dev, dist)
+            cb32 = w.record(el, a.cb32_steps, 1)
+            for k in ("metric", "unit", "higher_is_better", "scaling", "vs_baseline", "data"):
+                cb32.pop(k, None)
+            log("cb32 done: %.0f tok/s" % cb32["value"])
+            del w
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            if world > 1:
+                raise          # a rank that drops out of a collective must not leave the others waiting
+            log("cb32 failed: %r" % (exc,))
+            cb32 = {"value": None, "error": repr(exc)}
+    if cb32 is not None:
+        out["cb32"] = cb32
 
     if rank == 0:
         x, y, bert = reqs[0]
@@ -537,47 +588,54 @@ def run_single(a):
 
 
 # ================================================================================================ configs[2] / [3] / [4]
-def run_cb(a):
-    world, rank, dev, dist = setup_dist(a)
-    from gsv_tts_lite_amd import synth, engine
-    from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
-    from gsv_tts_lite_amd.sovits import _VocoderNative
+class CBWorkload:
+    """Continuous batching through the multi-GPU engine, the vocoder stage and the rank-0 gather included: what `--workload cb`
+    times, and what every `--workload single` line carries as its `cb32` sub-record (v2Pro, 32 slots and 256 requests per GPU:
+    BASELINE's "bs=1/32"; at --gpus 8 that sub-record IS configs[3])."""
 
-    dtype = _torch_dtype(a.dtype)
-    vdtype = torch.bfloat16 if a.dtype == "fp8" else dtype       # fp8 operands exist in the GPT batched step only
-    sbytes = 4 if a.dtype == "fp32" else 2
-    cfg = synth.gpt_config()
-    gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)      # lengths come from the per-request budgets below, not from EOS
-    hps = synth.sovits_hps(a.version)
-    sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
-    gin = hps["model"]["gin_channels"]
-    t2s = Text2SemanticDecoder(cfg)
-    t2s.load_state_dict(gw)
-    t2s.initialize_runtime(dtype, dev, [(a.slots, 512), (a.slots, 1024)])     # SURVEY.md 8(d) buckets
-    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, vdtype, dev)
-    eng = engine.ContinuousBatchingEngine(t2s, slots=a.slots, chunk=2)
-    book = engine.SpeakerBook(dev)
-    ge = book.sync("speaker-0", [torch.from_numpy(synth.synth_ge(0, gin, 1234))] if rank == 0 else None)[0]
+    def __init__(self, a, world, rank, dev, dist, version, dtype_name, slots, requests, voc=None, book=None, ge=None):
+        from gsv_tts_lite_amd import synth, engine
+        from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
+        from gsv_tts_lite_amd.sovits import _VocoderNative
+        self.a, self.world, self.rank, self.dev, self.dist = a, world, rank, dev, dist
+        self.version, self.dtype_name, self.slots, self.requests = version, dtype_name, slots, requests
+        self.dtype = _torch_dtype(dtype_name)
+        self.vdtype = torch.bfloat16 if dtype_name == "fp8" else self.dtype      # fp8 operands exist in the GPT batched step only
+        self.sbytes = 4 if dtype_name == "fp32" else 2
+        cfg = synth.gpt_config()
+        gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)      # lengths come from the per-request budgets below, not from EOS
+        self.hps = synth.sovits_hps(version)
+        gin = self.hps["model"]["gin_channels"]
+        self.t2s = Text2SemanticDecoder(cfg)
+        self.t2s.load_state_dict(gw)
+        self.t2s.initialize_runtime(self.dtype, dev, [(slots, 512), (slots, 1024)])     # SURVEY.md 8(d) buckets
+        if voc is None:
+            sw = synth.sovits_weights(self.hps, seed=1234, hot_path_only=True)
+            voc = _VocoderNative(self.hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, self.vdtype, dev)
+        self.voc = voc
+        self.eng = engine.ContinuousBatchingEngine(self.t2s, slots=slots, chunk=2)
+        self.book = book if book is not None else engine.SpeakerBook(dev)
+        self.ge = ge if ge is not None else self.book.sync("speaker-0", [torch.from_numpy(synth.synth_ge(0, gin, 1234))] if rank == 0 else None)[0]
+        self.n_req = n_req = requests * world
+        lens = synth.mixed_lengths(n_req)                         # Lx2 ~ U[20,120], Ly ~ U[75,150]   (SURVEY.md 8(d))
+        self.new_tok = synth.mixed_new_tokens(n_req)              # N ~ U[50,400]
+        reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
+        self.xs = [torch.from_numpy(r[0]).to(dev) for r in reqs]
+        self.ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
+        self.bs = [torch.from_numpy(r[2]).to(dev) for r in reqs]
+        self.acc = {"tok": 0, "frames": 0, "t_ar": 0.0, "t_voc": 0.0, "steps": 0, "kv_rows": 0, "mine": 0, "gathered_samples": 0, "timed": 0}
+        self.costs = [int(x.shape[0]) + int(y.shape[0]) + int(n) for x, y, n in zip(self.xs, self.ys, self.new_tok)] if a.lpt_budget else None
 
-    n_req = a.requests * world
-    lens = synth.mixed_lengths(n_req)                         # Lx2 ~ U[20,120], Ly ~ U[75,150]   
-    new_tok = synth.mixed_new_tokens(n_req)                   # N ~ U[50,400]
-    reqs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
-    xs = [torch.from_numpy(r[0]).to(dev) for r in reqs]
-    ys = [torch.from_numpy(r[1]).to(dev) for r in reqs]
-    bs = [torch.from_numpy(r[2]).to(dev) for r in reqs]
-    acc = {"tok": 0, "frames": 0, "t_ar": 0.0, "t_voc": 0.0, "steps": 0, "kv_rows": 0, "mine": 0}
-    costs = [int(x.shape[0]) + int(y.shape[0]) + int(n) for x, y, n in zip(xs, ys, new_tok)] if a.lpt_budget else None
-
-    def vocode(tokens):
+    def vocode(self, tokens):
         """TTS.infer_batched's vocoder stage (TTS.py:705-764, tts.py): length-balanced order over ALL requests, time-concatenated
         batches of 10 with per-frame ge, batch b on rank b mod world; -> ({request: its samples (device)}, frames vocoded here)"""
         from gsv_tts_lite_amd.batchmath import balance_order
+        dev, voc, ge = self.dev, self.voc, self.ge
         lengths = torch.tensor([len(p) for p in tokens])
         order = balance_order(lengths)
         batches = [order[s:s + 10].tolist() for s in range(0, len(order), 10)]
         tot, audio = 0, {}
-        for b in eng.deal_batches(len(batches)):
+        for b in self.eng.deal_batches(len(batches)):
             T = int(sum(2 * int(lengths[i]) for i in batches[b]))
             if T == 0:
                 for i in batches[b]:
@@ -593,15 +651,16 @@ def run_cb(a):
             tot += T
         return audio, tot
 
-    def vocode_decode(tokens, vq):
+    def vocode_decode(self, tokens, vq):
         """the same batches through SynthesizerTrn.decode: the requests' own tokens and target phonemes, per-token ge, slice_indices
         (quantizer lookup + device enc_p + noise + flow + Generator in one library call) -- exactly TTS.infer_batched's call"""
         from gsv_tts_lite_amd.batchmath import balance_order
+        dev, xs, ge = self.dev, self.xs, self.ge
         lengths = torch.tensor([len(p) for p in tokens])
         order = balance_order(lengths)
         batches = [order[s:s + 10].tolist() for s in range(0, len(order), 10)]
         tot = 0
-        for b in eng.deal_batches(len(batches)):
+        for b in self.eng.deal_batches(len(batches)):
             oi = [i for i in batches[b] if int(lengths[i]) > 0]
             if not oi:
                 continue
@@ -615,93 +674,132 @@ def run_cb(a):
             tot += 2 * sum(ln)
         return tot
 
-    def vocode_batch(items):
+    def vocode_batch(self, items):
         """one time-concatenated vocoder batch (completion order): the overlapped engine calls this on its side stream"""
+        dev = self.dev
         T = int(sum(2 * len(p) for _, p in items))
         if T:
             z = torch.randn(1, 192, T, device=dev)
-            voc.flow_dec(z, torch.ones(1, 1, T, device=dev), ge.expand(-1, -1, T).contiguous())
+            self.voc.flow_dec(z, torch.ones(1, 1, T, device=dev), self.ge.expand(-1, -1, T).contiguous())
         return {i: 2 * len(p) for i, p in items}
 
-    def step(i, timed_idx):
+    def step(self, i, timed_idx):
+        a, dev, eng, acc, t2s = self.a, self.dev, self.eng, self.acc, self.t2s
         torch.cuda.synchronize(dev); s0 = time.perf_counter()
         if (not a.overlap):
-            pred, idx = eng.run_gpt(xs, ys, bs, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            pred, idx = eng.run_gpt(self.xs, self.ys, self.bs, costs=self.costs, top_k=1, max_new_tokens=self.new_tok, async_refill=not a.sync_refill)
             torch.cuda.synchronize(dev); s1 = time.perf_counter()
             # every rank learns every request's tokens (ids: a few hundred KB), vocodes the batches dealt to it, and the
             # samples meet on rank 0 -- what TTS.infer_batched does between its GPT and its return (tts.py)
-            tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, n_req, dst=None)
+            tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, self.n_req, dst=None)
             eng._retire_cursors(None)
-            audio, frames = vocode(tokens)
-            full = eng.exchange(audio, n_req, dst=0)
+            audio, frames = self.vocode(tokens)
+            full = eng.exchange(audio, self.n_req, dst=0)
             if timed_idx is not None and full is not None:
-                acc["gathered_samples"] = acc.get("gathered_samples", 0) + int(sum(t.numel() for t in full))
+                acc["gathered_samples"] += int(sum(t.numel() for t in full))
             del full, audio
         else:
-            res, pred, idx = eng.run_overlapped(xs, ys, bs, vocode_batch, batch=10, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            res, pred, idx = eng.run_overlapped(self.xs, self.ys, self.bs, self.vocode_batch, batch=10, costs=self.costs, top_k=1,
+                                                max_new_tokens=self.new_tok, async_refill=not a.sync_refill)
             s1 = time.perf_counter()
             frames = int(sum(res.values()))
         torch.cuda.synchronize(dev); s2 = time.perf_counter()
         if timed_idx is not None:
             acc["tok"] += int(sum(len(p) for p in pred)); acc["frames"] += frames
             acc["t_ar"] += s1 - s0; acc["t_voc"] += s2 - s1; acc["mine"] += len(pred)
-            acc["steps"] += t2s.last_stats["steps"]; acc["kv_rows"] += t2s.last_stats["kv_rows"]
+            acc["steps"] += t2s.last_stats["steps"]; acc["kv_rows"] += t2s.last_stats["kv_rows"]; acc["timed"] += 1
 
+    def record(self, elapsed, steps, warmup):
+        """every rank calls it (one all-reduce of the totals); -> the record (value = whole-job tokens/s over all ranks)"""
+        a, acc, world, dev, t2s = self.a, self.acc, self.world, self.dev, self.t2s
+        tot = torch.tensor([acc["tok"], acc["frames"], acc["mine"], acc["steps"] * self.slots], dtype=torch.float64, device=dev)
+        if self.dist is not None:
+            self.dist.all_reduce(tot)
+        tok_all, frames_all, slot_steps_all = float(tot[0]), float(tot[1]), float(tot[3])
+        assert int(tot[2]) == self.n_req * steps, "every request must have been served exactly once per step"
+        value = tok_all / elapsed
+        which = "configs[4]" if self.dtype_name == "fp8" else ("configs[2]" if world == 1 and self.version == "v2ProPlus" else "configs[3]")
+        out = {
+            "metric": "semantic_tokens_per_sec_end_to_end (GPT AR incl. prefill + flow/Generator vocoder); RTF^-1 = value/25",
+            "value": value, "unit": "semantic_tokens/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": self.dtype_name, "data": "synthetic (seeded random weights of the real architecture, synthetic phoneme/token ids)",
+            "config": {"workload": "%s: %s continuous batching, %d mixed-length requests per GPU per step through %d slots per GPU "
+                                   "(greedy, 50..400 new tokens per request), flow/Generator over every utterance in time-concatenated batches of 10"
+                                   % (which, self.version, self.requests, self.slots),
+                       "requests_per_step": self.n_req, "gpt_cache": [(self.slots, 512), (self.slots, 1024)],
+                       "refill": "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)" if a.sync_refill else
+                                 "staged: the prompt pass of a finished slot runs on a side stream, the slot joins at the next window after it",
+                       "queue_order": "longest first by prompt rows + token budget" if a.lpt_budget else "longest first by text length (the budgets are independent of it)",
+                       "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
+                                  "overlapped with the slot loop on a side stream, batches of 10 in completion order",
+                       "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "
+                                      "speaker (%d tensor broadcasts in this run)" % (world, self.book.broadcasts)},
+            "dist": dist_info(a, world, self.book),
+            "gather": None if a.overlap else "inside the timed step: token ids all-gathered (device), every request's samples sent to rank 0 "
+                                             "(device, point-to-point); %d samples arrived on rank 0 over the %d timed steps" % (acc["gathered_samples"], steps),
+            "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
+            "tokens_per_step": tok_all / steps, "mean_tokens_per_request": tok_all / steps / self.n_req,
+            "idle_slot_steps_frac": 1.0 - tok_all / max(slot_steps_all, 1.0),
+            "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"],
+            "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
+            "rank0_requests_served_per_step": acc["mine"] / steps,
+        }
+        if self.rank == 0:
+            # step-level roofline of the batched decode step on this rank: weights once per step + the K/V rows read
+            wbytes = GPT_PARAMS * 2
+            if self.dtype_name == "fp32":
+                wbytes = GPT_PARAMS * 4
+            if self.dtype_name == "fp8":   # QKV / W1 / W2 as e4m3 (+ fp32 scales); out-proj, predict layer bf16
+                wbytes = (24 * (3 * 512 * 512 + 2 * 2048 * 512) * 1 + 24 * 512 * 512 * 2 + 1025 * 512 * 2 + 0.16e6 * 4 + 24 * 4096 * 4)
+            by = acc["steps"] * wbytes + acc["kv_rows"] * KV_BYTES_PER_POS * self.sbytes
+            gbs = by / acc["t_ar"] / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": None,
+                               "kernel": ("batched decode step (5 launches per layer: GEMMs on 16 x 16 x 32 MFMA tiles + attention per (head, sequence), csrc/t2s_small.h)" if self.slots >= t2s.batched_min else
+                                          "decode step, 2 launches per layer with 2 / 4 sequences per block (csrc/t2s_decode_multi.h)" if self.slots > 16
+                                          else "decode step, 2 launches per layer (csrc/t2s_decode.h)"),
+                               "ms_per_step_of_the_slot_loop": acc["t_ar"] / max(1, acc["steps"]) * 1e3,
+                               "note": "algorithmic bytes of the AR phase = decode steps x weight bytes + K/V rows read x row bytes (prefills and "
+                                       "refills are inside the time, not in the bytes) / AR wall time of rank 0"}
+            vbytes, vflops = vocoder_algorithmic(self.version, 4 if self.dtype_name == "fp32" else 2)
+            if acc["frames"] and (not a.overlap):
+                g = vbytes * acc["frames"] / acc["t_voc"] / 1e9
+                out["roofline_vocoder"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
+                                           "traffic": None, "mfma_tflops": vflops * acc["frames"] / acc["t_voc"] / 1e12}
+        return out
+
+
+def run_cb(a):
+    world, rank, dev, dist = setup_dist(a)
+    from gsv_tts_lite_amd import synth
+    w = CBWorkload(a, world, rank, dev, dist, a.version, a.dtype, a.slots, a.requests)
     log("models ready")
-    elapsed = timed_region(a.steps, a.warmup, step, dev, dist)
+    elapsed = timed_region(a.steps, a.warmup, w.step, dev, dist)
     log("timed region done: %.3f s" % elapsed)
-    tot = torch.tensor([acc["tok"], acc["frames"], acc["mine"]], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tot)
-    tok_all, frames_all = float(tot[0]), float(tot[1])
-    assert int(tot[2]) == n_req * a.steps, "every request must have been served exactly once per step"
-    value = tok_all / elapsed
-    which = "configs[4]" if a.dtype == "fp8" else ("configs[2]" if world == 1 and a.version == "v2ProPlus" else "configs[3]")
-    out = {
-        "metric": "semantic_tokens_per_sec_end_to_end (GPT AR incl. prefill + flow/Generator vocoder); RTF^-1 = value/25",
-        "value": value, "unit": "semantic_tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic (seeded random weights of the real architecture, synthetic phoneme/token ids)",
-        "config": {"workload": "%s: %s continuous batching, %d mixed-length requests per GPU per step through %d slots per GPU "
-                               "(greedy, 50..400 new tokens per request), flow/Generator over every utterance in time-concatenated batches of 10"
-                               % (which, a.version, a.requests, a.slots),
-                   "requests_per_step": n_req, "gpt_cache": [(a.slots, 512), (a.slots, 1024)],
-                   "refill": "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)" if a.sync_refill else
-                             "staged: the prompt pass of a finished slot runs on a side stream, the slot joins at the next window after it",
-                   "queue_order": "longest first by prompt rows + token budget" if a.lpt_budget else "longest first by text length (the budgets are independent of it)",
-                   "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
-                              "overlapped with the slot loop on a side stream, batches of 10 in completion order",
-                   "parallelism": "one engine per GPU x%d, requests pulled on demand from a shared cursor, ge broadcast once per "
-                                  "speaker (%d tensor broadcasts in this run)" % (world, book.broadcasts)},
-        "dist": dist_info(a, world, book),
-        "gather": None if a.overlap else "inside the timed step: token ids all-gathered (device), every request's samples sent to rank 0 "
-                                         "(device, point-to-point); %d samples arrived on rank 0 over the %d timed steps" % (acc.get("gathered_samples", 0), a.steps),
-        "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
-        "tokens_per_step": tok_all / a.steps, "mean_tokens_per_request": tok_all / a.steps / n_req,
-        "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"],
-        "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
-        "rank0_requests_served_per_step": acc["mine"] / a.steps,
-    }
+    out = w.record(elapsed, a.steps, a.warmup)
+    value = out["value"]
+    t2s, eng, xs, ys, bs, n_req = w.t2s, w.eng, w.xs, w.ys, w.bs, w.n_req
     if (not a.no_extras) and (not a.overlap):
         # one more pass over the queue with the vocoder stage as TTS.infer_batched runs it: decode() on the requests' own tokens
         # (every rank takes part: the token exchange is a collective)
         try:
             from gsv_tts_lite_amd.sovits import SynthesizerTrn
-            vq = SynthesizerTrn(1025, 32, n_speakers=300, **hps["model"])
-            vq.load_state_dict(synth.sovits_weights(hps, seed=1234))
-            vq.initialize_runtime(vdtype, dev, [])
+            vq = SynthesizerTrn(1025, 32, n_speakers=300, **w.hps["model"])
+            vq.load_state_dict(synth.sovits_weights(w.hps, seed=1234))
+            vq.initialize_runtime(w.vdtype, dev, [])
             # untimed: one batch through decode() (workspace allocation, kernel attributes, code load)
             wl = [50 + 17 * i for i in range(10)]
             vq.decode(torch.zeros(1, 1, sum(wl), dtype=torch.int64, device=dev), torch.cat([xs[i][40:] for i in range(10)])[None],
-                      ge.expand(-1, -1, sum(wl)), noise_scale=0.5, cuda_graph=False)
+                      w.ge.expand(-1, -1, sum(wl)), noise_scale=0.5, cuda_graph=False)
             torch.cuda.synchronize(dev)
             if dist is not None:
                 dist.barrier()
             q0 = time.perf_counter()
-            pred, idx = eng.run_gpt(xs, ys, bs, costs=costs, top_k=1, max_new_tokens=new_tok, async_refill=not a.sync_refill)
+            pred, idx = eng.run_gpt(xs, ys, bs, costs=w.costs, top_k=1, max_new_tokens=w.new_tok, async_refill=not a.sync_refill)
             tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, n_req, dst=None)
             eng._retire_cursors(None)
-            vocode_decode(tokens, vq)
+            w.vocode_decode(tokens, vq)
             torch.cuda.synchronize(dev)
             from gsv_tts_lite_amd import scheduler
             dt = scheduler.max_over_ranks(time.perf_counter() - q0, device=dev)
@@ -731,27 +829,6 @@ def run_cb(a):
             out["ttft_ms_p50_first_batch"] = None
             log("first-batch TTFT failed: %r" % (e,))
     if rank == 0:
-        # step-level roofline of the batched decode step on this rank: weights once per step + the K/V rows read
-        wbytes = GPT_PARAMS * 2
-        if a.dtype == "fp32":
-            wbytes = GPT_PARAMS * 4
-        if a.dtype == "fp8":   # QKV / W1 / W2 as e4m3 (+ fp32 scales); out-proj, predict layer bf16
-            wbytes = (24 * (3 * 512 * 512 + 2 * 2048 * 512) * 1 + 24 * 512 * 512 * 2 + 1025 * 512 * 2 + 0.16e6 * 4 + 24 * 4096 * 4)
-        by = acc["steps"] * wbytes + acc["kv_rows"] * KV_BYTES_PER_POS * sbytes
-        gbs = by / acc["t_ar"] / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": None,
-                           "kernel": ("batched decode step (5 launches per layer: GEMMs on 16 x 16 x 32 MFMA tiles + attention per (head, sequence), csrc/t2s_small.h)" if a.slots >= t2s.batched_min else
-                                      "decode step, 2 launches per layer with 2 / 4 sequences per block (csrc/t2s_decode_multi.h)" if a.slots > 16
-                                      else "decode step, 2 launches per layer (csrc/t2s_decode.h)"),
-                           "ms_per_step_of_the_slot_loop": acc["t_ar"] / max(1, acc["steps"]) * 1e3,
-                           "note": "algorithmic bytes of the AR phase = decode steps x weight bytes + K/V rows read x row bytes (prefills and "
-                                   "refills are inside the time, not in the bytes) / AR wall time of rank 0"}
-        vbytes, vflops = vocoder_algorithmic(a.version, 4 if a.dtype == "fp32" else 2)
-        if acc["frames"] and (not a.overlap):
-            g = vbytes * acc["frames"] / acc["t_voc"] / 1e9
-            out["roofline_vocoder"] = {"bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                                       "traffic": None, "mfma_tflops": vflops * acc["frames"] / acc["t_voc"] / 1e12}
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (subprocess) ...")
             cb = cpu_baseline("cb", a.version)

@@ -37,6 +37,7 @@ static hipError_t amalloc(void** p, size_t n) {
     static const size_t skew = getenv("GSV_ARENA_SKEW") ? (size_t)atol(getenv("GSV_ARENA_SKEW")) : 0;
     constexpr size_t kBlock = (size_t)256 << 20;
     Arena& a = *g_cur;
+    bool reuse = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = a.freed.lower_bound(n);        // smallest given-back piece that fits, if it is not wastefully large
@@ -44,8 +45,14 @@ static hipError_t amalloc(void** p, size_t n) {
             *p = it->second;
             a.live[*p] = it->first;
             a.freed.erase(it);
-            return hipSuccess;
+            reuse = true;
         }
+    }
+    if (reuse) {
+        // kernels or graph replays on ANY stream (the side refill stream's staging, a hot-swapped conv) may still read the
+        // piece's old contents: hipFree would have synchronised the device before the address could come back, so does this
+        // (re-bind / re-load only: never on a step's path)
+        return hipDeviceSynchronize();
     }
     const size_t sk = (a.count * skew) % align;
     size_t start = (a.used + align - 1) / align * align + sk;

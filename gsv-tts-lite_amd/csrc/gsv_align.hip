@@ -3,6 +3,7 @@
 
 #include "../../include/gsv_tts_hip.h"
 #include "align.h"
+#include "sola.h"
 #include "gsv_error.h"
 
 using namespace gsv;
@@ -77,6 +78,27 @@ int gsv_align_viterbi(const float* attn, int H, int T, int N, int32_t* assign, v
         else e = launch_dp<1024, 4>(p, normal, flag, T, N, assign, bits, st);
     }
     if (e != hipSuccess) return abi_fail(GSV_ERR_HIP, "align launch: %s", hipGetErrorString(e));
+    return GSV_OK;
+}
+
+
+// ---- streaming splice (sola.h)
+size_t gsv_sola_workspace(int search_len) { return search_len < 0 ? 0 : ((size_t)(search_len + 1) * sizeof(float) + 255) / 256 * 256; }
+
+int gsv_sola(const float* prev_tail, const float* chunk, int n, int overlap, int search_len, float* out, int32_t* offset,
+             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!prev_tail || !chunk || !out || !offset || !workspace) return abi_fail(GSV_ERR_ARG, "sola: null argument");
+    if (overlap < 1 || search_len < 0 || n < overlap) return abi_fail(GSV_ERR_ARG, "sola: chunk of %d samples, overlap %d, search %d", n, overlap, search_len);
+    // TTS.py:1614: key = f2[:, :, :overlap + search] -- a chunk shorter than that offers fewer candidate offsets
+    const int n_off = (n < overlap + search_len ? n : overlap + search_len) - overlap + 1;
+    if (workspace_bytes < (size_t)n_off * sizeof(float)) return abi_fail(GSV_ERR_ARG, "sola workspace %zu < %zu", workspace_bytes, (size_t)n_off * sizeof(float));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* score = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(sola_score_kernel, dim3(n_off), dim3(256), 0, st, prev_tail, chunk, overlap, score);
+    const int blocks = (n + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(sola_splice_kernel, dim3(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks)), dim3(256), 0, st, prev_tail, chunk, n, overlap,
+                       (const float*)score, n_off, out, offset);
+    if (hipGetLastError() != hipSuccess) return abi_fail(GSV_ERR_HIP, "sola: launch failed");
     return GSV_OK;
 }
 

@@ -69,7 +69,9 @@ struct gsv_voc {
             return std::tie(z, m, g, o, w, T, Tg) < std::tie(r.z, r.m, r.g, r.o, r.w, r.T, r.Tg);
         }
     };
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; };
+    std::map<GraphKey, GraphEntry> graphs;      // at most GSV_VOC_MAX_GRAPHS; the least recently replayed one makes room
+    unsigned long long graph_clock = 0;
     hipStream_t cap_stream = nullptr;
 };
 
@@ -890,7 +892,7 @@ int gsv_voc_create(const gsv_voc_config* cfg, gsv_voc** out) {
 int gsv_voc_destroy(gsv_voc* v) {
     if (!v) return GSV_OK;
     (void)hipDeviceSynchronize();
-    for (auto& kv : v->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : v->graphs) (void)hipGraphExecDestroy(kv.second.exec);
     if (v->cap_stream) (void)hipStreamDestroy(v->cap_stream);
     voc_free(v);
     delete v;
@@ -956,7 +958,14 @@ int gsv_voc_flow_dec_graph(gsv_voc* v, const float* z_p, const float* y_mask, co
     const gsv_voc::GraphKey key{z_p, y_mask, ge, out, workspace, T, Tg};
     auto it = v->graphs.find(key);
     if (it == v->graphs.end()) {
-        if (v->graphs.size() >= 64) return fail(GSV_ERR_STATE, "too many captured vocoder passes (64): reuse the static buffers of a bucket");
+        if (v->graphs.size() >= GSV_VOC_MAX_GRAPHS) {      // a long-lived server sees new (workspace, T) pairs for ever: evict, never fail
+            auto old = v->graphs.begin();
+            for (auto jt = v->graphs.begin(); jt != v->graphs.end(); ++jt)
+                if (jt->second.last_use < old->second.last_use) old = jt;
+            HIPCHK(hipStreamSynchronize(S(stream)));       // its last replay was enqueued on the caller's stream
+            (void)hipGraphExecDestroy(old->second.exec);
+            v->graphs.erase(old);
+        }
         if (!v->cap_stream && hipStreamCreateWithFlags(&v->cap_stream, hipStreamNonBlocking) != hipSuccess)
             return fail(GSV_ERR_HIP, "hipStreamCreate failed");
         // an eager pass first: it sets every kernel's dynamic-LDS attribute outside the capture and validates the arguments
@@ -972,9 +981,10 @@ int gsv_voc_flow_dec_graph(gsv_voc* v, const float* z_p, const float* y_mask, co
         e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-        it = v->graphs.emplace(key, exec).first;
+        it = v->graphs.emplace(key, gsv_voc::GraphEntry{exec, 0}).first;
     }
-    HIPCHK(hipGraphLaunch(it->second, S(stream)));
+    it->second.last_use = ++v->graph_clock;
+    HIPCHK(hipGraphLaunch(it->second.exec, S(stream)));
     return GSV_OK;
 }
 
@@ -1095,22 +1105,25 @@ DecWs dec_layout(gsv_voc* v, int n_codes, int P, int Tg, int Tp, int T_out, char
     return w;
 }
 
-inline int dec_lengths(int n_codes, float speed, int valid_start, int* Tp, int* T_out) {
+// The frame count after the speed change, int(Tp / speed) + 1 (models.py:217), is the CALLER's: it sized `out` with it in its
+// own arithmetic (Python doubles in the reference), and a second evaluation here in another precision disagrees in ~1.4 % of
+// (Tp, speed) pairs -- one hop written past the buffer or left unwritten.  out_frames == Tp means no resampling.
+inline int dec_lengths(int n_codes, int out_frames, int valid_start, int* Tp, int* T_out) {
     const int T = 2 * n_codes;
     *Tp = T - valid_start;
-    *T_out = speed == 1.0f ? *Tp : (int)((float)*Tp / speed) + 1;      // models.py:217: int(T / speed) + 1
+    *T_out = out_frames;
     return *Tp >= 1 && *T_out >= 1;
 }
 
 template <typename AT>
 int voc_decode_impl(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int P, const float* ge, int Tg, const int64_t* slice,
-                    float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len, float* overlap_state,
+                    float noise_scale, unsigned long long seed, int out_frames, int valid_start, int overlap_len, float* overlap_state,
                     int has_overlap, int use_graph, float* out, float* attn, void* ws, size_t ws_bytes, hipStream_t st) {
     const gsv_voc_config& c = v->cfg;
     const int C = c.inter_channels, gin = c.gin_channels, T = 2 * n_codes;
     const bool stream = overlap_len > 0;
     int Tp, T_out;
-    if (!dec_lengths(n_codes, speed, valid_start, &Tp, &T_out)) return fail(GSV_ERR_ARG, "decode: nothing left after valid_start %d", valid_start);
+    if (!dec_lengths(n_codes, out_frames, valid_start, &Tp, &T_out)) return fail(GSV_ERR_ARG, "decode: nothing left after valid_start %d", valid_start);
     if (stream && (Tg != 1 || !overlap_state || overlap_len > Tp)) return fail(GSV_ERR_ARG, "decode: streaming needs a broadcast ge, a state buffer and overlap_len <= frames");
     DecWs w = dec_layout(v, n_codes, P, Tg, Tp, T_out, (char*)ws);
     if (ws_bytes < w.bytes) return fail(GSV_ERR_ARG, "decode workspace %zu < %zu", ws_bytes, w.bytes);
@@ -1160,26 +1173,26 @@ int voc_decode_impl(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t
 
 extern "C" {
 
-size_t gsv_voc_decode_workspace(gsv_voc* v, int n_codes, int n_text, int Tg, float speed, int valid_start) {
-    if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || !(speed > 0.f) || valid_start < 0) return 0;
+size_t gsv_voc_decode_workspace(gsv_voc* v, int n_codes, int n_text, int Tg, int out_frames, int valid_start) {
+    if (!v || !v->finalized || !v->enc.ready || n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || out_frames < 1 || valid_start < 0) return 0;
     int Tp, T_out;
-    if (!dec_lengths(n_codes, speed, valid_start, &Tp, &T_out)) return 0;
+    if (!dec_lengths(n_codes, out_frames, valid_start, &Tp, &T_out)) return 0;
     return dec_layout(v, n_codes, n_text, Tg, Tp, T_out, nullptr).bytes;
 }
 
 int gsv_voc_decode(gsv_voc* v, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge, int Tg,
-                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len,
+                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, int out_frames, int valid_start, int overlap_len,
                    float* overlap_state, int has_overlap, int use_graph, float* out, float* attn, void* workspace, size_t workspace_bytes,
                    void* stream) {
     if (!v || !v->finalized) return fail(GSV_ERR_STATE, "vocoder not finalized");
     if (!v->enc.ready) return fail(GSV_ERR_STATE, "decode() needs the enc_p / quantizer tensors");
     if (!codes || !text || !ge || !out || !workspace) return fail(GSV_ERR_ARG, "null argument");
-    if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || !(speed > 0.f) || valid_start < 0 || overlap_len < 0)
+    if (n_codes < 1 || n_text < 1 || (Tg != 1 && Tg != n_codes) || out_frames < 1 || valid_start < 0 || overlap_len < 0)
         return fail(GSV_ERR_ARG, "decode: bad lengths");
     return v->cfg.dtype == GSV_BF16
-               ? voc_decode_impl<bf16_t>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, speed, valid_start, overlap_len,
+               ? voc_decode_impl<bf16_t>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, out_frames, valid_start, overlap_len,
                                          overlap_state, has_overlap, use_graph, out, attn, workspace, workspace_bytes, S(stream))
-               : voc_decode_impl<float>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, speed, valid_start, overlap_len,
+               : voc_decode_impl<float>(v, codes, n_codes, text, n_text, ge, Tg, slice_indices, noise_scale, seed, out_frames, valid_start, overlap_len,
                                         overlap_state, has_overlap, use_graph, out, attn, workspace, workspace_bytes, S(stream));
 }
 

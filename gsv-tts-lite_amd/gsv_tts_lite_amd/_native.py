@@ -22,7 +22,7 @@ EXPORTS = [
     "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min", "gsv_t2s_ffn_slices", "gsv_t2s_device_bytes",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow_dec_graph", "gsv_voc_resample_linear", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p", "gsv_voc_decode_workspace", "gsv_voc_decode",
-    "gsv_align_workspace", "gsv_align_viterbi",
+    "gsv_align_workspace", "gsv_align_viterbi", "gsv_sola_workspace", "gsv_sola",
     "gsv_ref_create", "gsv_ref_destroy", "gsv_ref_load_tensor", "gsv_ref_finalize", "gsv_ref_workspace",
     "gsv_ref_spectrogram", "gsv_ref_get_ge", "gsv_ref_extract_latent",
 ]
@@ -97,8 +97,9 @@ def lib():
         "gsv_voc_dec": [vp, vp, vp, i, i, vp, vp, sz, vp],
         "gsv_voc_has_enc_p": [vp],
         "gsv_voc_enc_p": [vp, vp, i, vp, i, vp, i, vp, vp, vp, vp, vp, sz, vp],
-        "gsv_voc_decode": [vp, vp, i, vp, i, vp, i, vp, ctypes.c_float, ctypes.c_uint64, ctypes.c_float, i, i, vp, i, i, vp, vp, vp, sz, vp],
+        "gsv_voc_decode": [vp, vp, i, vp, i, vp, i, vp, ctypes.c_float, ctypes.c_uint64, i, i, i, vp, i, i, vp, vp, vp, sz, vp],
         "gsv_align_viterbi": [vp, i, i, i, vp, vp, sz, vp],
+        "gsv_sola": [vp, vp, i, i, i, vp, vp, vp, sz, vp],
         "gsv_ref_create": [ctypes.POINTER(RefConfig), ctypes.POINTER(vp)],
         "gsv_ref_destroy": [vp],
         "gsv_ref_load_tensor": [vp, ctypes.c_char_p, vp, i64, vp],
@@ -119,12 +120,14 @@ def lib():
     L.gsv_voc_workspace.restype = sz
     L.gsv_voc_enc_workspace.argtypes = [vp, i, i]
     L.gsv_voc_enc_workspace.restype = sz
-    L.gsv_voc_decode_workspace.argtypes = [vp, i, i, i, ctypes.c_float, i]
+    L.gsv_voc_decode_workspace.argtypes = [vp, i, i, i, i, i]
     L.gsv_voc_decode_workspace.restype = sz
     L.gsv_ref_workspace.argtypes = [vp, i, i, i]
     L.gsv_ref_workspace.restype = sz
     L.gsv_align_workspace.argtypes = [i, i]
     L.gsv_align_workspace.restype = sz
+    L.gsv_sola_workspace.argtypes = [i]
+    L.gsv_sola_workspace.restype = sz
     _LIB = L
     return L
 

@@ -15,8 +15,10 @@ slot loop over ITS slots, and the only shared thing is the head of the queue.
   * speakers  `ge`, prompt tokens, prompt phonemes / BERT features exist only on the rank that ran the
               reference-audio models.  `SpeakerBook.sync` broadcasts them ONCE per new key over RCCL/xGMI
               (a few hundred KB, latency-bound) and every later request with that key is a dictionary hit.
-  * gather    per-utterance results (token ids, audio) are variable-length host objects: `all_gather_object`
-              keyed by the GLOBAL request index (`semantic_orig_idx` semantics kept globally).
+  * exchange  per-utterance results (token ids, audio samples) are variable-length DEVICE tensors keyed by the GLOBAL request
+              index (`semantic_orig_idx` semantics kept globally): one all-reduce of a length / owner table, then one
+              concatenated buffer per rank -- a padded all-gather (every rank wants them) or point-to-point to one rank
+              (`exchange`).  Nothing is pickled; `gather` remains for small host objects only.
 
 Decoding is placement-invariant: rows are independent through every kernel, and device sampling draws a request's noise
 from the REQUEST's stream (t2s.py puts request index + 1 into tok_override, gsv_tts_hip.h), not from its slot's.  N ranks
@@ -34,8 +36,14 @@ import torch
 import torch.distributed as dist
 
 
+# GSV_FORCE_COLLECTIVES=1 (or engine.FORCE_COLLECTIVES = True): an initialised process group of ONE rank still goes through the
+# backend -- the store cursor, the broadcasts, the all-reduce / all-gather of `exchange` -- instead of the single-process short
+# cuts.  A 1-GPU box proves with it that RCCL initialises and runs every collective this path issues (tests/test_hip_rccl.py).
+FORCE_COLLECTIVES = os.environ.get("GSV_FORCE_COLLECTIVES") == "1"
+
+
 def _dist_on(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
 
 
 # ----------------------------------------------------------------------------------------------- dealing
@@ -134,7 +142,7 @@ class ContinuousBatchingEngine:
     def _source(self, costs: Sequence[float]) -> RequestSource:
         order = lpt_order(costs)
         run = next(_RUN_COUNTER)        # SPMD: every rank makes the same sequence of runs -> the same key
-        if self.world == 1:
+        if self.world == 1 and not (FORCE_COLLECTIVES and self.store is not None):
             return RequestSource(order, None, chunk=len(order) or 1)
         if self.store is None:          # no store: static length-balanced partition (scheduler.shard_indices)
             from .scheduler import shard_indices
@@ -206,7 +214,7 @@ class ContinuousBatchingEngine:
     def gather(self, local: Dict[int, object], n_total: int, dst: Optional[int] = 0) -> Optional[List[object]]:
         """index -> (small, picklable) payload of this rank  =>  the full list in global index order on rank `dst` (None on
         the other ranks), or on every rank with dst=None.  Tensors go through `exchange`, not through here."""
-        if self.world == 1:
+        if self.world == 1 and not _dist_on(self.group):
             parts = [local]
         elif dst is None:
             parts = [None] * self.world
@@ -243,7 +251,7 @@ class ContinuousBatchingEngine:
         for i in local:
             if not 0 <= int(i) < n_total:
                 raise RuntimeError("exchange: request index %r outside [0, %d)" % (i, n_total))
-        if self.world == 1:
+        if self.world == 1 and not _dist_on(self.group):
             if len(local) != n_total:
                 raise RuntimeError("exchange: %d of %d requests present" % (len(local), n_total))
             return [local[i] for i in range(n_total)]

@@ -60,7 +60,8 @@ def gather_objects(local, dst: int = 0, group=None):
 
 
 def max_over_ranks(seconds: float, device=None, group=None) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    from .engine import _dist_on          # one rank goes through the backend too under GSV_FORCE_COLLECTIVES (engine.py)
+    if not _dist_on(group):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)

@@ -168,25 +168,29 @@ class _VocoderNative:
                                 self._ews.data_ptr(), self._ews.numel(), N.current_stream_ptr(self.device)))
         return m_p, logs_p, attn
 
-    def decode(self, codes, text, ge, slice_indices, noise_scale, seed, speed, valid_start, overlap_len, overlap_state,
+    def decode(self, codes, text, ge, slice_indices, noise_scale, seed, T_out, valid_start, overlap_len, overlap_state,
                has_overlap, bucket):
         """gsv_voc_decode: codes int64 [n], text int64 [P], ge fp32 [gin, Tg] (Tg = 1 or n) -> (audio [1, 1, T_out * hop],
-        attn [4, 2n, P]).  `bucket`: replay flow + Generator from the hipGraph of this chunk length (its own workspace)."""
+        attn [4, 2n, P]).  `T_out`: the frame count after the speed change, evaluated ONCE by the caller (models.py:217) -- it
+        sizes `out` here and is what the library resamples to.  `bucket`: replay flow + Generator from the hipGraph of this
+        chunk length (its own workspace)."""
         L = N.lib()
         n, P, Tg = int(codes.numel()), int(text.numel()), int(ge.shape[-1])
-        Tp = 2 * n - valid_start
-        T_out = Tp if speed == 1 else int(Tp / speed) + 1
-        need = L.gsv_voc_decode_workspace(self._h, n, P, Tg, float(speed), int(valid_start))
+        T_out = int(T_out)
+        need = L.gsv_voc_decode_workspace(self._h, n, P, Tg, T_out, int(valid_start))
         if need == 0:
-            raise RuntimeError("gsv_voc_decode_workspace failed (n_codes %d, n_text %d, Tg %d, speed %g, valid_start %d)" % (n, P, Tg, speed, valid_start))
+            raise RuntimeError("gsv_voc_decode_workspace failed (n_codes %d, n_text %d, Tg %d, out_frames %d, valid_start %d)" % (n, P, Tg, T_out, valid_start))
         if bucket:
             if not hasattr(self, "_dws_bucket"):
                 self._dws_bucket = {}
-            key = (n, Tg, valid_start, float(speed))
-            ws = self._dws_bucket.get(key)
+            key = (n, Tg, valid_start, T_out)
+            ws = self._dws_bucket.pop(key, None)
             if ws is None or ws.numel() < need:     # sized for longer texts than this one: a regrown workspace is a re-captured graph
-                ws = self._dws_bucket[key] = torch.empty(max(need, L.gsv_voc_decode_workspace(self._h, n, max(P, 384), Tg, float(speed), int(valid_start))),
-                                                         dtype=torch.uint8, device=self.device)
+                ws = torch.empty(max(need, L.gsv_voc_decode_workspace(self._h, n, max(P, 384), Tg, T_out, int(valid_start))),
+                                 dtype=torch.uint8, device=self.device)
+            self._dws_bucket[key] = ws              # most recently used last; the library evicts graphs the same way
+            while len(self._dws_bucket) > 32:
+                self._dws_bucket.pop(next(iter(self._dws_bucket)))
         else:
             if getattr(self, "_dws", None) is None or self._dws.numel() < need:
                 self._dws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -195,7 +199,7 @@ class _VocoderNative:
         attn = torch.empty(4, 2 * n, P, dtype=torch.float32, device=self.device)
         N.check(L.gsv_voc_decode(self._h, codes.data_ptr(), n, text.data_ptr(), P, ge.data_ptr(), Tg,
                                  0 if slice_indices is None else slice_indices.data_ptr(), float(noise_scale), int(seed) & (2 ** 64 - 1),
-                                 float(speed), int(valid_start), int(overlap_len), 0 if overlap_state is None else overlap_state.data_ptr(),
+                                 T_out, int(valid_start), int(overlap_len), 0 if overlap_state is None else overlap_state.data_ptr(),
                                  1 if has_overlap else 0, 1 if bucket else 0, out.data_ptr(), attn.data_ptr(), ws.data_ptr(), ws.numel(),
                                  N.current_stream_ptr(self.device)))
         return out, attn
@@ -249,7 +253,6 @@ class SynthesizerTrn:
         self._voc = None
         self.enc_p = None
         self._ref = None
-        self._noise_calls = 0
 
     def load_state_dict(self, sd, strict=False):
         self._weights = {k: (torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v)
@@ -325,11 +328,11 @@ class SynthesizerTrn:
         sl = None if slice_indices is None else slice_indices.to(device=dev, dtype=torch.int64).contiguous()
         seed = 0
         if noise_scale != 0:
-            if generator is not None:     # a replayable stream per generator seed: call k of a run draws from seed + k
-                seed = (int(generator.initial_seed()) * 0x9E3779B97F4A7C15 + self._noise_calls) & (2 ** 64 - 1)
-                self._noise_calls += 1
-            else:
-                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            # the 64-bit seed of this call's noise stream is DRAWN from the generator (torch's default CPU generator without one),
+            # as the reference's torch.randn_like draws from it (models.py:404): the generator's state advances per call, and
+            # re-seeding it replays the same sequence of calls
+            gdev = torch.device("cpu") if generator is None else generator.device
+            seed = int(torch.empty((), dtype=torch.int64, device=gdev).random_(generator=generator).item()) & (2 ** 64 - 1)
         start, ov, state, has = 0, 0, None, False
         if stream_mode:
             start, ov = int(valid_start_idx), int(overlap_len)
@@ -339,6 +342,6 @@ class SynthesizerTrn:
             self.enc_p.y_overlap = state          # updated in place by the call: the tail of this chunk's statistics
         T_out = 2 * n - start if speed == 1 else int((2 * n - start) / speed) + 1
         bucket = bool(cuda_graph) and T_out in self.cuda_graph_buckets and ge.shape[-1] == 1
-        o, attn = self._voc.decode(codes, text, ge, sl, noise_scale, seed, float(speed), start, ov, state, has, bucket)
+        o, attn = self._voc.decode(codes, text, ge, sl, noise_scale, seed, T_out, start, ov, state, has, bucket)
         self.enc_p.mrte.cross_attention.attn = attn[None]
         return o, attn

@@ -192,7 +192,7 @@ class Text2SemanticDecoder:
             N.check(L.gsv_t2s_load_tensor(h, name.encode(), d.data_ptr(), d.numel(), stream))
         N.check(L.gsv_t2s_finalize(h, stream))
         self.batched_min = int(L.gsv_t2s_batched_min(h))   # batch size from which the step is the batched MFMA chain
-        self.ffn_slices = lambda bsz: int(L.gsv_t2s_ffn_slices(h, int(bsz)))   # FFN slices per sequence below it (part of the bf16 arithmetic)
+        self.ffn_slices = lambda bsz: int(N.lib().gsv_t2s_ffn_slices(self._h, int(bsz)))   # FFN slices per sequence below it (part of the bf16 arithmetic)
 
         for batch_size, max_kv in gpt_cache:
             self.cuda_graph_buckets.setdefault(batch_size, [])

@@ -36,6 +36,7 @@ import torch
 
 from . import subtitles as sub
 from .batchmath import balance_order, split_bounds
+from .stream import ChunkSplicer
 from .loader import Gpt, Sovits, convert_to_safetensors, get_gpt_weights, get_sovits_weights
 
 log = logging.getLogger("gsv_tts_lite_amd")
@@ -498,18 +499,10 @@ class TTS:
             raise failure[0]
 
     def _sola_algorithm(self, f1_overlap, f2, overlap_len, search_len: int = 320):
-        """TTS.py:1612-1627: align the new chunk to the previous chunk's tail by normalised cross-correlation
-        over `search_len` offsets, then cross-fade `overlap_len` samples."""
-        import torch.nn.functional as F
-        query = f1_overlap
-        key = f2[:, :, :overlap_len + search_len]
-        corr = F.conv1d(key, query)
-        energy = F.conv1d(key ** 2, torch.ones_like(query)) + 1e-8
-        offset = (corr / torch.sqrt(energy)).argmax(dim=-1)
-        f2_aligned = f2[:, :, int(offset.item()):]
-        alpha = torch.linspace(0, 1, overlap_len, device=f2.device, dtype=f2.dtype).view(1, 1, -1)
-        faded = f1_overlap * (1 - alpha) + f2_aligned[:, :, :overlap_len] * alpha
-        return torch.cat([faded, f2_aligned[:, :, overlap_len:]], dim=-1), offset
+        """TTS.py:1612-1627, kept by name for callers of the reference's method: one library call (stream.sola -> gsv_sola)."""
+        from .stream import sola
+        out, k = sola(f1_overlap.reshape(-1)[-overlap_len:], f2.reshape(-1), search_len)
+        return out.reshape(1, 1, -1), torch.tensor([[k]], device=f2.device)
 
     def infer_stream(self, spk_audio_path, prompt_audio_path, prompt_audio_text, text, return_subtitles=False,
                      is_cut_text=True, cut_minlen=10, cut_mute=0.4,
@@ -549,21 +542,17 @@ class TTS:
                     ids = torch.tensor(phones1 + phones2, dtype=torch.int64, device=dev).unsqueeze(0)
                     bert = torch.cat([bert1, bert2]).unsqueeze(0)
                     phones2_t = torch.tensor(phones2, dtype=torch.int64, device=dev).unsqueeze(0)
-                    last_overlap_audio, valid_start_idx, chunk_idx, last_subtitles_end = None, 0, 0, 0
+                    splicer, valid_start_idx, chunk_idx, last_subtitles_end = ChunkSplicer(overlap_samples), 0, 0, 0
                     for pred, is_final in t2s.infer_stream(ids, prompt, bert, top_k=top_k, top_p=top_p, temperature=temperature,
                                                            repetition_penalty=repetition_penalty, stream_chunk=stream_chunk,
                                                            boost_first_chunk=boost_first_chunk if i == 0 else False, debug=debug):
                         with torch.inference_mode():
                             audio, attn = vq.decode(pred, phones2_t, ge, noise_scale=noise_scale, speed=speed, stream_mode=True,
                                                     valid_start_idx=valid_start_idx, overlap_len=overlap_len)
-                            if last_overlap_audio is not None:
-                                audio, _ = self._sola_algorithm(last_overlap_audio, audio, overlap_samples)
-                            last_overlap_audio = audio[:, :, -overlap_samples:].clone()
+                            audio = splicer.push(audio, is_final)     # aligned to the previous chunk's tail, its own tail kept back
                             if not is_final:
-                                audio = audio[:, :, :-overlap_samples]
                                 attn = attn[:, :-overlap_len, :]
                                 valid_start_idx = attn.shape[1]
-                            audio = audio[0, 0, :]
                             subtitles = []
                             if return_subtitles:   # TTS.py:444-451: a chunk whose path is mostly single frames is not trusted yet
                                 assign = sub.viterbi_monotonic(attn)

@@ -261,16 +261,19 @@ int gsv_voc_enc_p(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* 
  *     x2 nearest upsampling of models.py:389 and the nearest resize of :402 are index maps inside);
  *   ge_to512 (v2Pro / v2ProPlus, :394), quantizer lookup + x2 upsampling + TextEncoder.infer (enc_p, :395-400; slice_indices as
  *     for gsv_voc_enc_p), streaming slice + cross-fade (valid_start, overlap_len > 0, overlap_state fp32 [2*inter][overlap_len]
- *     in/out, has_overlap = 0 on a stream's first chunk; module/models.py:209-215), speed resampling to int(T / speed) + 1 frames
- *     (:217-219), z_p = m_p + N(0,1) * exp(logs_p) * noise_scale (:404), flow + Generator (:380-383).
+ *     in/out, has_overlap = 0 on a stream's first chunk; module/models.py:209-215), speed resampling to `out_frames` frames
+ *     (:217-219: the caller evaluates int(T' / speed) + 1 ONCE, in the arithmetic it sizes `out` with -- Python doubles in the
+ *     reference -- and passes the result; out_frames == T' means speed 1, no resampling), z_p = m_p + N(0,1) * exp(logs_p) * noise_scale (:404), flow + Generator (:380-383).
  *   The noise is counter-based (lowbias32 of the element index and `seed`, Box-Muller): a call is replayable from its seed; it is
  *   not torch's generator stream.  use_graph != 0 replays flow + Generator from a hipGraph captured for this workspace
- *   (keep one workspace per chunk length: the reference's per-bucket CUDA graphs, models.py:322-369).
- *   -> out fp32 [T_out * prod(upsample_rates)], T_out = T' (speed 1) or int(T' / speed) + 1, T' = 2 n_codes - valid_start;
+ *   (keep one workspace per chunk length: the reference's per-bucket CUDA graphs, models.py:322-369); a handle keeps at most
+ *   GSV_VOC_MAX_GRAPHS captured passes and evicts the least recently replayed one.
+ *   -> out fp32 [out_frames * prod(upsample_rates)], T' = 2 n_codes - valid_start;
  *      attn fp32 [4][2 n_codes][n_text] or NULL.  workspace: gsv_voc_decode_workspace(...) bytes, device. */
-size_t gsv_voc_decode_workspace(gsv_voc* h, int n_codes, int n_text, int Tg, float speed, int valid_start);
+#define GSV_VOC_MAX_GRAPHS 64
+size_t gsv_voc_decode_workspace(gsv_voc* h, int n_codes, int n_text, int Tg, int out_frames, int valid_start);
 int gsv_voc_decode(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t* text, int n_text, const float* ge, int Tg,
-                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, float speed, int valid_start, int overlap_len,
+                   const int64_t* slice_indices, float noise_scale, unsigned long long seed, int out_frames, int valid_start, int overlap_len,
                    float* overlap_state, int has_overlap, int use_graph, float* out, float* attn, void* workspace, size_t workspace_bytes,
                    void* stream);
 
@@ -283,6 +286,18 @@ int gsv_voc_decode(gsv_voc* h, const int64_t* codes, int n_codes, const int64_t*
 size_t gsv_align_workspace(int T, int N);
 int gsv_align_viterbi(const float* attn, int H, int T, int N, int32_t* assign, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* Streaming splice: replaces TTS._sola_algorithm (gsv_tts/TTS.py:1612-1627), which TTS.infer_stream calls between the decode of a
+ * chunk and its hand-out (TTS.py:429-431).
+ *   prev_tail fp32 [overlap]: the last `overlap` samples of the previous (already spliced) chunk; chunk fp32 [n], n >= overlap.
+ *   The chunk is slid by the offset k in [0, min(n, overlap + search_len) - overlap] that maximises
+ *   sum_j chunk[k + j] prev_tail[j] / sqrt(sum_j chunk[k + j]^2 + 1e-8) (first maximum), then cross-faded with
+ *   alpha = linspace(0, 1, overlap):  out[i] = prev_tail[i] (1 - alpha_i) + chunk[k + i] alpha_i for i < overlap, chunk[k + i] behind.
+ *   -> out fp32 (capacity n; n - *offset samples are written), offset int32 [1] (device; read it behind the stream).
+ *   workspace: gsv_sola_workspace(search_len) bytes, device.  Two launches, nothing allocated. */
+size_t gsv_sola_workspace(int search_len);
+int gsv_sola(const float* prev_tail, const float* chunk, int n, int overlap, int search_len, float* out, int32_t* offset,
+             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Reference-audio path, once per new speaker / prompt; fp32 in both numerics modes.
  * Replaces, on the device:

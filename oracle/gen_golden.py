@@ -393,7 +393,7 @@ def gen_refaudio(Syn):
     np.savez_compressed(os.path.join(GOLD, "refaudio.npz"), seed=1234, **META, **out)
 
 
-from gen_golden_inputs import FACADE_AUDIO, FACADE_LENGTHS, FACADE_SPLITS, facade_audio  # noqa: E402
+from gen_golden_inputs import FACADE_AUDIO, FACADE_LENGTHS, FACADE_SPLITS, SOLA_CASES, facade_audio, sola_case  # noqa: E402
 
 
 def gen_facade():
@@ -447,12 +447,34 @@ def gen_facade():
     print("facade: head", head, "tail", tail)
 
 
+def gen_sola():
+    """TTS._sola_algorithm (TTS.py:1612-1627), executed from the reference's source on the seeded cases of
+    gen_golden_inputs.SOLA_CASES: the chosen offset and the spliced chunk.  Only outputs are stored."""
+    import torch.nn.functional as F
+    fn = reference_functions("gsv_tts/TTS.py", ["_sola_algorithm"], {"torch": torch, "F": F})["_sola_algorithm"]
+
+    class Cfg:
+        device = torch.device("cpu")
+        dtype = torch.float32
+
+    class Self:
+        tts_config = Cfg()
+    out = {}
+    for k, case in enumerate(SOLA_CASES):
+        f1, f2 = sola_case(*case)
+        real, off = fn(Self(), tt(f1)[None, None], tt(f2)[None, None], case[2], case[3])
+        out["offset_%d" % k] = np.int64(int(off.item()))
+        out["out_%d" % k] = real[0, 0].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "sola.npz"), **META, **out)
+    print("sola offsets:", [int(out["offset_%d" % k]) for k in range(len(SOLA_CASES))])
+
+
 if __name__ == "__main__":
     tqdm.tqdm.__init__ = functools.partialmethod(tqdm.tqdm.__init__, disable=True)
     torch.manual_seed(0)
     T2S, sample, Syn = import_reference()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles", "refaudio", "facade"]
+    which = sys.argv[1:] or ["layers", "infer", "batched", "stream", "sample", "vocoder", "decode", "subtitles", "refaudio", "facade", "sola"]
     if "layers" in which: gen_t2s_layers(T2S)
     if "infer" in which: gen_t2s_infer(T2S)
     if "batched" in which: gen_t2s_batched(T2S)
@@ -463,3 +485,4 @@ if __name__ == "__main__":
     if "subtitles" in which: gen_subtitles()
     if "refaudio" in which: gen_refaudio(Syn)
     if "facade" in which: gen_facade()
+    if "sola" in which: gen_sola()

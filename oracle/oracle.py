@@ -791,3 +791,29 @@ class RefAudioOracle:
         dist = -(((y * y).sum(1, keepdims=True) - 2 * (y @ e.T)) + (e * e).sum(1)[None, :])
         top = np.sort(dist, axis=1)
         return dist.argmax(1).astype(np.int64), (top[:, -1] - top[:, -2]).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ streaming splice
+def sola(f1_overlap, f2, overlap_len, search_len=320):
+    """TTS._sola_algorithm (gsv_tts/TTS.py:1612-1627) restated in numpy: slide the new chunk `f2` over the previous chunk's tail
+    `f1_overlap` by the offset that maximises corr / sqrt(energy + 1e-8) (first maximum), cross-fade `overlap_len` samples with
+    alpha = torch.linspace(0, 1, overlap_len) (torch's two-sided evaluation: start + step * j below the middle, end - step *
+    (n - 1 - j) above).  -> (spliced chunk float32, offset).  Pinned to the reference by tests/golden/sola.npz."""
+    f1 = np.asarray(f1_overlap, np.float32)
+    f2 = np.asarray(f2, np.float32)
+    key = f2[:overlap_len + search_len]
+    n_off = len(key) - overlap_len + 1
+    win = np.lib.stride_tricks.sliding_window_view(key, overlap_len)[:n_off]            # [n_off][overlap]
+    corr = (win.astype(np.float64) * f1.astype(np.float64)).sum(1)
+    energy = (win.astype(np.float64) ** 2).sum(1) + 1e-8
+    score = (corr / np.sqrt(energy)).astype(np.float32)
+    off = int(np.argmax(score))
+    al = f2[off:]
+    n = overlap_len
+    step = np.float32(1.0) / np.float32(max(n - 1, 1))
+    j = np.arange(n)
+    alpha = np.where(j < n // 2, step * j.astype(np.float32), np.float32(1.0) - step * (n - 1 - j).astype(np.float32)).astype(np.float32)
+    if n == 1:
+        alpha = np.zeros(1, np.float32)
+    faded = f1 * (np.float32(1.0) - alpha) + al[:n] * alpha
+    return np.concatenate([faded, al[n:]]).astype(np.float32), off

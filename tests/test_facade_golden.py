@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-from oracle.gen_golden_inputs import FACADE_AUDIO, FACADE_LENGTHS, FACADE_SPLITS, facade_audio  # noqa: E402
+from oracle.gen_golden_inputs import FACADE_AUDIO, FACADE_LENGTHS, FACADE_SPLITS, SOLA_CASES, facade_audio, sola_case  # noqa: E402
 
 from gsv_tts_lite_amd.batchmath import balance_order, split_bounds  # noqa: E402
 from gsv_tts_lite_amd.tts import TTS  # noqa: E402
@@ -52,3 +52,16 @@ def test_split_and_trim_of_a_time_concatenated_batch(golden_dir):
             sizes.append(len(a)); sums.append(float(np.abs(a).astype(np.float64).sum()))
         assert sizes == g["split_%d_sizes" % k].tolist(), (k, sizes)
         np.testing.assert_allclose(sums, g["split_%d_sums" % k], rtol=1e-12)
+
+
+def test_oracle_sola_is_the_references(golden_dir):
+    """oracle.sola against tests/golden/sola.npz (the reference's TTS._sola_algorithm executed on the same seeded cases): the
+    offset exactly, the spliced chunk to fp32 rounding of the cross-fade."""
+    from oracle import oracle as orc
+    g = np.load(os.path.join(golden_dir, "sola.npz"))
+    for k, case in enumerate(SOLA_CASES):
+        f1, f2 = sola_case(*case)
+        out, off = orc.sola(f1, f2, case[2], case[3])
+        assert off == int(g["offset_%d" % k]), (k, off)
+        ref = g["out_%d" % k]
+        assert out.shape == ref.shape and np.abs(out - ref).max() <= 1.2e-7, (k, np.abs(out - ref).max())

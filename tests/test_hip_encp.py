@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gsv_tts_lite_amd import synth
+from gsv_tts_lite_amd import synth, _native as N
 
 pytestmark = pytest.mark.gpu
 
@@ -142,20 +142,24 @@ def test_decode_noise_is_the_counter_based_stream_and_per_token_ge_is_an_index_m
     text = torch.from_numpy(rng.integers(1, 700, (1, P))).to(dev)
     ge = torch.from_numpy(synth.synth_ge(1, 1024, 7)).to(dev)
     g = torch.Generator(device="cpu"); g.manual_seed(77)
-    vq._noise_calls = 0
+    seed = int(torch.empty((), dtype=torch.int64).random_(generator=g).item()) & (2 ** 64 - 1)   # what decode() will draw first
+    g.manual_seed(77)
     o1, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
-    seed = (77 * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
     noise = torch.from_numpy(orc.device_normal(seed, 192 * 2 * n).astype(np.float32)).reshape(1, 192, 2 * n).to(dev)
     assert abs(float(noise.mean())) < 0.03 and abs(float(noise.std()) - 1.0) < 0.03
     o_ref, _, _ = vq.ref_decode(codes, text, ge, noise=noise, noise_scale=0.5)
     e = (o1 - o_ref).abs()
     print("decode with noise vs restatement + device_normal: max %.2e" % float(e.max()))
     assert float(e.max()) < 1e-4
-    vq._noise_calls = 0
-    o1b, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
-    assert torch.equal(o1, o1b), "same generator seed, same call index: the same draw"
     o1c, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
-    assert not torch.equal(o1, o1c), "the next call of a run draws fresh noise"
+    assert not torch.equal(o1, o1c), "the next call of a run draws fresh noise: the generator's state advanced"
+    g.manual_seed(77)                                  # re-seeding replays the run, as torch.randn(generator=...) would
+    o1b, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
+    o1d, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g)
+    assert torch.equal(o1, o1b) and torch.equal(o1c, o1d), "same generator seed, same call index: the same draw"
+    g2 = torch.Generator(device="cpu"); g2.manual_seed(77)
+    o1e, _ = vq.decode(codes, text, ge, noise_scale=0.5, generator=g2)
+    assert torch.equal(o1, o1e), "a second generator with the same seed starts the same stream (no shared counter)"
     # per-token ge: two utterances concatenated, each with its own speaker
     cut = 15
     ge2 = torch.from_numpy(synth.synth_ge(2, 1024, 7)).to(dev)
@@ -170,3 +174,75 @@ def test_decode_noise_is_the_counter_based_stream_and_per_token_ge_is_an_index_m
         assert float(e.max()) < 1e-4 and float((attn - attn_r).abs().max()) < 1e-5
     with pytest.raises(ValueError):
         vq.decode(codes.expand(2, -1, -1), text, ge)       # batched codes: the reference never passes them, the library refuses
+
+
+def test_decode_frame_count_is_the_callers_at_every_speed(dev):
+    """int(T / speed) + 1 (models.py:217) is evaluated ONCE, in Python doubles as the reference does, and handed to
+    the library; a float32 re-evaluation inside disagreed at e.g. (speed 1.1, T 110) and (0.6, 9).  Sweep chunk lengths at those
+    speeds: the output has exactly the reference's length, every sample is written (no NaN canary left), nothing is written
+    past the end, and the graph-bucket path agrees with the eager one."""
+    vq = _vq("v2Pro", 7, dev, torch.float32)
+    rng = np.random.default_rng(3)
+    P = 11
+    text = torch.from_numpy(rng.integers(1, 700, (1, P))).to(dev)
+    ge = torch.from_numpy(synth.synth_ge(1, 1024, 7)).to(dev)
+    hop = vq.samples_per_frame
+    cases = [(55, 1.1, 0), (5, 0.6, 1), (50, 1.1, 0), (7, 0.6, 0), (12, 0.7, 3), (55, 2.0, 0), (33, 0.9, 0)]   # (n, speed, valid_start)
+    import torch as _t
+    real_empty = _t.empty
+    for n, speed, start in cases:
+        Tp = 2 * n - start
+        T_ref = int(Tp / speed) + 1
+        codes = torch.from_numpy(rng.integers(0, 1024, (1, 1, n))).to(dev)
+        kw = dict(noise_scale=0.0, speed=speed)
+        if start:
+            vq.enc_p.y_overlap = None
+            kw.update(stream_mode=True, valid_start_idx=start, overlap_len=2)
+        o, _ = vq.decode(codes, text, ge, cuda_graph=False, **kw)
+        assert o.shape[-1] == T_ref * hop, (n, speed, start, o.shape, T_ref)
+        assert bool(torch.isfinite(o).all())
+        o_r, _, _ = vq.ref_decode(codes, text, ge, speed=speed) if not start else (None, None, None)
+        if o_r is not None:
+            assert o.shape == o_r.shape and float((o - o_r).abs().max()) < 1e-4
+        # the same call into a NaN-filled, guard-padded buffer through the ABI: all of [0, T_ref * hop) written, nothing after
+        vn = vq._voc
+        c1 = codes.reshape(-1).contiguous(); t1 = text.reshape(-1).contiguous()
+        g1 = ge.to(torch.float32).reshape(vq.gin_channels, -1).contiguous()
+        need = N.lib().gsv_voc_decode_workspace(vn._h, n, P, 1, T_ref, start)
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        buf = torch.full((T_ref * hop + 4 * hop,), float("nan"), device=dev)
+        state = torch.zeros(2 * vq.inter_channels, 2, device=dev)
+        N.check(N.lib().gsv_voc_decode(vn._h, c1.data_ptr(), n, t1.data_ptr(), P, g1.data_ptr(), 1, 0, 0.0, 0, T_ref, start,
+                                       2 if start else 0, state.data_ptr() if start else 0, 0, 0, buf.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                                       N.current_stream_ptr(dev)))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(buf[:T_ref * hop]).all()) and bool(torch.isnan(buf[T_ref * hop:]).all()), (n, speed, start)
+        assert torch.equal(buf[:T_ref * hop], o.reshape(-1))
+    # a bucketed (hipGraph) chunk at speed != 1
+    vq.cuda_graph_buckets = [int(110 / 1.1) + 1]
+    codes = torch.from_numpy(rng.integers(0, 1024, (1, 1, 55))).to(dev)
+    a, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=1.1, cuda_graph=True)
+    b, _ = vq.decode(codes, text, ge, noise_scale=0.0, speed=1.1, cuda_graph=False)
+    assert a.shape == b.shape and torch.equal(a, b)
+    assert N.lib().gsv_voc_decode_workspace(vq._voc._h, 10, P, 1, 0, 0) == 0      # out_frames < 1 is refused
+
+
+def test_vocoder_graph_cache_evicts_instead_of_failing(dev):
+    """the captured-pass cache is bounded (GSV_VOC_MAX_GRAPHS = 64) and evicts its least recently replayed entry; a
+    long-lived server that keeps meeting new (workspace, T) pairs must keep decoding."""
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps("v2Pro")
+    sw = synth.sovits_weights(hps, seed=5, hot_path_only=True)
+    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.bfloat16, dev)
+    ge = torch.from_numpy(synth.synth_ge(0, 1024, 5)).to(dev)
+    first = None
+    for k in range(70):                       # 70 distinct lengths -> 70 captures through a 64-entry cache
+        T = 4 + k
+        z = torch.from_numpy(synth.hashed_uniform("gc.z", (1, 192, T), 5)).to(dev)
+        o = voc.flow_dec_bucket(z, torch.ones(1, 1, T, device=dev), ge)
+        assert bool(torch.isfinite(o).all())
+        if k == 0:
+            first = (z, o.clone())
+    z, o0 = first                              # evicted by now: re-captured, same result
+    assert torch.equal(voc.flow_dec_bucket(z, torch.ones(1, 1, 4, device=dev), ge), o0)

@@ -132,16 +132,19 @@ def test_bf16_greedy_tokens_bench_shape_vs_bf16_oracle(dev):
         agree.append(250 if first is None else first)
         del m
     print("bf16 tokens equal to the bf16 oracle for the first %s of 250 steps" % agree)
-    assert min(agree) >= 25, agree     # BOTH requests: a matched prefix far beyond the suppression window
+    # BOTH requests: measured 250 and 107 matched steps (r3, r4); the gate keeps 25 % headroom under the shorter one.  The
+    # matched prefix is a property of (weights seed, request, summation order): a kernel change that re-orders a bf16 sum may
+    # move it, and the margin assertion above is what decides whether such a move is legitimate
+    assert min(agree) >= 80 and max(agree) >= 200, agree
 
 
 @pytest.mark.parametrize("dtype,numerics", [(torch.float32, "fp32"), (torch.bfloat16, "bf16")])
 def test_continuous_batching_40_requests_32_slots(dev, dtype, numerics):
-    """BASELINE configs[2]'s slot count: 40 mixed-length requests through 32 slots (8 refills), greedy; 32 slots run the
-    two-sequences-per-block decode kernels (csrc/t2s_decode_multi.h).  fp32: tokens, completion order and
-    semantic_orig_idx bit-exact against the oracle's continuous batching.  bf16: each request equal to the bf16 oracle's
-    up to the first step whose margin is below TOKEN_MARGIN.  (The batched MFMA chain, >= 40 slots, has its own
-    margin-gated run in tests/test_hip_t2s.py and the hidden-state checks below.)"""
+    """BASELINE configs[2]'s slot count: 40 mixed-length requests through 32 slots (8 refills), greedy.  fp32 handles run the
+    two-sequences-per-block decode kernels at 32 slots (csrc/t2s_decode_multi.h); bf16 handles run the batched MFMA chain from
+    17 sequences on (csrc/t2s_small.h, `batched_min`).  fp32: tokens, completion order and semantic_orig_idx bit-exact against
+    the oracle's continuous batching.  bf16: each request equal to the bf16 oracle's up to the first step whose margin is below
+    TOKEN_MARGIN.  (The full-size 256-request / 24-layer run is tests/test_hip_cb_fullsize.py.)"""
     from oracle import oracle as orc
     cfg = synth.gpt_config(n_layer=4)
     w = synth.gpt_weights(cfg, seed=41, eos_gain=2.0)

@@ -44,6 +44,16 @@ if passes:
     tot = sum(2.0 * 1024.0 * sum(v) for k, v in fetch.items() if _is_voc(k)) + sum(1024.0 * sum(v) for k, v in write.items() if _is_voc(k))
     flat["vocoder_pass"] = tot / passes
     flat["vocoder_passes_counted"] = passes
-json.dump({"_detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
+import hashlib, os
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+d = os.path.join(root, "gsv-tts-lite_amd", "csrc")
+for f in sorted(os.listdir(d)):
+    if f.endswith((".h", ".hip")):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+stamp = os.path.join(root, ".commit_stamp")      # written by tools/gpu.sh before the snapshot leaves (the GPU box has no .git)
+meta = {"commit": open(stamp).read().strip() if os.path.exists(stamp) else None, "csrc_sha16": h.hexdigest()[:16],
+        "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-cb32 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE"}
+json.dump({"_meta": meta, "_detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k]["launches"])[:12]:
     print("%-28s launches %6d  fetch %10.0f B  write %9.0f B" % (k, out[k]["launches"], out[k]["fetch_bytes_per_launch"], out[k]["write_bytes_per_launch"]))

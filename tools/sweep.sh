@@ -8,11 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
 # 1. default bench line (configs[1]) and its rocprofv3 summary
 run timeout 900 python $R/bench.py > $O/bench_line.json 2> $O/bench_line.log
-rm -rf /tmp/p1; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/prof_bench.log
+rm -rf /tmp/p1; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-cb32 > /dev/null 2> $O/prof_bench.log
 f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/rocprofv3_kernel_stats.csv
 # 2. HBM / fabric traffic: two PMC passes (counters only, no tracing beyond kernel dispatch)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm_$c; run timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_$c.log
+  rm -rf /tmp/pm_$c; run timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-cb32 > /dev/null 2> $O/pmc_$c.log
 done
 ff=$(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 [ -n "$ff" ] && [ -n "$fw" ] && python $R/tools/pmc_traffic.py "$ff" "$fw" $O/traffic.json > $O/traffic_table.txt 2>&1
