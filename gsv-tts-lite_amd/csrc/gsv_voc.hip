@@ -4,6 +4,7 @@
 
 #include "abi_common.h"
 #include "flowfuse.h"
+#include "flowstage.h"
 #include "rbfuse.h"
 #include "encp.h"
 #include "voc_kernels.h"
@@ -128,6 +129,8 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     return w;
 }
 
+constexpr int kFlowStagedMaxT = 2048;   // frames up to which the flow runs as staged launches (measured: profiles/r04_flow_staged.txt)
+
 template <typename AT>
 int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStream_t st) {
     const gsv_voc_config& c = v->cfg;
@@ -138,6 +141,32 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
         // one launch for every flow's conditioning, then one fused kernel per coupling layer; no Flip passes
         const int ldg_all = 8 * H * c.n_flows;
         if (int rc = run_cond<AT>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, st)) return rc;
+        // few frames: ten short many-CU launches per coupling layer (flowstage.h); many frames: one kernel per layer (flowfuse.h)
+        static const int staged_max_T = getenv("GSV_FLOW_STAGED_MAX_T") ? atoi(getenv("GSV_FLOW_STAGED_MAX_T")) : kFlowStagedMaxT;
+        if (T <= staged_max_T) {
+            static const int rpb_env = getenv("GSV_FLOW_STAGED_RPB") ? atoi(getenv("GSV_FLOW_STAGED_RPB")) : 0;
+            const int ntiles = cdiv(T, FS_ROWS);
+            for (int f = c.n_flows - 1; f >= 0; --f) {
+                VocFlow& F = v->flows[f];
+                FlowStageArgs a;
+                a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
+                a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
+                a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
+                a.h = (bf16_t*)w.h; a.acts = (bf16_t*)w.acts; a.skip = (float*)w.a; a.outp = (bf16_t*)w.outp;
+                a.l = 0;
+                a.rpb = rpb_env > 0 ? rpb_env : std::max(1, cdiv(ntiles, 64));      // <= 64 frame groups: (64 x 6) in_layer blocks fill the chip
+                const int gx = cdiv(ntiles, a.rpb);
+                hipLaunchKernelGGL((flowstage_kernel<FS_PRE>), dim3(gx, 2), dim3(256), 0, st, a);
+                for (int l = 0; l < 4; ++l) {
+                    a.l = l;
+                    hipLaunchKernelGGL((flowstage_kernel<FS_IN>), dim3(gx, 6), dim3(256), 0, st, a);
+                    hipLaunchKernelGGL((flowstage_kernel<FS_RS>), dim3(gx, l < 3 ? 3 : 2), dim3(256), 0, st, a);
+                }
+                hipLaunchKernelGGL((flowstage_kernel<FS_POST>), dim3(gx, 1), dim3(256), 0, st, a);
+            }
+            HIPCHK(hipGetLastError());
+            return GSV_OK;
+        }
         HIPCHK(hipFuncSetAttribute((const void*)flowfuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FF_LDS_TOTAL));
         for (int f = c.n_flows - 1; f >= 0; --f) {
             VocFlow& F = v->flows[f];

@@ -15,6 +15,7 @@ checkers in oracle/sovits_encoder.py.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -94,15 +95,17 @@ class _VocoderNative:
         key = (T, Tg)
         if not hasattr(self, "_buckets"):
             self._buckets = {}
-        b = self._buckets.get(key)
+        b = self._buckets.pop(key, None)
         if b is None:
+            while len(self._buckets) >= self.GRAPH_BUCKETS:          # least recently replayed bucket goes (its graph is evicted by
+                self._buckets.pop(next(iter(self._buckets)))         # the library when its own cache fills: gsv_voc_flow_dec_graph)
             need = N.lib().gsv_voc_workspace(self._h, T)
             b = {"z": torch.zeros(1, self.inter, T, dtype=torch.float32, device=self.device),
                  "m": torch.zeros(T, dtype=torch.float32, device=self.device),
                  "g": torch.zeros(1, self.gin, Tg, dtype=torch.float32, device=self.device),
                  "o": torch.zeros(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device),
                  "w": torch.empty(need, dtype=torch.uint8, device=self.device)}
-            self._buckets[key] = b
+        self._buckets[key] = b                                       # most recently used last
         b["z"].copy_(z)
         b["m"].copy_(y_mask.to(device=self.device, dtype=torch.float32).reshape(-1))
         b["g"].copy_(ge)
@@ -127,7 +130,31 @@ class _VocoderNative:
         Tg = ge.shape[2]
         return z, ge, T, Tg
 
+    # flow_dec(graph replay): measured on MI355X (profiles/r04_vocoder_graph_replay_negative.txt), replaying the ~40-kernel pass of one
+    # utterance from a hipGraph is NOT faster for a pass that starts on an idle stream -- hipGraphLaunch spends ~20 us per kernel
+    # node before the first kernel runs (bench: 1.19 ms eager -> 1.91 ms replayed), while eager launches (3-4 us each) stay ahead
+    # of 5-60 us kernels after the first one.  Replay only pays when passes are queued back to back (streaming chunks:
+    # SynthesizerTrn's cuda_graph_buckets).  `auto_graph` therefore defaults to off; it promotes a length to a bucket on its
+    # third use when switched on.
+    GRAPH_MAX_FRAMES = 1024
+    GRAPH_AFTER_USES = 3
+    GRAPH_BUCKETS = 8
+
+    def _graph_worthy(self, T, Tg):
+        if T > self.GRAPH_MAX_FRAMES or not self.auto_graph:
+            return False
+        seen = self.__dict__.setdefault("_len_uses", {})
+        n = seen.pop((T, Tg), 0) + 1
+        seen[(T, Tg)] = n                      # most recently used last
+        while len(seen) > 64:
+            seen.pop(next(iter(seen)))
+        return n >= self.GRAPH_AFTER_USES
+
+    auto_graph = False
+
     def flow_dec(self, z_p, y_mask, ge):
+        if self._graph_worthy(int(z_p.shape[2]), int(ge.shape[2])):
+            return self.flow_dec_bucket(z_p, y_mask, ge)
         z, ge, T, Tg = self._prep(z_p, ge)
         mask = y_mask.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
         out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)

@@ -46,7 +46,9 @@ def test_sola_vs_oracle_on_fresh_inputs_and_short_chunks(dev):
         f2 = (base[at - shift: at - shift + n] + 0.05 * rng.standard_normal(n)).astype(np.float32)
         want, woff = orc.sola(f1, f2, ov, search)
         got, off = sola(torch.from_numpy(f1).to(dev), torch.from_numpy(f2).to(dev), search)
-        assert off == woff == shift, (n, ov, search, off, woff, shift)
+        assert off == woff, (n, ov, search, off, woff, shift)
+        if ov >= 64:           # a one-sample overlap scores every candidate +-|tail|: the FIRST maximum wins, not the planted shift
+            assert off == shift, (n, ov, search, off, shift)
         assert got.shape[0] == want.shape[0] and np.abs(got.cpu().numpy() - want).max() <= 1.2e-7
 
 
@@ -71,7 +73,7 @@ def test_chunk_splicer_protocol(dev):
     out, pos, shifts = [], 0, [0, 13, 200, 0, 77]
     for c, sh in enumerate(shifts):
         final = c == len(shifts) - 1
-        start = pos - ov - sh if c else 0                      # the vocoder re-renders the overlap (+ `sh` samples of slack)
+        start = pos - sh if c else 0                           # the vocoder re-renders the held-back tail, `sh` samples late
         chunk = torch.from_numpy(sm[start: start + n_chunk].copy()).to(dev)
         piece = sp.push(chunk[None, None], final)
         out.append(piece.cpu().numpy())

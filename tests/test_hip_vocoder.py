@@ -187,3 +187,30 @@ def test_bench_shape_bf16_flow_and_generator_vs_bf16_oracle(dev):
     ef = np.abs(full - o16.flow_dec(z[0], mask, ge[0]))
     print("flow_dec T=500 bf16 vs bf16 oracle: max %.2e mean %.2e" % (ef.max(), ef.mean()))
     assert ef.max() < 8e-2 and ef.mean() < 8e-3, (ef.max(), ef.mean())
+
+
+def test_flow_dec_switches_to_graph_replay_on_a_repeated_length(dev):
+    """With auto_graph on, _VocoderNative.flow_dec replays a length from a hipGraph from its third use on (sovits.py:
+    GRAPH_AFTER_USES; off by default: a replay from an idle stream measured slower than eager launches); the replayed pass must
+    return exactly what the eager pass returns, for new inputs too, and long passes must stay eager."""
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps("v2Pro")
+    w = synth.sovits_weights(hps, seed=3, hot_path_only=True)
+    v = _VocoderNative(hps["model"], {k: torch.from_numpy(a) for k, a in w.items()}, torch.bfloat16, dev)
+    ge = torch.from_numpy(synth.synth_ge(0, 1024, 3)).to(dev)
+    T = 77
+    outs = []
+    v.auto_graph = True
+    for k in range(5):
+        z = torch.from_numpy(synth.hashed_uniform("gr.z%d" % k, (1, 192, T), 3)).to(dev)
+        o = v.flow_dec(z, torch.ones(1, 1, T, device=dev), ge)
+        v.auto_graph = False
+        e = v.flow_dec(z, torch.ones(1, 1, T, device=dev), ge)
+        v.auto_graph = True
+        assert torch.equal(o, e), k
+        outs.append(o)
+    assert (T, 1) in v._buckets and len(v._buckets) == 1
+    assert not torch.equal(outs[3], outs[4])
+    for _ in range(4):       # a long (batched) pass never takes a bucket
+        v.flow_dec(torch.zeros(1, 192, v.GRAPH_MAX_FRAMES + 8, device=dev), torch.ones(1, 1, v.GRAPH_MAX_FRAMES + 8, device=dev), ge)
+    assert len(v._buckets) == 1
