@@ -129,6 +129,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     return w;
 }
 
+constexpr int kFlowMergedMaxT = 1024;   // frames up to which the staged flow runs in its merged (5 launches per layer) form
 constexpr int kFlowStagedMaxT = 2048;   // frames up to which the flow runs as staged launches (measured: profiles/r04_flow_staged.txt)
 
 template <typename AT>
@@ -145,15 +146,50 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
         static const int staged_max_T = getenv("GSV_FLOW_STAGED_MAX_T") ? atoi(getenv("GSV_FLOW_STAGED_MAX_T")) : kFlowStagedMaxT;
         if (T <= staged_max_T) {
             static const int rpb_env = getenv("GSV_FLOW_STAGED_RPB") ? atoi(getenv("GSV_FLOW_STAGED_RPB")) : 0;
-            const int ntiles = cdiv(T, FS_ROWS);
-            for (int f = c.n_flows - 1; f >= 0; --f) {
+            // merged form (5 launches per layer, each fatter): 166 vs 173 us up to ~1000 frames, slower beyond (249 vs 218 us at 2000)
+            static const int merged_max_T = getenv("GSV_FLOW_MERGED_MAX_T") ? atoi(getenv("GSV_FLOW_MERGED_MAX_T")) : kFlowMergedMaxT;
+            const bool merged = T <= merged_max_T;
+            auto stage_args = [&](int f) {
                 VocFlow& F = v->flows[f];
                 FlowStageArgs a;
                 a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
                 a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
                 a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
                 a.h = (bf16_t*)w.h; a.acts = (bf16_t*)w.acts; a.skip = (float*)w.a; a.outp = (bf16_t*)w.outp;
-                a.l = 0;
+                a.l = 0; a.rpb = 1;
+                return a;
+            };
+            if (merged) {
+                // five launches per coupling layer (flowstage.h, merged form): h ping-pongs between w.h and w.outp, acts between w.acts and w.zflip
+                bf16_t* hb[2] = {(bf16_t*)w.h, (bf16_t*)w.outp};
+                bf16_t* ab[2] = {(bf16_t*)w.acts, (bf16_t*)w.zflip};
+                const int gin_ = cdiv(T, FM_VR), gt = cdiv(T, FS_ROWS);
+                {
+                    FlowStageArgs a = stage_args(c.n_flows - 1);
+                    hipLaunchKernelGGL((flowstage_kernel<FS_PRE>), dim3(gt, 2), dim3(256), 0, st, a);
+                }
+                for (int f = c.n_flows - 1; f >= 0; --f) {
+                    FlowMergeArgs m;
+                    m.s = stage_args(f);
+                    m.Wn = nullptr; m.Bn = nullptr;
+                    for (int l = 0; l < 4; ++l) {
+                        m.s.l = l;
+                        // h_l lives in hb[l & 1] (h_0 from pre in hb[0]); acts_l in ab[l & 1]
+                        m.h_in = hb[l == 0 ? 0 : (l - 1) & 1]; m.h_out = hb[l & 1];
+                        m.acts_in = ab[l == 0 ? 0 : (l - 1) & 1]; m.acts_out = ab[l & 1];
+                        hipLaunchKernelGGL(flowmerge_in_kernel, dim3(gin_, 6), dim3(256), 0, st, m);
+                    }
+                    m.acts_in = ab[1];                     // acts_3
+                    m.h_out = hb[0];
+                    if (f > 0) { m.Wn = (const uint4*)v->flows[f - 1].ff_w; m.Bn = v->flows[f - 1].ff_b; }
+                    hipLaunchKernelGGL(flowmerge_tail_kernel, dim3(gt), dim3(256), 0, st, m);
+                }
+                HIPCHK(hipGetLastError());
+                return GSV_OK;
+            }
+            const int ntiles = cdiv(T, FS_ROWS);
+            for (int f = c.n_flows - 1; f >= 0; --f) {
+                FlowStageArgs a = stage_args(f);
                 a.rpb = rpb_env > 0 ? rpb_env : std::max(1, cdiv(ntiles, 64));      // <= 64 frame groups: (64 x 6) in_layer blocks fill the chip
                 const int gx = cdiv(ntiles, a.rpb);
                 hipLaunchKernelGGL((flowstage_kernel<FS_PRE>), dim3(gx, 2), dim3(256), 0, st, a);

@@ -1,5 +1,5 @@
 """the flow alone (gsv_voc_flow: 4 coupling layers in reverse) at several frame counts; GSV_FLOW_STAGED_MAX_T=0 forces the fused kernel,
-GSV_FLOW_STAGED_RPB the frame tiles per block of the staged form.  usage: tools/flow_time.py [T ...]"""
+GSV_FLOW_STAGED_RPB the frame tiles per block of the staged form, GSV_FLOW_MERGED_MAX_T=0 the ten-launch form instead of the merged one.  usage: tools/flow_time.py [T ...]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gsv-tts-lite_amd")]
