@@ -101,6 +101,8 @@ struct Epi {
     const float* mask = nullptr;
     float scale = 1.0f; int act = ACT_NONE; int accumulate = 0; float in_slope = 1.0f;
     bool use_bias = true;
+    bool fixed_order = false;   // the contraction's summation order must not depend on the row count: always the split-K tile (the prompt pass:
+                                // a request's rows must not change with how many prompts share its pass)
 };
 
 struct Branch {
@@ -150,7 +152,7 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
     }
     const int nz = nbr > 1 ? nbr : pc.nphase;
     const long tiles11 = (long)cdiv(n_rows, 128) * pc.mtiles * nz;   // blocks at (WM,WN) = (1,1)
-    const bool splitk = tiles11 < 256;
+    const bool splitk = e.fixed_order || tiles11 < 256;
     const bool wide_m = !splitk && pc.mtiles >= 2 && tiles11 >= 1024;
     const bool wide_n = !splitk && (long)cdiv(n_rows, 256) * cdiv(pc.mtiles, wide_m ? 2 : 1) * nz >= 1024;
     // mid-size problems (the 256-channel resblock stage: 5000 rows x 8 m-tiles x 3 branches): 64-row waves at two

@@ -728,7 +728,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
     } else {
         for (int l = 0; l < h->cfg.n_layer; ++l) {
             T2SLayer& L = h->layers[l];
-            Epi e0;
+            Epi e0; e0.fixed_order = true;      // fp32 prompt pass: one tile shape (= one summation order) for every row count
             if (int rc = run_conv<float, WT, float>(L.g_qkv, xy, kD, M, qkv, 3 * kD, M, e0, st)) return rc;
             PrefillAttnArgs<WT> pa;
             pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
@@ -743,15 +743,15 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             } else {
                 hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
             }
-            Epi e1; e1.res = xy; e1.ld_res = kD;
+            Epi e1; e1.res = xy; e1.ld_res = kD; e1.fixed_order = true;
             // out_proj bias lives in the decode copy (L.bo); tapgemm bias pointer set per call
             PackedConv go = L.g_out; go.bias = L.bo;
             if (int rc = run_conv<float, WT, float>(go, attn, kD, M, ybuf, kD, M, e1, st)) return rc;
             hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln1g, L.ln1b, xy, M);
-            Epi e2; e2.act = ACT_RELU;
+            Epi e2; e2.act = ACT_RELU; e2.fixed_order = true;
             PackedConv g1 = L.g_w1; g1.bias = L.b1;
             if (int rc = run_conv<float, WT, float>(g1, xy, kD, M, fbuf, kF, M, e2, st)) return rc;
-            Epi e3; e3.res = xy; e3.ld_res = kD;
+            Epi e3; e3.res = xy; e3.ld_res = kD; e3.fixed_order = true;
             PackedConv g2 = L.g_w2; g2.bias = L.b2;
             if (int rc = run_conv<float, WT, float>(g2, fbuf, kF, M, ybuf, kD, M, e3, st)) return rc;
             hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ybuf, L.ln2g, L.ln2b, xy, M);
@@ -960,6 +960,10 @@ int gsv_t2s_embed_prompt(gsv_t2s* h, int nrows, int lx_max, int ly_max, int l_ma
     if (nrows < 1 || lx_max < 1 || ly_max < 1 || l_max < 1 || l_max > h->cfg.n_pos) return fail(GSV_ERR_ARG, "bad sizes");
     const int M = nrows * lx_max;
     Epi e;
+    // split-K tiles whatever the row count: the wide tiles tapgemm picks from ~2 000 phoneme rows on sum K in another order, and a
+    // request's embedded rows -- hence its K/V rows and first logits -- changed with the number of prompts packed beside it
+    // (found in round 4: tests/test_hip_t2s.py::test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16)
+    e.fixed_order = true;
     int rc = h->cfg.dtype == GSV_BF16 ? run_conv<float, bf16_t, float>(h->g_bert, bert, 1024, M, scratch, kD, M, e, S(stream))
                                       : run_conv<float, float, float>(h->g_bert, bert, 1024, M, scratch, kD, M, e, S(stream));
     if (rc) return rc;

@@ -482,6 +482,49 @@ def test_prefill_into_scattered_slots_equals_one_by_one(dev, dtype):
         assert torch.equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("nreq,plen", [(6, 130), (26, 190)])
+def test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16(dev, nreq, plen):
+    """A request's K/V rows, first logits and recorded tokens must not depend on how many prompts shared its prompt pass (the slot
+    loop's refills and the engine's ranks pack different sets): a packed pass of ~800 rows and one of ~5 000 rows against the same
+    prompts one by one, bit for bit.  The second size is the one that FAILED in round 4: from ~2 000 phoneme rows on the BERT
+    projection (a tapgemm launch) switched from its split-K tile to a wide tile that sums K in another order, the embedded rows
+    moved by an fp32 ulp and the bf16 K/V rows behind them by a bf16 ulp (csrc/abi_common.h: Epi::fixed_order pins the tile)."""
+    cfg = synth.gpt_config(n_layer=3)
+    w = synth.gpt_weights(cfg, seed=33)
+    rng = np.random.default_rng(nreq)
+    shapes = [(int(rng.integers(20, 40)), int(rng.integers(plen // 2 - 20, plen // 2)), int(rng.integers(plen // 3, plen // 2))) for _ in range(nreq)]
+    rs = [synth.synth_request(170 + i, p, t, n, seed=33, bert="random") for i, (p, t, n) in enumerate(shapes)]
+    xs, ys, bs = ([_T(r[k], dev) for r in rs] for k in range(3))
+    B = nreq
+    slots = list(rng.permutation(B))
+    states = []
+    for packed in (False, True):
+        with torch.inference_mode():
+            m = _model(cfg, w, [(B, 256)], torch.bfloat16, dev)
+            rt = m._rt[B]
+            for t in (rt["kv_len"], rt["x_len"], rt["logits"], rt["pre_tokens"]):
+                t.zero_()
+            m.k_cache_root.zero_()
+            m.v_cache_root.zero_()
+            if packed:
+                xy, xl, yl, _, _ = m.embed_prompt(xs, ys, bs)
+                assert xy.shape[0] * xy.shape[1] >= (4096 if nreq > 20 else 512), xy.shape     # rows of the packed pass
+                m.prefill_slots(B, [int(v) for v in slots], xy, xl, yl)
+            else:
+                for s_, x, y, b in zip(slots, xs, ys, bs):
+                    xy, xl, yl, _, _ = m.embed_prompt([x], [y], [b])
+                    m.prefill(B, int(s_), xy, xl, yl)
+            m._flush(B)
+            torch.cuda.synchronize()
+            st = {k: rt[k].clone() for k in ("kv_len", "x_len", "logits", "pre_tokens")}
+            st.update({"k": m.k_cache_root.clone(), "v": m.v_cache_root.clone()})
+            states.append(st)
+            del m
+    a, b = states
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
+
+
 def test_bf16_long_prompt_uses_the_mfma_attention_limit(dev):
     """the bf16 prompt pass is gated by ITS kernel's LDS footprint (prompts up to 1056 positions), not by
     the fp32 parity kernel's (591): a 900-position prompt -- inside the reference's default 1024 bucket -- must run
