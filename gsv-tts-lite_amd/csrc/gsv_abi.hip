@@ -500,6 +500,7 @@ int t2s_token(gsv_t2s* h, const gsv_t2s_state& s, int advance, hipStream_t st) {
 //   chain, 16 x 16 tiles          --     --     0.54   0.57   0.59   0.61   0.62   0.65   --     --
 // GSV_BATCHED_MIN overrides it at handle creation (bench / tuning aid).
 constexpr int kBatchedMinDefault = 17;
+constexpr int kWideMinM = 3072;       // prompt-pass rows from which the chain's GEMMs are bgemm_wide_kernel (profiles/r04_prompt_pass_wide.txt)
 constexpr size_t kPrefillLdsMax = 160 * 1024;
 constexpr int kNtFromLayerF32 = 9;     // fp32 handles: 9 layers (114 MB; best of 6..14 at kv ~400, within 1 % of the best at kv ~200) + the K/V rows of a step stay in the Infinity Cache: 0.490 -> 0.440 ms per step (profiles/r03_f32_nontemporal_layers.txt)
 
@@ -539,8 +540,62 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     // (the prompt pass's weight fragments non-temporal, so that they do not evict the decode step's copy: measured, no gain in the
     // cb workload, TTFT 1.11 -> 1.37 ms: not adopted)
     const bool nwv4 = M > 48;
+    // a prompt pass of MANY rows (a packed batch of prompts): the same contraction, bit for bit, shaped for throughput
+    // (bgemm_wide_kernel: 128 rows staged once per block, a wave per column tile over the full K, weights three groups ahead)
+    static const int wide_min = getenv("GSV_WIDE_MIN_M") ? atoi(getenv("GSV_WIDE_MIN_M")) : kWideMinM;
+    const bool wide = prompt && !f8 && M >= wide_min;
+    auto run_wide = [&](auto kern, bool w2, BGemmArgs ba) -> int {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
+        const int rgroups = cdiv(M, 32 * kWideRT), cgroups = cdiv(ba.mtiles, 4 * kWideTPW);
+        // column groups per block: the block count that costs the fewest rounds of (stage the rows once + walk the groups)
+        int gpb = 1;
+        if (!w2) {
+            double best = 1e30;
+            for (int g = 1; g <= cgroups; ++g) {
+                if (cgroups % g) continue;
+                const double cost = (double)cdiv(rgroups * (cgroups / g), 256) * (1.0 + g);
+                if (cost < best - 1e-9) { best = cost; gpb = g; }
+            }
+        }
+        ba.cpb = gpb * 4 * kWideTPW;
+        hipLaunchKernelGGL(kern, dim3(rgroups, cgroups / gpb), dim3(256), kWideLds, st, ba);
+        return GSV_OK;
+    };
     for (int l = 0; l < h->cfg.n_layer; ++l) {
         T2SLayer& L = h->layers[l];
+        if (wide) {
+            if (!(skip & 1)) {   // K1
+                BGemmArgs g{};
+                g.M = M; g.ldx = kD; g.W = (const uint4*)L.g_qkv.w; g.mtiles = 3 * kD / 32; g.cout = 3 * kD; g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
+                if (l == 0) {
+                    g.X = x0;
+                    if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, float, float>, false, g)) return rc;
+                } else {
+                    g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
+                    if (int rc = run_wide(bgemm_wide_kernel<PRO_LN, float, float>, false, g)) return rc;
+                }
+            }
+            if (!(skip & 2)) attn_launch(l);
+            if (!(skip & 4)) {   // K3
+                BGemmArgs g{};
+                g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
+                g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
+                if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, float, float>, false, g)) return rc;
+            }
+            if (!(skip & 8)) {   // K4
+                BGemmArgs g{};
+                g.M = M; g.X = c.y1; g.ldx = kD; g.lng = L.ln1g; g.lnb = L.ln1b; g.xout = c.x1;
+                g.W = (const uint4*)L.g_w1.w; g.mtiles = kF / 32; g.cout = kF; g.bias = L.b1; g.relu = 1; g.Y = c.hid; g.ldy = kF;
+                if (int rc = run_wide(bgemm_wide_kernel<PRO_LN, float, bf16_t>, false, g)) return rc;
+            }
+            if (!(skip & 16)) {  // K5
+                BGemmArgs g{};
+                g.M = M; g.X = c.hid; g.ldx = kF; g.W = (const uint4*)L.g_w2.w; g.mtiles = kD / 32; g.cout = kD;
+                g.bias = L.b2; g.res = c.x1; g.ldres = kD; g.Y = c.y2; g.ldy = kD;
+                if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, bf16_t, float>, true, g)) return rc;
+            }
+            continue;
+        }
         if (small) {
             if (!(skip & 1)) {   // K1
                 SGemmArgs g{};

@@ -387,6 +387,236 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
     }   // column tiles
 }
 
+// ---- the prompt pass at MANY rows ------------------------------------------------------------------------------------------------
+// bgemm_kernel is shaped for launch latency: a 32 x 32 tile per block, its four waves split K and meet in LDS, wave 0 writes; a
+// block pulls 320 KB for 8.4 MFLOP (26 FLOP per byte), and one CU sustains ~60 GB/s from L2 / the Infinity Cache (its requests in
+// flight over a ~1.5 us round trip): 9-11 % MFMA utilisation at the thousands of rows of a packed prompt pass
+// (profiles/r04_pmc_prompt_pass_mfma_lds.txt), 8 ms for the first batch of 32 prompts.  bgemm_wide_kernel is the same contraction
+// shaped for that rate:
+//   * a block owns 128 rows x `cpb` column tiles (groups of 8: 256 columns -- 65 FLOP per byte); the rows are staged ONCE in LDS as
+//     bf16 (same coalesced loads, same wave-local LayerNorm, same rounding as the staged form above) and serve every column group
+//     the block walks;
+//   * a wave owns whole column tiles (two per group) over the full K -- no K split, no LDS meeting, every wave writes its tiles --
+//     and streams their weight fragments THREE 8-k-step groups ahead (24 KB per wave, ~96 KB per CU in flight: what 60 GB/s over
+//     that round trip takes; one group ahead measured no faster than bgemm_kernel); an A fragment feeds four MFMAs;
+//   * W2 (K = 2048, bf16 hidden rows) walks four 512-channel chunks of its rows through the same LDS tile.
+// BIT-IDENTICAL to bgemm_kernel, which a request's K/V rows depend on (they must not change with how many prompts were packed into a
+// pass: tests/test_hip_t2s.py::test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16): an output element is the sum, in
+// order, of partial sums over groups of 8 k-steps (128 channels), each accumulated from zero by 8 chained MFMAs -- there a group is
+// a wave and the partials meet in LDS in wave order; here `tot += acc` every 8 k-steps in the same order.
+#ifndef GSV_WIDE_RT
+#define GSV_WIDE_RT 2
+#define GSV_WIDE_TPW 2
+#define GSV_WIDE_PD 3
+#endif
+constexpr int kWideRT = GSV_WIDE_RT, kWideTPW = GSV_WIDE_TPW, kWidePD = GSV_WIDE_PD;
+template <int PRO, typename XT, typename OT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bgemm_wide_kernel(BGemmArgs a) {
+    constexpr int RT = kWideRT, TPW = kWideTPW, PD = kWidePD;
+    constexpr bool XBF = sizeof(XT) == 2;
+    constexpr int LDXS = kD + 8, ROWS = 32 * RT, NCHUNK = XBF ? 4 : 1, KST = NCHUNK * 32;   // bf16 per staged row; k-steps of the contraction
+    static_assert(PRO == PRO_NONE || !XBF, "LayerNorm prologue: fp32 rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
+    bf16_t* xstage = reinterpret_cast<bf16_t*>(wide_lds);                                   // [ROWS][LDXS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, j = lane & 31, hf = lane >> 5;
+    const int rbase = blockIdx.x * ROWS;
+    const int ngroups = XBF ? 1 : max(1, a.cpb / (4 * TPW));          // column groups this block walks (W2: one, its chunks re-stage the tile)
+    const int mtb = blockIdx.y * (XBF ? 4 * TPW : a.cpb);             // the block's first column tile
+    f32x16 tot[TPW][RT];
+
+    auto stage = [&](int c) {
+        if constexpr (!XBF) {
+            const float* X = reinterpret_cast<const float*>(a.X);
+            f32x4 lg[2], lb[2];
+            if constexpr (PRO == PRO_LN) {
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    lg[cc] = *reinterpret_cast<const f32x4*>(a.lng + cc * 256 + lane * 4);
+                    lb[cc] = *reinterpret_cast<const f32x4*>(a.lnb + cc * 256 + lane * 4);
+                }
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < RT; t2 += 2) {
+                // two row tiles' loads in flight at once (16 rows per wave): half the memory round trips of a tile at a time
+                f32x4 xall[2][8][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int grow = min(rbase + 32 * (t2 + u) + wid * 8 + r, a.M - 1);
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) xall[u][r][cc] = *reinterpret_cast<const f32x4*>(X + (size_t)grow * a.ldx + cc * 256 + lane * 4);
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t2 + u;
+                    f32x4 (&xr)[8][2] = xall[u];
+                    if constexpr (PRO == PRO_LN) {
+                        float s8[8], q8[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            s8[r] = 0.f; q8[r] = 0.f;
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { s8[r] += xr[r][cc][i]; q8[r] = fmaf(xr[r][cc][i], xr[r][cc][i], q8[r]); }
+                        }
+                        const float ts = wave_sumN<8>(s8), tq = wave_sumN<8>(q8);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int src = ((r >> 2) & 1) * 32 + ((r >> 1) & 1) * 16 + (r & 1) * 8;
+                            const float rs_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ts), src));
+                            const float rq_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tq), src));
+                            const float mean = rs_ * (1.0f / kD);
+                            const float var = fmaxf(rq_ * (1.0f / kD) - mean * mean, 0.f);
+                            const float rstd = __builtin_amdgcn_rsqf(var + kEps);
+#pragma unroll
+                            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) xr[r][cc][i] = (xr[r][cc][i] - mean) * rstd * lg[cc][i] + lb[cc][i];
+                            const int grow = rbase + 32 * t + wid * 8 + r;
+                            if (blockIdx.y == 0 && a.xout != nullptr && grow < a.M) {
+#pragma unroll
+                                for (int cc = 0; cc < 2; ++cc) *reinterpret_cast<f32x4*>(a.xout + (size_t)grow * kD + cc * 256 + lane * 4) = xr[r][cc];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(xr[r][cc][0], xr[r][cc][1]);
+                            pk.y = pack_bf16x2(xr[r][cc][2], xr[r][cc][3]);
+                            *reinterpret_cast<uint2*>(xstage + (32 * t + wid * 8 + r) * LDXS + cc * 256 + lane * 4) = pk;
+                        }
+                }
+            }
+        } else {
+            const bf16_t* X = reinterpret_cast<const bf16_t*>(a.X);
+            u32x4 xr[RT][8];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int grow = min(rbase + 32 * t + wid * 8 + r, a.M - 1);
+                    xr[t][r] = *reinterpret_cast<const u32x4*>(X + (size_t)grow * a.ldx + c * kD + lane * 8);
+                }
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) *reinterpret_cast<u32x4*>(xstage + (32 * t + wid * 8 + r) * LDXS + lane * 8) = xr[t][r];
+        }
+    };
+
+    for (int cg = 0; cg < ngroups; ++cg) {
+        const int mt0 = mtb + cg * (4 * TPW);
+        if (mt0 >= a.mtiles) break;                                      // block-uniform
+        for (int c = 0; c < NCHUNK; ++c) {
+            if (cg == 0 || NCHUNK > 1) {
+                if (c > 0) __syncthreads();                              // everyone is done with the previous chunk's rows
+                stage(c);
+                __syncthreads();
+            }
+            // ONE flat walk over (tile, 8-k-step group) with the weight fragments of the next PD groups in flight
+            constexpr int NG = TPW * 4;
+            u32x4 wf[PD + 1][8];
+            auto wbase = [&](int n) {
+                const int mt = min(mt0 + (n >> 2) * 4 + wid, a.mtiles - 1);
+                return a.W + ((size_t)mt * KST + c * 32 + (n & 3) * 8) * 64 + lane;
+            };
+#pragma unroll
+            for (int n = 0; n < PD; ++n) {
+                const uint4* wp = wbase(n);
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) wf[n][s8] = __builtin_bit_cast(u32x4, wp[(size_t)s8 * 64]);
+            }
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                const int ti = n >> 2, g = n & 3;
+                // (the fence keeps hipcc from hoisting every later group's loads up here: 64 fragments = 256 registers in flight, and spills)
+                asm volatile("" : : : "memory");
+                if (n + PD < NG) {
+                    const uint4* wp = wbase(n + PD);
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) wf[(n + PD) % (PD + 1)][s8] = __builtin_bit_cast(u32x4, wp[(size_t)s8 * 64]);
+                }
+                asm volatile("" : : : "memory");
+                f32x16 acc[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        const u32x4 bv = *reinterpret_cast<const u32x4*>(xstage + (32 * t + j) * LDXS + (g * 8 + s8) * 16 + hf * 8);
+                        Mma<bf16_t>::run(acc[t], wf[n % (PD + 1)][s8], bv);
+                    }
+                }
+                // the partial sum of this 128-channel group joins the running total (the wave order of bgemm_kernel)
+                if (c == 0 && g == 0) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) tot[ti][t] = acc[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) tot[ti][t][q] += acc[t][q];
+                }
+            }
+        }
+        // ---- epilogue: bias, ReLU, residual, store; lane (j, hf) holds channels mt * 32 + 16 hf + q of row 32 t + j
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+            const int mt = mt0 + ti * 4 + wid;
+            if (mt >= a.mtiles) continue;
+            const int ch = mt * 32 + 16 * hf;
+            f32x4 e_bias[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + ch + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const int row = rbase + 32 * t + j;
+                if (row >= a.M) continue;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    v[q] = tot[ti][t][q];
+                    v[q] += e_bias[q >> 2][q & 3];
+                    if (a.relu) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (a.res) {
+                    const float* rp = a.res + (size_t)row * a.ldres + ch;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rp + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 * g + e] += r4[e];
+                    }
+                }
+                if constexpr (sizeof(OT) == 4) {
+                    float* yp = reinterpret_cast<float*>(a.Y) + (size_t)row * a.ldy + ch;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(yp + 4 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                } else {
+                    bf16_t* yp = reinterpret_cast<bf16_t*>(a.Y) + (size_t)row * a.ldy + ch;
+                    u32x4 oa, ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        oa[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                        ob[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+                    }
+                    *reinterpret_cast<u32x4*>(yp) = oa;
+                    *reinterpret_cast<u32x4*>(yp + 8) = ob;
+                }
+            }
+        }
+    }
+}
+constexpr size_t kWideLds = (size_t)32 * kWideRT * (kD + 8) * sizeof(bf16_t);
+
 // ---- attention of the batched step ------------------------------------------------------------------
 // One block per (head, sequence): append the new K/V row (rounded through the cache type, t2s_model.py:87-88), then
 // softmax(q K^T / sqrt(32)) V over positions [0, kv_len[b]] (the token attends to itself).

@@ -482,8 +482,8 @@ def test_prefill_into_scattered_slots_equals_one_by_one(dev, dtype):
         assert torch.equal(a[key], b[key]), key
 
 
-@pytest.mark.parametrize("nreq,plen", [(6, 130), (26, 190)])
-def test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16(dev, nreq, plen):
+@pytest.mark.parametrize("nreq,plen,dtype", [(6, 130, torch.bfloat16), (26, 190, torch.bfloat16), (26, 190, torch.float32)])
+def test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16(dev, nreq, plen, dtype):
     """A request's K/V rows, first logits and recorded tokens must not depend on how many prompts shared its prompt pass (the slot
     loop's refills and the engine's ranks pack different sets): a packed pass of ~800 rows and one of ~5 000 rows against the same
     prompts one by one, bit for bit.  The second size is the one that FAILED in round 4: from ~2 000 phoneme rows on the BERT
@@ -500,7 +500,7 @@ def test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16(dev, nreq, plen)
     states = []
     for packed in (False, True):
         with torch.inference_mode():
-            m = _model(cfg, w, [(B, 256)], torch.bfloat16, dev)
+            m = _model(cfg, w, [(B, 256)], dtype, dev)
             rt = m._rt[B]
             for t in (rt["kv_len"], rt["x_len"], rt["logits"], rt["pre_tokens"]):
                 t.zero_()
