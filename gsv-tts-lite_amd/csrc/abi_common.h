@@ -322,6 +322,8 @@ int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, voi
     a.cvalid = std::min(ldy, (pc.cout + 15) / 16 * 16); a.in_slope = in_slope;
     auto launch = [&](auto kern, size_t lds, int ms, int bn, int pg, int max_blocks) -> int {
         if (pc.u % pg != 0) return -1;
+        static const int maxb_env = getenv("GSV_WUPS_MAXB") ? atoi(getenv("GSV_WUPS_MAXB")) : 0;   // tuning aid
+        if (maxb_env > 0) max_blocks = maxb_env;
         const int groups = (pc.u / pg) * cdiv(pc.mtiles, ms);
         a.nwalk = std::max(1, std::min(cdiv(n_in, bn), max_blocks / groups));
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -332,10 +334,10 @@ int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, voi
 #define GSV_WUPS(CIN, MS, BN, NT, PG, MAXB)                                                     \
     if (pc.cin == CIN && pc.ntaps == NT && ldx >= CIN)                                           \
         return launch(wups_kernel<CIN, MS, BN, NT, PG>, wups_lds_bytes<CIN, MS, BN, NT, PG>(), MS, BN, PG, MAXB);
-    GSV_WUPS(512, 4, 32, 2, 1, 512)
+    GSV_WUPS(512, 4, 32, 2, 1, 256)     // <= 256 blocks: one block per CU (512 registers), a 257th block is a second round (13.9 -> 11.5 us at 10 s)
     GSV_WUPS(256, 4, 64, 2, 2, 256)
     GSV_WUPS(128, 2, 128, 4, 2, 256)
-    GSV_WUPS(64, 1, 256, 1, 2, 512)
+    GSV_WUPS(64, 1, 256, 1, 2, 256)
     GSV_WUPS(32, 1, 256, 1, 2, 768)
     // 768 -> 384 channels (v2ProPlus stage 0) stays on tapgemm: 96 fragments per wave spill, and its 500 rows per 10 s of
     // audio give a block one tile to amortise a 393 KB weight load over (measured 47 vs 40 us)

@@ -393,12 +393,13 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
 // flight over a ~1.5 us round trip): 9-11 % MFMA utilisation at the thousands of rows of a packed prompt pass
 // (profiles/r04_pmc_prompt_pass_mfma_lds.txt), 8 ms for the first batch of 32 prompts.  bgemm_wide_kernel is the same contraction
 // shaped for that rate:
-//   * a block owns 128 rows x `cpb` column tiles (groups of 8: 256 columns -- 65 FLOP per byte); the rows are staged ONCE in LDS as
+//   * a block owns 32 RT rows (RT = 2: 64) x `cpb` column tiles (groups of 8: 256 columns -- 44 FLOP per byte); the rows are staged ONCE in LDS as
 //     bf16 (same coalesced loads, same wave-local LayerNorm, same rounding as the staged form above) and serve every column group
 //     the block walks;
 //   * a wave owns whole column tiles (two per group) over the full K -- no K split, no LDS meeting, every wave writes its tiles --
 //     and streams their weight fragments THREE 8-k-step groups ahead (24 KB per wave, ~96 KB per CU in flight: what 60 GB/s over
-//     that round trip takes; one group ahead measured no faster than bgemm_kernel); an A fragment feeds four MFMAs;
+//     that round trip takes); an A fragment feeds RT MFMAs.  RT = 4 (128 rows, 65 FLOP per byte) is what the model asks for: hipcc spills
+//     in its unrolled walk and a rolled one measured slower (profiles/r04_prompt_pass_wide.txt);
 //   * W2 (K = 2048, bf16 hidden rows) walks four 512-channel chunks of its rows through the same LDS tile.
 // BIT-IDENTICAL to bgemm_kernel, which a request's K/V rows depend on (they must not change with how many prompts were packed into a
 // pass: tests/test_hip_t2s.py::test_packed_prompt_pass_of_many_rows_equals_one_by_one_bf16): an output element is the sum, in
