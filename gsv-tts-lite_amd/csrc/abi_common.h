@@ -96,7 +96,7 @@ void free_conv(PackedConv& pc) {
 }
 
 struct Epi {
-    const float* add = nullptr; int ld_add = 0;
+    const float* add = nullptr; int ld_add = 0; const int* add_index = nullptr;
     const void* res = nullptr; int ld_res = 0;
     const float* mask = nullptr;
     float scale = 1.0f; int act = ACT_NONE; int accumulate = 0; float in_slope = 1.0f;
@@ -132,7 +132,7 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
                    a.ntaps1 = brs[1].pc->ntaps; a.tstep1 = brs[1].pc->dil; a.tpad1 = brs[1].pc->pad; }
     if (nbr > 2) { a.X2 = brs[2].X; a.W2 = brs[2].pc->w; a.res2 = brs[2].res; a.bias2 = e.use_bias ? brs[2].pc->bias : nullptr; a.Y2 = brs[2].Y;
                    a.ntaps2 = brs[2].pc->ntaps; a.tstep2 = brs[2].pc->dil; a.tpad2 = brs[2].pc->pad; }
-    a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add;
+    a.in_slope = e.in_slope; a.bias = e.use_bias ? pc.bias : nullptr; a.add = e.add; a.ld_add = e.ld_add; a.add_index = e.add_index;
     a.res = brs[0].res; a.ld_res = e.ld_res; a.mask = e.mask; a.scale = e.scale; a.act = e.act;
     a.accumulate = e.accumulate; a.Y = brs[0].Y; a.ldy = ldy; a.n_rows = n_rows;
     // tile choice.  Enough rows to fill the chip several times over -> wide tiles (weights reused

@@ -46,6 +46,7 @@ struct FlowFuseArgs {
     const float* mask;    // [T]
     const float* gc;      // conditioning for this layer's WN: [1 or T][ldg], layer l at +l*384
     int ldg;              // 0 = one broadcast row
+    const int* seg;       // null, or: frame g takes conditioning row seg[g] (few distinct ge columns: voc_kernels.h)
     const uint4* W;       // weight arena (FF_W_*)
     const float* B;       // bias arena (FF_T_*)
     int T;
@@ -297,7 +298,7 @@ static __global__ __launch_bounds__(256, 1) void flowfuse_kernel(FlowFuseArgs a)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { ga[q] = bp[q]; gb[q] = bp[192 + q]; }
                 if (a.ldg != 0) {                          // per-frame conditioning
-                    const float* gp = a.gc + (size_t)g * a.ldg + l * 384 + ch;
+                    const float* gp = a.gc + (size_t)(a.seg ? a.seg[g] : g) * a.ldg + l * 384 + ch;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) { ga[q] += gp[q]; gb[q] += gp[192 + q]; }
                 }

@@ -23,6 +23,7 @@ struct FlowStageArgs {
     const float* mask;    // [T]
     const float* gc;      // this flow's conditioning [1 or T][ldg], WN layer l at + l * 384
     int ldg;              // 0 = one broadcast row
+    const int* seg;       // null, or: frame g takes conditioning row seg[g]
     const uint4* W;       // flowfuse.h weight arena
     const float* B;       // flowfuse.h bias arena
     int T, xin_off, xup_off;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void flowstage_kernel(FlowStageArgs a) {
             if (rok) {
                 const int ch = at * 32 + 16 * hf + 4 * wid;
                 const float* bi = a.B + FF_T_IN + a.l * 384 + ch;
-                const float* gp = a.gc + (a.ldg != 0 ? (size_t)g * a.ldg : 0) + a.l * 384 + ch;
+                const float* gp = a.gc + (a.ldg != 0 ? (size_t)(a.seg ? a.seg[g] : g) * a.ldg : 0) + a.l * 384 + ch;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -389,7 +390,7 @@ static __global__ __launch_bounds__(256) void flowmerge_in_kernel(FlowMergeArgs 
     if (valid) {
         const int ch = at * 32 + 16 * hf + 4 * wid;
         const float* bi = a.B + FF_T_IN + l * 384 + ch;
-        const float* gp = a.gc + (a.ldg != 0 ? (size_t)g * a.ldg : 0) + l * 384 + ch;
+        const float* gp = a.gc + (a.ldg != 0 ? (size_t)(a.seg ? a.seg[g] : g) * a.ldg : 0) + l * 384 + ch;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

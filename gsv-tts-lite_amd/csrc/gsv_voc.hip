@@ -83,12 +83,12 @@ inline int ld_of(int c) { return (c + 15) / 16 * 16; }
 // conditioning GEMV / small-row 1x1 convs (bf16 in, fp32 out): the latency-shaped rowgemm when the
 // contraction is 512 or 1024 channels, else the generic kernel
 template <typename AT>
-int run_cond(const PackedConv& pc, const void* X, int ldx, int rows, float* Y, int ldy, hipStream_t st) {
+int run_cond(const PackedConv& pc, const void* X, int ldx, int rows, float* Y, int ldy, hipStream_t st, const int* rows_dev = nullptr) {
     if (sizeof(AT) == 2 && pc.u == 0 && pc.k == 1 && (pc.cin == 512 || pc.cin == 1024)) {
         RowGemmArgs ra;
         ra.X = X; ra.ldx = ldx; ra.M = rows; ra.W = (const uint4*)pc.w; ra.ksteps = pc.cin / 16; ra.ntaps = 1; ra.pad = 0; ra.mtiles = pc.mtiles;
         ra.bias = pc.bias; ra.relu = 0;
-        ra.Y = Y; ra.ldy = ldy; ra.split_stride = 0;
+        ra.Y = Y; ra.ldy = ldy; ra.split_stride = 0; ra.m_dev = rows_dev;
         const dim3 grid(cdiv(rows, 32), pc.mtiles, 1);
         if (pc.cin == 512) hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 8>), grid, dim3(256), 0, st, ra);
         else hipLaunchKernelGGL((rowgemm_kernel<bf16_t, float, 16>), grid, dim3(256), 0, st, ra);
@@ -103,6 +103,8 @@ struct VocWs {
     // channels-last buffers (element type AT unless noted)
     void *zin, *zflip, *h, *outp, *a, *acts, *ge_cl;
     float *gc, *condbuf;
+    int *seg_flag, *seg_id, *seg_first, *nseg;   // per-frame ge with few distinct columns (voc_kernels.h); seg = null: one row per frame
+    const int* seg;
     void* st[11];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}
     size_t bytes;
 };
@@ -123,6 +125,11 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.ge_cl = take(sizeof(AT) * (size_t)Tg * c.gin_channels);
     w.gc = (float*)take(sizeof(float) * (size_t)Tg * 8 * H * std::max(1, c.n_flows));
     w.condbuf = (float*)take(sizeof(float) * (size_t)Tg * c.upsample_initial_channel);
+    w.seg_flag = (int*)take(sizeof(int) * (size_t)Tg);
+    w.seg_id = (int*)take(sizeof(int) * (size_t)Tg);
+    w.seg_first = (int*)take(sizeof(int) * (size_t)Tg);
+    w.nseg = (int*)take(sizeof(int) * 64);
+    w.seg = nullptr;
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
     for (int i = 0; i < 11; ++i) w.st[i] = take(sizeof(AT) * se);
     w.bytes = off;
@@ -141,7 +148,7 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
     if (v->fused_flow && sizeof(AT) == 2) {
         // one launch for every flow's conditioning, then one fused kernel per coupling layer; no Flip passes
         const int ldg_all = 8 * H * c.n_flows;
-        if (int rc = run_cond<AT>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, st)) return rc;
+        if (int rc = run_cond<AT>(v->cond_all, w.ge_cl, c.gin_channels, Tg, w.gc, ldg_all, st, w.seg ? w.nseg : nullptr)) return rc;
         // few frames: ten short many-CU launches per coupling layer (flowstage.h); many frames: one kernel per layer (flowfuse.h)
         static const int staged_max_T = getenv("GSV_FLOW_STAGED_MAX_T") ? atoi(getenv("GSV_FLOW_STAGED_MAX_T")) : kFlowStagedMaxT;
         if (T <= staged_max_T) {
@@ -152,7 +159,7 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
             auto stage_args = [&](int f) {
                 VocFlow& F = v->flows[f];
                 FlowStageArgs a;
-                a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
+                a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all; a.seg = w.seg;
                 a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
                 a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
                 a.h = (bf16_t*)w.h; a.acts = (bf16_t*)w.acts; a.skip = (float*)w.a; a.outp = (bf16_t*)w.outp;
@@ -207,7 +214,7 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
         for (int f = c.n_flows - 1; f >= 0; --f) {
             VocFlow& F = v->flows[f];
             FlowFuseArgs a;
-            a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all;
+            a.P = (bf16_t*)x; a.mask = mask; a.gc = w.gc + (size_t)f * 8 * H; a.ldg = Tg == 1 ? 0 : ldg_all; a.seg = w.seg;
             a.W = (const uint4*)F.ff_w; a.B = F.ff_b; a.T = T;
             a.xin_off = F.parity ? half : 0; a.xup_off = F.parity ? 0 : half;
             const int nt = cdiv(T, FF_VR), nx = std::min(8, cdiv(nt, 32));
@@ -242,7 +249,7 @@ int voc_flow_impl(gsv_voc* v, VocWs& w, const float* mask, int T, int Tg, hipStr
         Epi ec;
         if (int rc = run_conv<AT, AT, float>(F.cond, w.ge_cl, c.gin_channels, Tg, w.gc, 8 * H, Tg, ec, st)) return rc;
         for (int l = 0; l < 4; ++l) {
-            Epi ei; ei.add = w.gc + (size_t)l * 2 * H; ei.ld_add = Tg == 1 ? 0 : 8 * H;
+            Epi ei; ei.add = w.gc + (size_t)l * 2 * H; ei.ld_add = Tg == 1 ? 0 : 8 * H; ei.add_index = Tg == 1 ? nullptr : w.seg;
             if (int rc = run_conv<AT, AT, AT>(F.in_l[l], w.h, H, T, w.a, 2 * H, T, ei, st)) return rc;
             hipLaunchKernelGGL((gate_kernel<AT>), dim3(ew), dim3(256), 0, st, (const AT*)w.a, (AT*)w.acts, H, T);
             Epi es; es.accumulate = l > 0;
@@ -265,9 +272,9 @@ template <typename AT>
 int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st) {
     const gsv_voc_config& c = v->cfg;
     const int C0 = c.upsample_initial_channel;
-    if (int rc = run_cond<AT>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, st)) return rc;
+    if (int rc = run_cond<AT>(v->cond, w.ge_cl, c.gin_channels, Tg, w.condbuf, C0, st, w.seg ? w.nseg : nullptr)) return rc;
     AT* x = (AT*)w.st[1];
-    Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0;
+    Epi ep; ep.add = w.condbuf; ep.ld_add = Tg == 1 ? 0 : C0; ep.add_index = Tg == 1 ? nullptr : w.seg;
     if (int rc = run_conv<AT, AT, AT>(v->conv_pre, w.zin, c.inter_channels, T, x, ld_of(C0), T, ep, st)) return rc;
     int Tc = T;
     AT* xu = (AT*)w.st[0];
@@ -365,8 +372,19 @@ int voc_prepare(gsv_voc* v, VocWs& w, const float* z, const float* ge, int T, in
     const gsv_voc_config& c = v->cfg;
     hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(T, 32), cdiv(c.inter_channels, 32)), dim3(256), 0, st, z,
                        (AT*)w.zin, c.inter_channels, T, c.inter_channels);
-    hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(c.gin_channels, 32)), dim3(256), 0, st, ge,
-                       (AT*)w.ge_cl, c.gin_channels, Tg, c.gin_channels);
+    // one ge column per frame (a time-concatenated batch): the conditioning runs on the DISTINCT columns, found on the device
+    // (bf16 handles; GSV_NO_GE_SEGMENTS=1 keeps one row per frame -- the A/B switch of tests/test_hip_vocoder.py)
+    if (sizeof(AT) == 2 && Tg > 1 && getenv("GSV_NO_GE_SEGMENTS") == nullptr) {
+        HIPCHK(hipMemsetAsync(w.seg_flag, 0, sizeof(int) * (size_t)Tg, st));
+        hipLaunchKernelGGL(seg_flag_kernel, dim3(cdiv(Tg, 256), cdiv(c.gin_channels, 64)), dim3(256), 0, st, ge, c.gin_channels, Tg, w.seg_flag);
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)w.seg_flag, Tg, w.seg_id, w.seg_first, w.nseg);
+        hipLaunchKernelGGL((seg_gather_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(c.gin_channels, 256)), dim3(256), 0, st, ge, c.gin_channels, Tg,
+                           (const int*)w.seg_first, (const int*)w.nseg, (AT*)w.ge_cl, c.gin_channels);
+        w.seg = w.seg_id;
+    } else {
+        hipLaunchKernelGGL((cf_to_cl_kernel<AT>), dim3(cdiv(Tg, 32), cdiv(c.gin_channels, 32)), dim3(256), 0, st, ge,
+                           (AT*)w.ge_cl, c.gin_channels, Tg, c.gin_channels);
+    }
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }

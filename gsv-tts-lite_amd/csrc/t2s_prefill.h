@@ -336,6 +336,8 @@ struct RowGemmArgs {
     void* Y;              // [nsplit][M][ldy], float or bf16
     int ldy;
     size_t split_stride;  // elements between the partial outputs of consecutive splits
+    const int* m_dev = nullptr;   // or: the live row count on the device (<= M); row tiles past it leave at once (vocoder conditioning on the
+                                  // distinct ge columns: the count is known on the device only)
 };
 
 template <typename XT, typename OT, int KPW = 8>       // KPW: k-steps per wave (ntaps * ksteps = 4 * KPW * nsplit)
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(RowGemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, hf = lane >> 5;
     const int rt = blockIdx.x, mt = blockIdx.y, sp = blockIdx.z;
+    if (a.m_dev != nullptr && rt * 32 >= *a.m_dev) return;      // block-uniform
     const int row = rt * 32 + j;
     const int g0 = (sp * 4 + wid) * KPW;                    // first global k-step of the wave: (tap, k-step) = (g / kpt, g % kpt)
     u32x4 wf[KPW], xf[KPW];

@@ -47,6 +47,7 @@ struct TapGemmArgs {
     const float* bias;   // [cout] or null
     const void* add;     // conditioning term, element type = OT? no: float. [rows or 1][ld_add]
     int ld_add;          // row stride of add (0 = broadcast one row)
+    const int* add_index;// null, or: output row r takes add row add_index[r] (per-frame conditioning with few distinct rows)
     const void* res;     // residual, same type/layout as output (row index n*omul + r), or null
     int ld_res;
     const float* mask;   // [n_out rows] multiplies the result, or null
@@ -468,7 +469,7 @@ static __global__ __launch_bounds__(256, OCC) void tapgemm_kernel(TapGemmArgs a)
             for (int g = 0; g < 4; ++g) {
                 const int m = mt * 32 + 16 * hf + 4 * g;
                 const bool full = m + 4 <= a.cout;
-                if (A) addv[g] = *reinterpret_cast<const f32x4*>(full ? A + (a.ld_add ? orow * (size_t)a.ld_add : (size_t)0) + m : A);
+                if (A) addv[g] = *reinterpret_cast<const f32x4*>(full ? A + (a.ld_add ? (a.add_index ? (size_t)a.add_index[orow] : (size_t)orow) * (size_t)a.ld_add : (size_t)0) + m : A);
                 if (a.accumulate) oldv[g] = Out4<OT>::raw(full ? Y + orow * a.ldy + m : Y);
             }
 #pragma unroll
@@ -509,7 +510,7 @@ static __global__ __launch_bounds__(256, OCC) void tapgemm_kernel(TapGemmArgs a)
                     Out4<OT>::store(yp, v);
                 } else {
                     // ragged channel tail (cout not a multiple of 4): element by element
-                    const float* ap = A ? A + (a.ld_add ? orow * (size_t)a.ld_add : (size_t)0) + m : nullptr;
+                    const float* ap = A ? A + (a.ld_add ? (a.add_index ? (size_t)a.add_index[orow] : (size_t)orow) * (size_t)a.ld_add : (size_t)0) + m : nullptr;
                     for (int e = 0; e < 4 && m + e < a.cout; ++e) {
                         float x = v[e];
                         if (ap) x += ap[e];

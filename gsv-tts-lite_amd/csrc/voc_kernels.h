@@ -22,6 +22,57 @@ __global__ void cf_to_cl_kernel(const float* __restrict__ src, AT* __restrict__ 
     }
 }
 
+// ---- per-frame conditioning with few distinct columns ---------------------------------------------------------------------------
+// A time-concatenated batch (TTS.infer_batched, TTS.py:728-764) hands the vocoder one `ge` column PER FRAME, but the columns of one
+// utterance are all the same: ten utterances are ten distinct columns among thousands.  The conditioning GEMMs (flow: 6 144 outputs,
+// Generator: 512, K = gin) then run on the distinct columns only and every consumer indexes their rows through seg_id[frame].
+// Detection is exact (bit compare of neighbouring columns) and stays on the device: nothing is assumed about the caller's layout.
+// flag[t] |= (column t differs from column t - 1 in this block's 64-channel group); flag[0] = 1.  grid (ceil(T / 256), ceil(C / 64))
+static __global__ __launch_bounds__(256) void seg_flag_kernel(const float* __restrict__ ge, int C, int T, int* __restrict__ flag) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c0 = blockIdx.y * 64;
+    if (t >= T) return;
+    if (t == 0) { if (blockIdx.y == 0) flag[0] = 1; return; }
+    int diff = 0;
+    for (int c = c0; c < min(c0 + 64, C); ++c) {
+        const uint32_t a = __float_as_uint(ge[(size_t)c * T + t]), b = __float_as_uint(ge[(size_t)c * T + t - 1]);
+        diff |= (a != b);
+    }
+    if (diff) atomicOr(flag + t, 1);
+}
+// seg_id[t] = number of flagged frames in [0, t] - 1; seg_first[s] = first frame of segment s; *nseg.  One block of 1024 threads.
+static __global__ __launch_bounds__(1024) void seg_scan_kernel(const int* __restrict__ flag, int T, int* __restrict__ seg_id, int* __restrict__ seg_first,
+                                                                 int* __restrict__ nseg) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (T + 1023) / 1024, lo = tid * per, hi = min(lo + per, T);
+    int n = 0;
+    for (int t = lo; t < hi; ++t) n += flag[t] != 0;
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int id = part[tid] - n;                                  // flagged frames before this thread's range
+    for (int t = lo; t < hi; ++t) {
+        if (flag[t] != 0) { seg_first[id] = t; ++id; }
+        seg_id[t] = id - 1;
+    }
+    if (tid == 1023) *nseg = part[1023];
+}
+// the distinct columns, channels-last: dst[s][c] = ge[c][seg_first[s]] for s < *nseg.  grid (ceil(T / 32), ceil(ld / 256)): blocks past
+// the segment count leave at once
+template <typename AT>
+__global__ __launch_bounds__(256) void seg_gather_cl_kernel(const float* __restrict__ ge, int C, int T, const int* __restrict__ seg_first,
+                                                            const int* __restrict__ nseg, AT* __restrict__ dst, int ld) {
+    const int ns = *nseg, s0 = blockIdx.x * 32;
+    if (s0 >= ns) return;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= ld) return;
+    for (int s = s0; s < min(s0 + 32, ns); ++s) dst[(size_t)s * ld + c] = c < C ? from_f32<AT>(ge[(size_t)c * T + seg_first[s]]) : from_f32<AT>(0.f);
+}
+
 // channels-last AT [T][ld] -> torch channels-first fp32 [C][T]
 template <typename AT>
 __global__ void cl_to_cf_kernel(const AT* __restrict__ src, float* __restrict__ dst, int C, int T, int ld) {

@@ -214,3 +214,38 @@ def test_flow_dec_switches_to_graph_replay_on_a_repeated_length(dev):
     for _ in range(4):       # a long (batched) pass never takes a bucket
         v.flow_dec(torch.zeros(1, 192, v.GRAPH_MAX_FRAMES + 8, device=dev), torch.ones(1, 1, v.GRAPH_MAX_FRAMES + 8, device=dev), ge)
     assert len(v._buckets) == 1
+
+
+def test_per_frame_ge_runs_on_its_distinct_columns(dev):
+    """A time-concatenated batch hands flow_dec one ge column per frame; the library finds the distinct columns on the device and
+    runs the conditioning GEMMs on those only (csrc/voc_kernels.h: seg_*).  The result must equal, bit for bit, the pass that
+    conditions every frame (GSV_NO_GE_SEGMENTS=1) -- for one speaker, for several utterances of different speakers (also with a
+    speaker coming back), for columns that all differ, at a length that takes the staged flow and one that takes the fused kernel."""
+    import os
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps("v2Pro")
+    w = synth.sovits_weights(hps, seed=11, hot_path_only=True)
+    v = _VocoderNative(hps["model"], {k: torch.from_numpy(a) for k, a in w.items()}, torch.bfloat16, dev)
+    g = [torch.from_numpy(synth.synth_ge(i, 1024, 11)).to(dev) for i in range(4)]
+
+    def cols(spec):
+        return torch.cat([g[i].expand(-1, -1, n) for i, n in spec], 2).contiguous()
+    cases = [("one speaker", 300, cols([(0, 300)])),
+             ("three utterances", 700, cols([(0, 250), (1, 130), (2, 320)])),
+             ("a speaker comes back", 2500, cols([(0, 900), (1, 700), (0, 600), (3, 300)])),
+             ("every column differs", 96, torch.randn(1, 1024, 96, device=dev))]
+    for name, T, ge in cases:
+        z = torch.from_numpy(synth.hashed_uniform("seg.z%d" % T, (1, 192, T), 11)).to(dev)
+        m = torch.ones(1, 1, T, device=dev)
+        a = v.flow_dec(z, m, ge)
+        os.environ["GSV_NO_GE_SEGMENTS"] = "1"
+        try:
+            b = v.flow_dec(z, m, ge)
+        finally:
+            del os.environ["GSV_NO_GE_SEGMENTS"]
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b), name
+    # one speaker per frame == the same speaker broadcast (the reference's two ways of saying the same thing)
+    T = 300
+    z = torch.from_numpy(synth.hashed_uniform("seg.z%d" % T, (1, 192, T), 11)).to(dev)
+    m = torch.ones(1, 1, T, device=dev)
+    assert torch.equal(v.flow_dec(z, m, cols([(0, T)])), v.flow_dec(z, m, g[0]))
