@@ -569,10 +569,10 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
                 g.M = M; g.ldx = kD; g.W = (const uint4*)L.g_qkv.w; g.mtiles = 3 * kD / 32; g.cout = 3 * kD; g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
                 if (l == 0) {
                     g.X = x0;
-                    if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, float, float>, false, g)) return rc;
+                    if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, float, bf16_t>, false, g)) return rc;
                 } else {
                     g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
-                    if (int rc = run_wide(bgemm_wide_kernel<PRO_LN, float, float>, false, g)) return rc;
+                    if (int rc = run_wide(bgemm_wide_kernel<PRO_LN, float, bf16_t>, false, g)) return rc;
                 }
             }
             if (!(skip & 2)) attn_launch(l);
@@ -580,7 +580,7 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
                 BGemmArgs g{};
                 g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
                 g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
-                if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, float, float>, false, g)) return rc;
+                if (int rc = run_wide(bgemm_wide_kernel<PRO_NONE, bf16_t, float>, false, g)) return rc;      // the attention's bf16 rows
             }
             if (!(skip & 8)) {   // K4
                 BGemmArgs g{};
@@ -643,13 +643,17 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             BGemmArgs g{};
             g.M = M; g.ldx = kD; g.W = (const uint4*)(f8 ? L.f8_qkv : L.g_qkv.w); g.wscale = L.s_qkv; g.mtiles = 3 * kD / 32; g.cout = 3 * kD;
             g.bias = L.g_qkv.bias; g.Y = c.qkv; g.ldy = 3 * kD;
+            // the prompt pass keeps qkv and the attention rows in bf16: its attention kernel rounds q / k / v to bf16 and the out-proj GEMM
+            // rounds the attention rows to bf16 anyway, so the producers round instead -- the same values, half the bytes (decode step: fp32)
             if (l == 0) {
                 g.X = x0;
                 if (f8) run(bgemm_kernel<PRO_NONE, float, float, 4, true>, 256, g);
+                else if (prompt) run(bgemm_kernel<PRO_NONE, float, bf16_t, 4, false, true>, 256, g);
                 else run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
             } else {
                 g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
                 if (f8) run(bgemm_kernel<PRO_LN, float, float, 4, true>, 256, g);
+                else if (prompt) run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g);
                 else run(bgemm_kernel<PRO_LN, float, float, 4, false, true>, 256, g);
             }
         }
@@ -658,7 +662,8 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             BGemmArgs g{};
             g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
             g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
-            run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
+            if (prompt) run(bgemm_kernel<PRO_NONE, bf16_t, float, 4, false>, 256, g);
+            else run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
         }
         if (!(skip & 8)) {   // K4: [LayerNorm1] -> W1 + bias + ReLU
             BGemmArgs g{};
@@ -771,9 +776,9 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
         c.qkv = qkv; c.attn = attn; c.y1 = ybuf; c.y2 = fbuf; c.x1 = fbuf + (size_t)M * kD; c.hid = fbuf + (size_t)2 * M * kD;
         auto attn_launch = [&](int l) {
             PrefillAttnMfmaArgs pm;
-            pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
+            pm.qkv = (const bf16_t*)qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
             pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
-            pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
+            pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = (bf16_t*)attn;
             hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
         };
         if (int rc = t2s_gemm_chain(h, M, xy, c, false, attn_launch, st, true)) return rc;
@@ -789,13 +794,7 @@ int t2s_prefill_impl(gsv_t2s* h, T2SBound& bd, int slot0, int nrows, int l_max, 
             pa.qkv = qkv; pa.x_lens = x_lens; pa.y_lens = y_lens;
             pa.kc = (WT*)s.k_cache + (size_t)l * layer_elems; pa.vc = (WT*)s.v_cache + (size_t)l * layer_elems;
             pa.T = T; pa.slot0 = slot0; pa.slots = slots; pa.l_max = l_max; pa.qsplit = qsplit; pa.out = attn;
-            if constexpr (sizeof(WT) == 2) {   // bf16 cache: flash attention on the matrix cores
-                PrefillAttnMfmaArgs pm;
-                pm.qkv = qkv; pm.x_lens = x_lens; pm.y_lens = y_lens;
-                pm.kc = (bf16_t*)s.k_cache + (size_t)l * layer_elems; pm.vc = (bf16_t*)s.v_cache + (size_t)l * layer_elems;
-                pm.T = T; pm.slot0 = slot0; pm.slots = slots; pm.l_max = l_max; pm.out = attn;
-                hipLaunchKernelGGL(t2s_prefill_attn_mfma_kernel, dim3(kH, nrows, cdiv(l_max, 128)), dim3(256), lds_mfma, st, pm);
-            } else {
+            {
                 hipLaunchKernelGGL((t2s_prefill_attn_kernel<WT>), dim3(kH, nrows, qsplit), dim3(256), lds, st, pa);
             }
             Epi e1; e1.res = xy; e1.ld_res = kD; e1.fixed_order = true;

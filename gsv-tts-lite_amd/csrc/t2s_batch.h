@@ -415,14 +415,15 @@ template <int PRO, typename XT, typename OT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bgemm_wide_kernel(BGemmArgs a) {
     constexpr int RT = kWideRT, TPW = kWideTPW, PD = kWidePD;
     constexpr bool XBF = sizeof(XT) == 2;
-    constexpr int LDXS = kD + 8, ROWS = 32 * RT, NCHUNK = XBF ? 4 : 1, KST = NCHUNK * 32;   // bf16 per staged row; k-steps of the contraction
+    constexpr int LDXS = kD + 8, ROWS = 32 * RT;                          // bf16 per staged row
+    const int NCHUNK = XBF ? a.ldx / kD : 1, KST = NCHUNK * 32;          // 512-channel chunks of the rows (W2: 4; bf16 attention rows: 1); k-steps of the contraction
     static_assert(PRO == PRO_NONE || !XBF, "LayerNorm prologue: fp32 rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char wide_lds[];
     bf16_t* xstage = reinterpret_cast<bf16_t*>(wide_lds);                                   // [ROWS][LDXS]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, j = lane & 31, hf = lane >> 5;
     const int rbase = blockIdx.x * ROWS;
-    const int ngroups = XBF ? 1 : max(1, a.cpb / (4 * TPW));          // column groups this block walks (W2: one, its chunks re-stage the tile)
-    const int mtb = blockIdx.y * (XBF ? 4 * TPW : a.cpb);             // the block's first column tile
+    const int ngroups = NCHUNK > 1 ? 1 : max(1, a.cpb / (4 * TPW));     // column groups this block walks (W2: one, its chunks re-stage the tile)
+    const int mtb = blockIdx.y * (NCHUNK > 1 ? 4 * TPW : a.cpb);        // the block's first column tile
     f32x16 tot[TPW][RT];
 
     auto stage = [&](int c) {

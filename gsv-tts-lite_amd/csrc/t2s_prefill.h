@@ -157,14 +157,15 @@ __global__ __launch_bounds__(256) void t2s_prefill_attn_kernel(PrefillAttnArgs<W
 // K, V and the scores' Q are rounded to bf16 (what the cache stores / what SDPA does in bf16); softmax
 // statistics and accumulation are fp32.  Masking as t2s_prefill_attn_kernel (appendix A.3).
 struct PrefillAttnMfmaArgs {
-    const float* qkv;    // [nrows][l_max][1536]
+    const bf16_t* qkv;   // [nrows][l_max][1536] bf16: the QKV GEMM's rows, rounded where this kernel used to round them (K / V for the cache,
+                         // Q for the score MFMA) -- the same values, half the bytes written and re-read
     const int64_t* x_lens;
     const int64_t* y_lens;
     bf16_t* kc;          // this layer: [B][16][T][32]
     bf16_t* vc;
     int T, slot0, l_max;
     const int32_t* slots;  // state slot of every row, or null = slot0 + row
-    float* out;          // [nrows][l_max][512]
+    bf16_t* out;         // [nrows][l_max][512] bf16: what the out-proj GEMM stages (it rounded the fp32 rows the same way)
 };
 
 // position of tile-local key kk inside its 32-key group of the permuted V^T row
@@ -191,7 +192,7 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
     unsigned char* Ks = plds;                                // [nkt*32][KRS]
     unsigned char* Qs = Ks + (size_t)nkt * 32 * KRS;         // [128][KRS]
     unsigned char* Vt = Qs + 128 * KRS;                      // [32 d][vrs]
-    const float* base = a.qkv + (size_t)r * a.l_max * 1536;
+    const bf16_t* base = a.qkv + (size_t)r * a.l_max * 1536;
     bf16_t* Kp = a.kc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
     bf16_t* Vp = a.vc + (((size_t)(a.slots ? a.slots[r] : a.slot0 + r) * kH + h) * a.T) * kDh;
     // ---- stage K (rows), V (transposed, permuted), Q (rows): one float4 of 4 d per item.  Four items' loads are in flight before the
@@ -200,13 +201,13 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
     constexpr int SU = 4;
     const int n_items = nkt * 32 * 8;
     for (int e0 = tid; e0 < n_items; e0 += 256 * SU) {
-        f32x4 kv[SU], vv[SU];
+        uint2 kv[SU], vv[SU];
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
             const int e = e0 + u * 256, t = e >> 3, d4 = (e & 7) * 4;
             const int tc = min(t, max(L - 1, 0));
-            kv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)tc * 1536 + 512 + h * 32 + d4);
-            vv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)tc * 1536 + 1024 + h * 32 + d4);
+            kv[u] = *reinterpret_cast<const uint2*>(base + (size_t)tc * 1536 + 512 + h * 32 + d4);
+            vv[u] = *reinterpret_cast<const uint2*>(base + (size_t)tc * 1536 + 1024 + h * 32 + d4);
         }
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -214,8 +215,8 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
             if (e < n_items) {
                 const bool ok = t < L;
                 uint2 kp, vp;
-                kp.x = ok ? pack_bf16x2(kv[u][0], kv[u][1]) : 0u; kp.y = ok ? pack_bf16x2(kv[u][2], kv[u][3]) : 0u;
-                vp.x = ok ? pack_bf16x2(vv[u][0], vv[u][1]) : 0u; vp.y = ok ? pack_bf16x2(vv[u][2], vv[u][3]) : 0u;
+                kp.x = ok ? kv[u].x : 0u; kp.y = ok ? kv[u].y : 0u;
+                vp.x = ok ? vv[u].x : 0u; vp.y = ok ? vv[u].y : 0u;
                 *reinterpret_cast<uint2*>(Ks + (size_t)t * KRS + d4 * 2) = kp;
                 const int pos = (t & ~31) + vpos(t & 31);
                 *reinterpret_cast<bf16_t*>(Vt + (size_t)(d4 + 0) * vrs + pos * 2) = (bf16_t)(vp.x & 0xffff);
@@ -230,19 +231,19 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
         }
     }
     {
-        f32x4 qv[4];
+        uint2 qv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                            // 128 x 8 items = 4 per thread, all in flight
             const int e = tid + u * 256, qi = e >> 3, d4 = (e & 7) * 4;
             const int ic = min(qb0 + qi, max(L - 1, 0));
-            qv[u] = *reinterpret_cast<const f32x4*>(base + (size_t)ic * 1536 + h * 32 + d4);
+            qv[u] = *reinterpret_cast<const uint2*>(base + (size_t)ic * 1536 + h * 32 + d4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + u * 256, qi = e >> 3, d4 = (e & 7) * 4;
             const bool ok = qb0 + qi < L;
             uint2 qp;
-            qp.x = ok ? pack_bf16x2(qv[u][0], qv[u][1]) : 0u; qp.y = ok ? pack_bf16x2(qv[u][2], qv[u][3]) : 0u;
+            qp.x = ok ? qv[u].x : 0u; qp.y = ok ? qv[u].y : 0u;
             *reinterpret_cast<uint2*>(Qs + (size_t)qi * KRS + d4 * 2) = qp;
         }
     }
@@ -307,11 +308,13 @@ static __global__ __launch_bounds__(256) void t2s_prefill_attn_mfma_kernel(Prefi
     l += __shfl_xor(l, 32, 64);
     const float inv = qvalid && l > 0.f ? 1.0f / l : 0.f;
     if (i < a.l_max) {
-        float* op = a.out + ((size_t)r * a.l_max + i) * kD + h * 32;
+        bf16_t* op = a.out + ((size_t)r * a.l_max + i) * kD + h * 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + 8 * g + 4 * hf) = v;
+            uint2 v;
+            v.x = pack_bf16x2(o[4 * g] * inv, o[4 * g + 1] * inv);
+            v.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * g + 4 * hf) = v;
         }
     }
 }
