@@ -836,6 +836,43 @@ __global__ __launch_bounds__(256) void t2s_commit_kernel(CommitArgs a) {
     if (tid == 0) { a.kv_len[s] = a.sg_kv[s]; a.x_len[s] = a.sg_x[s]; a.step[s] = a.sg_step[s]; a.eos_at[s] = a.sg_eos[s]; eos_publish(a.eos_host, s, a.sg_eos[s]); }
 }
 
+
+// A prompt pass that ran AHEAD into another bound state's cache and staging (gsv_t2s_adopt_slots): its K/V rows and its staged
+// state move into slots of the state the steps run on.  The slot pairs ride in the kernel arguments: no device slot list has to
+// be built between two decode windows.
+constexpr int kAdoptMax = 64;
+struct AdoptArgs {
+    short dst[kAdoptMax], src[kAdoptMax];
+    long long ovr[kAdoptMax];         // tok_override of the adopting slot, or < 0: left alone
+    const unsigned char *ks, *vs;     // source cache [n_layer][Bs][16][Ts][32]
+    unsigned char *kd, *vd;           // destination cache [n_layer][Bd][16][Td][32]
+    int Bs, Ts, Bd, Td, esz;
+    const int64_t *sg_kv, *sg_x; const int32_t *sg_step, *sg_eos; const float *sg_logits, *sg_hidden; const TokPart* sg_tok;
+    int64_t *kv_len, *x_len, *tok_override; int32_t *step, *eos_at, *eos_host; float *logits, *hidden; TokPart* tokpart;
+    int V;
+};
+__global__ __launch_bounds__(256) void t2s_adopt_kv_kernel(AdoptArgs a) {
+    const int lh = blockIdx.x, r = blockIdx.y, l = lh / kH, hd = lh % kH;
+    const int ss = a.src[r], ds = a.dst[r];
+    const size_t n16 = (size_t)a.sg_kv[ss] * kDh * a.esz / 16;          // rows [0, kv_len) of the panel are contiguous
+    const size_t so = ((((size_t)l * a.Bs + ss) * kH + hd) * a.Ts) * kDh * a.esz;
+    const size_t d0 = ((((size_t)l * a.Bd + ds) * kH + hd) * a.Td) * kDh * a.esz;
+    const uint4* sp = reinterpret_cast<const uint4*>((blockIdx.z ? a.vs : a.ks) + so);
+    uint4* dp = reinterpret_cast<uint4*>((blockIdx.z ? a.vd : a.kd) + d0);
+    for (size_t i = threadIdx.x; i < n16; i += 256) dp[i] = sp[i];
+}
+__global__ __launch_bounds__(256) void t2s_adopt_state_kernel(AdoptArgs a) {
+    const int ss = a.src[blockIdx.x], s = a.dst[blockIdx.x], tid = threadIdx.x;
+    for (int v = tid; v < a.V; v += 256) a.logits[(size_t)s * a.V + v] = a.sg_logits[(size_t)ss * a.V + v];
+    for (int c = tid; c < kD; c += 256) a.hidden[(size_t)s * kD + c] = a.sg_hidden[(size_t)ss * kD + c];
+    if (tid < kNP) a.tokpart[(size_t)s * kNP + tid] = a.sg_tok[(size_t)ss * kNP + tid];
+    if (tid == 0) {
+        a.kv_len[s] = a.sg_kv[ss]; a.x_len[s] = a.sg_x[ss]; a.step[s] = a.sg_step[ss]; a.eos_at[s] = a.sg_eos[ss];
+        eos_publish(a.eos_host, s, a.sg_eos[ss]);
+        if (a.ovr[blockIdx.x] >= 0) a.tok_override[s] = a.ovr[blockIdx.x];
+    }
+}
+
 }  // namespace
 
 // One class of decode-step kernels (all layers' launches of it) captured into a hipGraph and replayed `iters` times
@@ -1082,6 +1119,35 @@ int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows,
     a.sg_hidden = b->sg_hidden; a.sg_tok = b->sg_tok; a.kv_len = b->st.kv_len; a.x_len = b->st.x_len; a.step = b->st.step; a.eos_at = b->st.eos_at; a.eos_host = b->st.eos_host;
     a.logits = b->st.logits; a.hidden = b->st.hidden; a.tokpart = h->tokpart; a.V = h->cfg.vocab;
     hipLaunchKernelGGL(t2s_commit_kernel, dim3(nrows), dim3(256), 0, S(stream), a);
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int gsv_t2s_adopt_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int batch_src, const int32_t* slots_src,
+                        const int64_t* tok_override, int nrows, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* d = t2s_find(h, batch_dst);
+    T2SBound* sb = t2s_find(h, batch_src);
+    if (!d || !sb) return fail(GSV_ERR_STATE, "no state bound for batch %d", d ? batch_src : batch_dst);
+    if (d == sb) return fail(GSV_ERR_ARG, "adopt_slots: source and destination are the same state");
+    if (!slots_dst || !slots_src || nrows < 1 || nrows > batch_dst || nrows > batch_src) return fail(GSV_ERR_ARG, "adopt_slots: need 1..batch slot pairs (host arrays)");
+    if (d->st.k_cache == sb->st.k_cache || d->st.v_cache == sb->st.v_cache) return fail(GSV_ERR_ARG, "adopt_slots: the two states share their KV cache");
+    for (int i = 0; i < nrows; ++i) {
+        if (slots_dst[i] < 0 || slots_dst[i] >= batch_dst || slots_src[i] < 0 || slots_src[i] >= batch_src) return fail(GSV_ERR_ARG, "adopt_slots: slot out of range");
+        for (int j = 0; j < i; ++j) if (slots_dst[j] == slots_dst[i]) return fail(GSV_ERR_ARG, "adopt_slots: destination slot %d listed twice", slots_dst[i]);
+    }
+    AdoptArgs a;
+    a.ks = (const unsigned char*)sb->st.k_cache; a.vs = (const unsigned char*)sb->st.v_cache; a.kd = (unsigned char*)d->st.k_cache; a.vd = (unsigned char*)d->st.v_cache;
+    a.Bs = batch_src; a.Ts = sb->st.max_kv; a.Bd = batch_dst; a.Td = d->st.max_kv; a.esz = h->cfg.dtype == GSV_F32 ? 4 : 2;
+    a.sg_kv = sb->sg_kv; a.sg_x = sb->sg_x; a.sg_step = sb->sg_step; a.sg_eos = sb->sg_eos; a.sg_logits = sb->sg_logits; a.sg_hidden = sb->sg_hidden; a.sg_tok = sb->sg_tok;
+    a.kv_len = d->st.kv_len; a.x_len = d->st.x_len; a.tok_override = d->st.tok_override; a.step = d->st.step; a.eos_at = d->st.eos_at; a.eos_host = d->st.eos_host;
+    a.logits = d->st.logits; a.hidden = d->st.hidden; a.tokpart = h->tokpart; a.V = h->cfg.vocab;
+    for (int r0 = 0; r0 < nrows; r0 += kAdoptMax) {
+        const int n = std::min(kAdoptMax, nrows - r0);
+        for (int i = 0; i < n; ++i) { a.dst[i] = (short)slots_dst[r0 + i]; a.src[i] = (short)slots_src[r0 + i]; a.ovr[i] = tok_override ? (long long)tok_override[r0 + i] : -1; }
+        hipLaunchKernelGGL(t2s_adopt_kv_kernel, dim3(h->cfg.n_layer * kH, n, 2), dim3(256), 0, S(stream), a);
+        hipLaunchKernelGGL(t2s_adopt_state_kernel, dim3(n), dim3(256), 0, S(stream), a);
+    }
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }

@@ -90,7 +90,11 @@ class Text2SemanticDecoder:
         self.EOS = m["EOS"]
         self.suppressed_tokens = [280, 486, self.EOS]
         self.cuda_graph_buckets = {}
-        self.refill_group = int(os.environ.get("GSV_REFILL_GROUP", "2"))   # staged refill: requests a prompt pass waits for (at most one window)
+        self.refill_group = int(os.environ.get("GSV_REFILL_GROUP", "2"))   # staged refill: requests a prompt pass waits for ...
+        self.refill_wait = int(os.environ.get("GSV_REFILL_WAIT", "1"))     # ... for at most this many windows
+        self.refill_priority = int(os.environ.get("GSV_REFILL_PRIO", "0")) # stream priority of the prompt passes' side stream
+        self.step_priority = int(os.environ.get("GSV_STEP_PRIO", "0"))     # ... and of the stream the slot loop's steps run on
+        self.refill_ahead = int(os.environ.get("GSV_REFILL_AHEAD", "8"))   # async_refill: requests prefilled AHEAD of the slots that will run them (0: the park / prompt pass / commit loop)
         self.use_graph = True
         self.fuse_token_step = os.environ.get("GSV_FUSE_TOKEN", "1") != "0"  # greedy / host-sampled steps: layer 0's attention kernel does the token kernel's work (<= 16 sequences)
         self._eos_pipe = None
@@ -108,7 +112,7 @@ class Text2SemanticDecoder:
         return self
 
     # ------------------------------------------------------------------ runtime
-    _RUNTIME_FIELDS = ("_h", "k_cache_root", "v_cache_root", "_rt", "cuda_graph_buckets", "batched_min", "_ws", "_ws_staged")
+    _RUNTIME_FIELDS = ("_h", "k_cache_root", "v_cache_root", "_rt", "cuda_graph_buckets", "batched_min", "_ws", "_ws_staged", "_ahead")
 
     @torch.inference_mode()
     def initialize_runtime(self, dtype, device, gpt_cache, tune_placement=None):
@@ -124,7 +128,7 @@ class Text2SemanticDecoder:
         cands = []
         try:
             for _ in range(tune_placement):
-                self.cuda_graph_buckets, self._rt, self._ws, self._ws_staged, self._h = {}, {}, None, None, None
+                self.cuda_graph_buckets, self._rt, self._ws, self._ws_staged, self._h, self._ahead = {}, {}, None, None, None, None
                 self._build_runtime(dtype, device, gpt_cache)
                 cands.append((self._time_step(min(self._rt)), {k: getattr(self, k) for k in self._RUNTIME_FIELDS}))
                 self._h = None
@@ -242,6 +246,7 @@ class Text2SemanticDecoder:
             self.cuda_graph_buckets[b] = [Bucket(b, t, rt) for t in ts]
         self._ws = None
         self._ws_staged = None
+        self._ahead = None
         torch.cuda.synchronize(device)
 
     def __del__(self):
@@ -313,6 +318,46 @@ class Text2SemanticDecoder:
         ws = self._ws_staged
         N.check(L.gsv_t2s_prefill_slots_staged(self._h, batch, sl.data_ptr(), n, lmax, xy.data_ptr(), xl.data_ptr(), yl.data_ptr(),
                                                ws.data_ptr(), ws.numel(), stream_ptr))
+
+    def _ahead_state(self, n_slots, max_kv):
+        """a second bound state that is never stepped: the prompt passes of the NEXT requests run into its K/V cache and its
+        staging (gsv_t2s_prefill_slots_staged) while the steps of the live state run; gsv_t2s_adopt_slots moves a finished pass
+        into the slot that takes the request.  Its batch size must differ from every stepped family's (states are keyed by it)
+        and its cache is its own memory (the families' caches alias one root)."""
+        key = (n_slots, max_kv)
+        sh = getattr(self, "_ahead", None)
+        if sh is not None and sh["key"] == key:
+            return sh
+        S = n_slots
+        while S in self._rt:
+            S += 1
+        dev, dh = self.device, self.model_dim // self.num_head
+        kv_dtype = torch.bfloat16 if self.dtype == torch.float8_e4m3fn else self.dtype
+        spec = [("kv_len", (S,), torch.int64), ("x_len", (S,), torch.int64), ("pre_tokens", (S, max_kv + 1), torch.int64),
+                ("seen", (S, self.vocab_size), torch.uint8), ("step", (S,), torch.int32), ("eos_at", (S,), torch.int32),
+                ("logits", (S, self.vocab_size), torch.float32), ("hidden", (S, self.model_dim), torch.float32),
+                ("tok_override", (S,), torch.int64), ("ctl", (8,), torch.int32), ("fctl", (4,), torch.float32)]
+        rt = {"batch": S, "T": max_kv, "key": key, "slots": n_slots,
+              "k": torch.zeros(self.num_layers, S, self.num_head, max_kv, dh, dtype=kv_dtype, device=dev),
+              "v": torch.zeros(self.num_layers, S, self.num_head, max_kv, dh, dtype=kv_dtype, device=dev)}
+        for name, shp, dt in spec:
+            rt[name] = torch.zeros(*shp, dtype=dt, device=dev)
+        rt["eos_at"].fill_(-1)
+        rt["fctl"].fill_(1.0)
+        st = N.T2SState(S, max_kv, *[rt[k].data_ptr() for k in (
+            "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden", "tok_override", "ctl", "fctl")])
+        torch.cuda.synchronize(dev)       # binding may re-allocate the handle's scratch: nothing may be running on it
+        N.check(N.lib().gsv_t2s_bind_state(self._h, ctypes.byref(st)))
+        self._ahead = rt
+        return rt
+
+    def adopt_slots(self, batch, slots, src_batch, src_slots, tok_override=None):
+        """gsv_t2s_adopt_slots on the current stream; the slot lists are host lists (they ride in the kernel arguments)"""
+        n = len(slots)
+        d = (ctypes.c_int32 * n)(*[int(v) for v in slots])
+        sv = (ctypes.c_int32 * n)(*[int(v) for v in src_slots])
+        ov = None if tok_override is None else (ctypes.c_int64 * n)(*[int(v) for v in tok_override])
+        N.check(N.lib().gsv_t2s_adopt_slots(self._h, batch, d, src_batch, sv, ov, n, N.current_stream_ptr(self.device)))
 
     def commit_slots(self, batch, sl):
         N.check(N.lib().gsv_t2s_commit_slots(self._h, batch, sl.data_ptr(), int(sl.numel()), N.current_stream_ptr(self.device)))
@@ -533,7 +578,7 @@ class Text2SemanticDecoder:
         dev = self.device
         cap = max(b.max_kv_cache for b in self.cuda_graph_buckets[B])
         if getattr(self, "_refill_stream", None) is None:
-            self._refill_stream = torch.cuda.Stream(device=dev)
+            self._refill_stream = torch.cuda.Stream(device=dev, priority=self.refill_priority)
         side = self._refill_stream
         main = torch.cuda.current_stream(dev)
         # the requests' inputs (phoneme ids, prompt tokens, BERT rows) were produced on the caller's stream; the side stream
@@ -589,7 +634,7 @@ class Text2SemanticDecoder:
                 return
             # a prompt pass is ~120 launches whatever its row count and takes its share of the chip from the steps: a lone
             # request waits one window for company (costs 1/B of a window's tokens, saves most of a pass)
-            if not force and len(waiting) < self.refill_group and window - waiting_since[0] < 1:
+            if not force and len(waiting) < self.refill_group and window - waiting_since[0] < self.refill_wait:
                 return
             group = waiting[:]
             waiting.clear()
@@ -695,6 +740,197 @@ class Text2SemanticDecoder:
         return pred, torch.tensor(orig, device=dev)
 
     @torch.inference_mode()
+    def _infer_batched_ahead(self, x, y, bert_feature, B, first, nxt, exhausted, first_len, check_interval, on_finish,
+                             max_new_tokens, stream_by_request=False):
+        """The slot loop of t2s_model.py:555-734 with the prompt passes run AHEAD of the slots that will decode them.
+
+        `_infer_batched_staged` starts a request's prompt pass when a slot has finished: the slot idles for the pass and
+        for the windows around it (two to three windows of five steps per refill), and a pass carries the one or two
+        requests whose slots happened to finish together (a pass of one costs what a pass of two costs: ~120 dependent
+        launches).  Here up to `refill_ahead` of the NEXT requests are prefilled, several per pass, on a side stream into a
+        second bound state that is never stepped (`_ahead_state`); a slot that finishes at a window boundary takes a
+        finished one before the next window is issued (gsv_t2s_adopt_slots: its K/V rows and staged state move over, ~10 us)
+        and decodes on.  A prompt pass is row-independent and packing-invariant, so every request's tokens equal the
+        reference-order loop's (tests/test_hip_t2s.py); which slot and window a request gets depends on timing.
+        The window read-back, the budget / full-cache ends and the cut at the first EOS are the staged loop's."""
+        rt = self._rt[B]
+        dev = self.device
+        cap = max(b.max_kv_cache for b in self.cuda_graph_buckets[B])
+        sh = self._ahead_state(max(1, min(self.refill_ahead, B)), cap)
+        S = sh["slots"]
+        for k in ("ctl", "fctl"):
+            sh[k].copy_(rt[k])          # the prompt pass's first logits obey the same control words
+        if getattr(self, "_refill_stream", None) is None:
+            self._refill_stream = torch.cuda.Stream(device=dev, priority=self.refill_priority)
+        side = self._refill_stream
+        main = torch.cuda.current_stream(dev)
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main)       # the requests' inputs and the control words above
+        side.wait_event(inputs_ready)
+        LIVE, EMPTY = 0, 1
+        actual = len(first)
+        state = [LIVE] * actual + [EMPTY] * (B - actual)
+        req = list(first) + [-1] * (B - actual)
+        start = list(first_len) + [0] * (B - actual)
+        steps = [0] * B
+        joined = [0] * B
+        if actual < B:
+            rt["kv_len"][actual:] = -1
+        pred, orig = [], []
+        free_src = list(range(S))       # slots of the ahead state holding nothing
+        ready: list = []                # (source slot, request, prompt length, completion event of its pass), oldest first
+        inflight = [None]               # completion event of the one prompt pass that may be running
+        adopted_ev = [None]             # behind the last adopt: a later pass may overwrite the source slots it read
+        window = 0
+        to_cut: list = []               # (window, slot, request, saved tokens, most tokens)
+        snap_host = torch.empty((2, 2, B), dtype=torch.int64).pin_memory()
+        snaps: list = []
+        keep: list = []                 # tensors of the pass in flight
+        self.last_stats = {"slots": B, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0, "passes": 1}
+
+        def top_up(force=False):
+            """one packed prompt pass for the next requests, into the free slots of the ahead state"""
+            nonlocal exhausted
+            if exhausted or not free_src:
+                return
+            if inflight[0] is not None:
+                if force:
+                    inflight[0].synchronize()
+                elif not inflight[0].query():
+                    return
+                inflight[0] = None
+                keep.clear()
+            if not force and len(free_src) < max(1, S // 2) and ready:
+                return                  # a pass of few rows costs what a pass of many costs: wait until half the slots are free
+            group = []
+            while free_src and not exhausted:
+                cur = nxt()
+                if cur is None:
+                    exhausted = True
+                    break
+                n_new = int(x[cur].shape[0]) + int(y[cur].shape[0])
+                if n_new > cap - 1:
+                    raise ValueError("prompt longer than the largest KV bucket")
+                group.append((free_src.pop(0), cur, n_new))
+            if not group:
+                return
+            rq = [c for _, c, _ in group]
+            with torch.cuda.stream(side):
+                xy1, xl1, yl1, _, _ = self.embed_prompt([x[c] for c in rq], [y[c] for c in rq], [bert_feature[c] for c in rq])
+                sl = torch.tensor([i for i, _, _ in group], dtype=torch.int32, device=dev)
+                if adopted_ev[0] is not None:
+                    side.wait_event(adopted_ev[0])
+                self.prefill_slots_staged(sh["batch"], sl, xy1, xl1, yl1, side.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(side)
+            keep.extend((xy1, xl1, yl1, sl))
+            inflight[0] = done
+            for i, c, n_new in group:
+                ready.append((i, c, n_new, done, window))
+            self.last_stats["refills"] += len(group)
+            self.last_stats["prefill_rows"] += len(group)
+            self.last_stats["passes"] += 1
+
+        def fill(block=False):
+            """empty slots take finished prompt passes, oldest first, before the next window is issued"""
+            empty = [i for i in range(B) if state[i] == EMPTY]
+            take = []
+            while empty and ready:
+                src, cur, n_new, done, launched = ready[0]
+                if not done.query():
+                    # the steps' stream may wait for a pass that has had a window to run (it ends inside the wait, if at all);
+                    # a younger one would stall every slot for most of its ~1 ms: the slot idles this window instead
+                    if not block and window - launched < 1:
+                        break
+                main.wait_event(done)
+                ready.pop(0)
+                take.append((empty.pop(0), src, cur, n_new))
+            if not take:
+                return
+            self.adopt_slots(B, [i for i, _, _, _ in take], sh["batch"], [s_ for _, s_, _, _ in take],
+                             [c + 1 for _, _, c, _ in take] if stream_by_request else None)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            adopted_ev[0] = ev
+            for i, src, cur, n_new in take:
+                state[i], req[i], steps[i], start[i], joined[i] = LIVE, cur, 0, n_new, window
+                free_src.append(src)
+
+        def collect(r, seg):
+            pred.append(seg)
+            orig.append(r)
+            if on_finish is not None:
+                on_finish(r, seg)
+
+        def vacate(i):
+            rt["kv_len"][i] = -1        # parked: the step leaves the slot's rows and state alone
+            state[i], req[i] = EMPTY, -1
+
+        def examine(window, buf, ev):
+            ev.synchronize()
+            kv_s, eos_s = snap_host[buf].tolist()
+            for rec in [c for c in to_cut if c[0] == window]:
+                _, i, r, saved, n_max = rec
+                e = eos_s[i]
+                collect(r, saved[: max(0, n_max if e < 1 else min(n_max, e - 1))].clone())
+                to_cut.remove(rec)
+            for i in range(B):
+                if state[i] == LIVE and joined[i] <= window and eos_s[i] >= 0:
+                    collect(req[i], rt["pre_tokens"][i, start[i] + 1: start[i] + 1 + max(0, eos_s[i] - 1)].clone())
+                    vacate(i)
+
+        top_up(force=True)
+        idx = 0
+        while True:
+            live = any(st == LIVE for st in state)
+            if not live:
+                while snaps:
+                    examine(*snaps.pop(0))
+            fill(block=not live)
+            live = any(st == LIVE for st in state)
+            if not live:
+                if ready:
+                    continue
+                top_up(force=True)
+                if ready:
+                    continue
+                break
+            n = 1 if idx == 0 else min(check_interval, 1000 - idx)
+            self._decode(B, n)
+            self._flush(B)
+            idx = 0 if idx + n >= 1000 else idx + n
+            buf = window & 1
+            snap_host[buf].copy_(torch.stack([rt["kv_len"], rt["eos_at"].to(torch.int64)]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.last_stats["steps"] += n
+            for i in range(B):
+                if state[i] == LIVE:
+                    steps[i] += n
+                    self.last_stats["kv_rows"] += (start[i] + steps[i]) * n
+            for i in range(B):
+                if state[i] != LIVE:
+                    continue
+                budget = None if max_new_tokens is None else int(max_new_tokens[req[i]])
+                full = start[i] + steps[i] + check_interval >= cap
+                if full or (budget is not None and steps[i] - 1 >= budget):
+                    n_max = steps[i] - 1 if budget is None else min(steps[i] - 1, budget)
+                    # the slot may decode another request from the next window on: its tokens are saved now (behind this
+                    # window's steps on the stream), cut at the first EOS when the window's read-back is in
+                    saved = rt["pre_tokens"][i, start[i] + 1: start[i] + 1 + max(0, n_max)].clone()
+                    to_cut.append((window, i, req[i], saved, n_max))
+                    vacate(i)
+            snaps.append((window, buf, ev))
+            top_up()
+            while len(snaps) > 1:
+                examine(*snaps.pop(0))
+            window += 1
+        for sn in snaps:
+            examine(*sn)
+        assert not to_cut and not ready
+        return pred, torch.tensor(orig, device=dev)
+
+    @torch.inference_mode()
     def infer_batched(self, x: List[torch.Tensor], y: List[torch.Tensor], bert_feature: List[torch.Tensor],
                       top_k: int = 15, top_p: float = 1.0, temperature: float = 1.0,
                       repetition_penalty: float = 1.35, check_interval: int = 5, generator=None,
@@ -710,6 +946,22 @@ class Text2SemanticDecoder:
         request i once it has produced that many tokens -- tested at the same 5-step cadence as EOS, cut exactly.
         `async_refill` (not in the reference, whose slots all wait while a refill's prompt pass runs, :696-722) runs the
         slot loop of `_infer_batched_staged` instead: same requests, same tokens per request, no stall."""
+        if async_refill and self.step_priority != 0 and not getattr(self, "_in_step_stream", False):
+            # the slot loop on a stream of its own priority (the steps are a chain of short dependent launches: whatever a
+            # launch waits for behind a prompt pass's blocks is on the critical path, the prompt pass itself is not)
+            if getattr(self, "_step_stream", None) is None:
+                self._step_stream = torch.cuda.Stream(device=self.device, priority=self.step_priority)
+            cur = torch.cuda.current_stream(self.device)
+            self._step_stream.wait_stream(cur)
+            self._in_step_stream = True
+            try:
+                with torch.cuda.stream(self._step_stream):
+                    out = self.infer_batched(x, y, bert_feature, top_k, top_p, temperature, repetition_penalty, check_interval,
+                                             generator, source, slots, on_finish, max_new_tokens, async_refill)
+            finally:
+                self._in_step_stream = False
+                cur.wait_stream(self._step_stream)
+            return out
         B = len(x)
         sizes = sorted(self.cuda_graph_buckets)
         if slots is not None:
@@ -743,6 +995,9 @@ class Text2SemanticDecoder:
             return [], torch.zeros(0, dtype=torch.int64, device=dev)
         mode, seed = self._sampling_mode(top_k, top_p, generator)
         greedy = mode != 1
+        if async_refill and mode != 1 and self.refill_ahead > 0:
+            # bound BEFORE the first prompt pass: binding a state may re-allocate the handle's per-slot scratch (pending tokens)
+            self._ahead_state(max(1, min(self.refill_ahead, batch_size)), max(caps))
         self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed, top_p)
         rt["kv_len"].zero_()
         rt["x_len"].zero_()
@@ -763,7 +1018,8 @@ class Text2SemanticDecoder:
             rt["tok_override"][:actual] = torch.tensor([c + 1 for c in first], dtype=torch.int64, device=dev)
         if async_refill and mode != 1:      # host-sampled tokens need every refill's logits at once: reference order
             try:
-                return self._infer_batched_staged(x, y, bert_feature, batch_size, first, nxt, exhausted,
+                loop = self._infer_batched_ahead if self.refill_ahead > 0 else self._infer_batched_staged
+                return loop(x, y, bert_feature, batch_size, first, nxt, exhausted,
                                                   [int(a) + int(b) for a, b in zip(x_lens_h, y_lens_h)], check_interval,
                                                   on_finish, max_new_tokens, mode == 2)
             finally:    # also on an exception (a prompt that does not fit): no prompt pass may outlive the call

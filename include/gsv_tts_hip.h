@@ -146,6 +146,19 @@ int gsv_t2s_prefill_slots_staged(gsv_t2s* h, int batch, const int32_t* slots, in
                                  void* stream);
 int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows, void* stream);
 
+/* Prompt passes AHEAD of the slots that will decode them (continuous batching whose refills cost no idle slot-steps; the
+ * reference prefills a request when a slot has finished, t2s_model.py:696-722, and every slot waits for it).  Bind a SECOND
+ * state of another batch size (`batch_src`, with a KV cache of its own, never stepped) and run the prompt passes of the
+ * NEXT requests into it with gsv_t2s_prefill_slots_staged on a side stream, several requests per pass, while the steps of
+ * `batch_dst` run.  When a slot of `batch_dst` has finished, this call -- on the step's stream, after the pass's completion
+ * event -- copies K/V rows [0, kv_len) of source slot slots_src[r] into slot slots_dst[r] and moves the staged kv_len,
+ * x_len, step, eos_at, first logits / hidden / pending token into the live state of slots_dst[r]; the next step decodes it.
+ * slots_dst / slots_src / tok_override are HOST arrays [nrows] (they ride in the kernel arguments); tok_override (may be
+ * NULL) sets state.tok_override[slots_dst[r]] (device sampling: the request's noise stream).  A prompt pass is
+ * row-independent and packing-invariant, so a request's tokens do not depend on when or beside what it was prefilled. */
+int gsv_t2s_adopt_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int batch_src, const int32_t* slots_src,
+                        const int64_t* tok_override, int nrows, void* stream);
+
 /* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
  * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
  * final hidden state to state.hidden and bumps kv_len.  No sampling.  Takes the path gsv_t2s_decode would take for

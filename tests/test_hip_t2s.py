@@ -594,11 +594,17 @@ def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_
         return {int(i): p.cpu().numpy() for i, p in zip(idx.tolist(), pred)}, dict(m.last_stats)
 
     ref, st0 = run()
-    for rep in range(2):        # twice: the staging / parked state of one run must not leak into the next
-        got, st1 = run(async_refill=True)
-        assert st1["refills"] == st0["refills"] == n_req - slots
-        for i in range(n_req):
-            assert np.array_equal(got[i], ref[i]), (rep, i)
+    # refill_ahead > 0 (the default): the NEXT requests' prompt passes run ahead into a second bound state, several per pass, and a
+    # finished slot adopts one (gsv_t2s_adopt_slots); 0: park -> prompt pass into the live rows -> commit.  3: fewer ahead slots than finishers
+    for ahead in (m.refill_ahead, 3, 0):
+        m.refill_ahead = ahead
+        for rep in range(2):        # twice: the staging / parked state of one run must not leak into the next
+            got, st1 = run(async_refill=True)
+            assert st1["refills"] == st0["refills"] == n_req - slots
+            for i in range(n_req):
+                assert np.array_equal(got[i], ref[i]), (ahead, rep, i)
+        if ahead > 3:
+            assert st1["passes"] <= st1["refills"] // 2 + 2, st1    # at least two requests per prompt pass (half the ahead slots)
     again, _ = run()
     for i in range(n_req):
         assert np.array_equal(again[i], ref[i])
