@@ -525,9 +525,20 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     static const int force_cpb = getenv("GSV_CHAIN_CPB") ? atoi(getenv("GSV_CHAIN_CPB")) : 0;   // scan aid
     int cpb = 1;
     if (prompt) cpb = force_cpb > 0 ? force_cpb : (rtiles < 40 ? 2 : (rtiles < 100 ? 4 : 8));
-    auto run = [&](auto kern, int nthreads, BGemmArgs ba) {
-        ba.cpb = cpb;
-        hipLaunchKernelGGL(kern, dim3(rtiles, cdiv(ba.mtiles, cpb)), dim3(nthreads), 0, st, ba);
+    // per launch (scan aid): GSV_CPB_K1 / K3 / K4 / K5 = column tiles per block of the QKV / out-proj / W1 / W2 launch of a prompt pass
+    static const int cpb_k[4] = {getenv("GSV_CPB_K1") ? atoi(getenv("GSV_CPB_K1")) : 0, getenv("GSV_CPB_K3") ? atoi(getenv("GSV_CPB_K3")) : 0,
+                                 getenv("GSV_CPB_K4") ? atoi(getenv("GSV_CPB_K4")) : 0, getenv("GSV_CPB_K5") ? atoi(getenv("GSV_CPB_K5")) : 0};
+    auto run = [&](auto kern, int nthreads, BGemmArgs ba, int which = -1) {
+        // per launch (profiles/r04_prompt_pass_cpb.txt): the out-proj and W2 launches have 16 column tiles only -- at up to ~20 row tiles (one or two
+        // prompts) a tile per block (128 blocks pulling half the weights each) is 0.95 -> 0.88 ms per pass; QKV and W1 at 21-39 row tiles: four
+        int cb = cpb;
+        if (prompt && which >= 0) {
+            if (rtiles <= 20 && (which == 1 || which == 3)) cb = 1;
+            if (rtiles > 20 && rtiles < 40 && (which == 0 || which == 2)) cb = 4;
+            if (cpb_k[which] > 0) cb = cpb_k[which];
+        }
+        ba.cpb = cb;
+        hipLaunchKernelGGL(kern, dim3(rtiles, cdiv(ba.mtiles, cb)), dim3(nthreads), 0, st, ba);
     };
     // few rows (the decode step at 17 .. kSmallMaxM sequences, bf16 operands): 16 x 16 tiles, one wave per channel tile (t2s_small.h)
     static const bool no_small = getenv("GSV_NO_SMALL_CHAIN") != nullptr;   // A/B switch
@@ -648,12 +659,12 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             if (l == 0) {
                 g.X = x0;
                 if (f8) run(bgemm_kernel<PRO_NONE, float, float, 4, true>, 256, g);
-                else if (prompt) run(bgemm_kernel<PRO_NONE, float, bf16_t, 4, false, true>, 256, g);
+                else if (prompt) run(bgemm_kernel<PRO_NONE, float, bf16_t, 4, false, true>, 256, g, 0);
                 else run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
             } else {
                 g.X = c.y2; g.lng = h->layers[l - 1].ln2g; g.lnb = h->layers[l - 1].ln2b; g.xout = x0;
                 if (f8) run(bgemm_kernel<PRO_LN, float, float, 4, true>, 256, g);
-                else if (prompt) run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g);
+                else if (prompt) run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g, 0);
                 else run(bgemm_kernel<PRO_LN, float, float, 4, false, true>, 256, g);
             }
         }
@@ -662,7 +673,7 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             BGemmArgs g{};
             g.M = M; g.X = c.attn; g.ldx = kD; g.W = (const uint4*)L.g_out.w; g.mtiles = kD / 32; g.cout = kD; g.bias = L.bo;
             g.res = x0; g.ldres = kD; g.Y = c.y1; g.ldy = kD;
-            if (prompt) run(bgemm_kernel<PRO_NONE, bf16_t, float, 4, false>, 256, g);
+            if (prompt) run(bgemm_kernel<PRO_NONE, bf16_t, float, 4, false>, 256, g, 1);
             else run(bgemm_kernel<PRO_NONE, float, float, 4, false, true>, 256, g);
         }
         if (!(skip & 8)) {   // K4: [LayerNorm1] -> W1 + bias + ReLU
@@ -671,14 +682,14 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
             g.W = (const uint4*)(f8 ? L.f8_w1 : L.g_w1.w); g.wscale = L.s_w1; g.mtiles = kF / 32; g.cout = kF; g.bias = L.b1; g.relu = 1;
             g.Y = c.hid; g.ldy = kF;
             if (f8) run(bgemm_kernel<PRO_LN, float, fp8_t, 4, true>, 256, g);
-            else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g);
+            else run(bgemm_kernel<PRO_LN, float, bf16_t, 4, false, true>, 256, g, 2);
         }
         if (!(skip & 16)) {   // K5: W2 over the full K + bias + residual -> pre-LN2
             BGemmArgs g{};
             g.M = M; g.X = c.hid; g.ldx = kF; g.W = (const uint4*)(f8 ? L.f8_w2 : L.g_w2.w); g.wscale = L.s_w2; g.mtiles = kD / 32; g.cout = kD;
             g.bias = L.b2; g.res = c.x1; g.ldres = kD; g.Y = c.y2; g.ldy = kD;
             if (f8) run(bgemm_kernel<PRO_NONE, fp8_t, float, 16, true>, 1024, g);
-            else run(bgemm_kernel<PRO_NONE, bf16_t, float, 16, false>, 1024, g);
+            else run(bgemm_kernel<PRO_NONE, bf16_t, float, 16, false>, 1024, g, 3);
         }
     }
     HIPCHK(hipGetLastError());

@@ -630,6 +630,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     float m_run = -INFINITY, l_run = 0.f, acc[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wid) == 0;
     for (int c0 = 0; c0 == 0 || c0 < n; c0 += KCH * RPI) {
         if (c0 > 0) {
 #pragma unroll
@@ -656,7 +657,11 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
             sv[it] = r < n ? s * scale : -INFINITY;
             cmax = max_nn(cmax, sv[it]);
         }
-        {   // the new token's own key/value (position n) rides with wave 0's first chunk
+        // the new token's own key/value (position n) rides with wave 0's first chunk; the other waves (fifteen of sixteen, all
+        // of them VALU-issue bound here) skip its score, exponential and eight FMAs, which contributed exact zeros
+        const bool own = wave0 && c0 == 0;
+        sv[KCH] = -INFINITY;
+        if (own) {
             float s = 0.f;
             if constexpr (BF) {
                 s = dot8(*reinterpret_cast<const raw16*>(kn + part * 8), qp);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
                 for (int i = 0; i < EPL; ++i) s = fmaf(qr[i], qkv[32 + part * EPL + i], s);
             }
             s = group_sum<LPR>(s);
-            sv[KCH] = (c0 == 0 && tid < LPR) ? s * scale : -INFINITY;
+            sv[KCH] = tid < LPR ? s * scale : -INFINITY;
             cmax = max_nn(cmax, sv[KCH]);
         }
         cmax = wave_max(cmax);
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
             for (int i = 0; i < EPL; ++i) acc[i] = fmaf(p, vv[i], acc[i]);
         }
-        {
+        if (own) {
             const float p = sm_exp<BF>(sv[KCH] - mref);
             if (part == 0) l_run += p;
 #pragma unroll
