@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 for ver in (sys.argv[1:] or ["v2Pro", "v2ProPlus"]):
     hps = synth.sovits_hps(ver)
     sw = synth.sovits_weights(hps, seed=1234, hot_path_only=True)
-    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.bfloat16, dev)
+    voc = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.float32 if os.environ.get("GSV_VOC_DTYPE") == "fp32" else torch.bfloat16, dev)
     for T, per_frame in ((500, False), (5800, True)):
         ge = torch.from_numpy(synth.synth_ge(0, hps["model"]["gin_channels"])).to(dev)
         if per_frame:
