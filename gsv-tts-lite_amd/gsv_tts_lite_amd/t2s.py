@@ -268,18 +268,26 @@ class Text2SemanticDecoder:
         [x_b | y_b | 0-pad] -> (xy float32 [n, Lmax, D], x_lens, y_lens)."""
         n = len(xs)
         dev = self.device
-        x_lens = torch.tensor([int(t.shape[0]) for t in xs], dtype=torch.int64)
-        y_lens = torch.tensor([int(t.shape[0]) for t in ys], dtype=torch.int64)
-        lx, ly = int(x_lens.max()), int(y_lens.max())
-        lmax = int((x_lens + y_lens).max())
-        xi = torch.zeros(n, lx, dtype=torch.int64, device=dev)
-        yi = torch.zeros(n, ly, dtype=torch.int64, device=dev)
-        bt = torch.zeros(n, lx, 1024, dtype=torch.float32, device=dev)
-        for i in range(n):
-            xi[i, : x_lens[i]] = xs[i].to(dev)
-            yi[i, : y_lens[i]] = ys[i].to(dev)
-            bt[i, : x_lens[i]] = berts[i].to(device=dev, dtype=torch.float32)
-        xl, yl = x_lens.to(dev), y_lens.to(dev)
+        xln, yln = [int(t.shape[0]) for t in xs], [int(t.shape[0]) for t in ys]
+        lens = torch.tensor([xln, yln], dtype=torch.int64)
+        x_lens, y_lens = lens[0], lens[1]
+        lx, ly = max(xln), max(yln)
+        lmax = max(a + b for a, b in zip(xln, yln))
+        if n == 1:
+            # one request (TTFT): nothing to pad -- the inputs are the rows (no zero-fill and three slice copies in front of the first launch)
+            xi = xs[0].to(device=dev, dtype=torch.int64).reshape(1, lx).contiguous()
+            yi = ys[0].to(device=dev, dtype=torch.int64).reshape(1, ly).contiguous()
+            bt = berts[0].to(device=dev, dtype=torch.float32).reshape(1, lx, 1024).contiguous()
+        else:
+            xi = torch.zeros(n, lx, dtype=torch.int64, device=dev)
+            yi = torch.zeros(n, ly, dtype=torch.int64, device=dev)
+            bt = torch.zeros(n, lx, 1024, dtype=torch.float32, device=dev)
+            for i in range(n):
+                xi[i, : xln[i]] = xs[i].to(dev)
+                yi[i, : yln[i]] = ys[i].to(dev)
+                bt[i, : xln[i]] = berts[i].to(device=dev, dtype=torch.float32)
+        lens_d = lens.to(dev)           # one host-to-device copy for both length vectors
+        xl, yl = lens_d[0], lens_d[1]
         xy = torch.empty(n, lmax, self.model_dim, dtype=torch.float32, device=dev)
         scratch = torch.empty(n * lx, self.model_dim, dtype=torch.float32, device=dev)
         N.check(N.lib().gsv_t2s_embed_prompt(self._h, n, lx, ly, lmax, xi.data_ptr(), yi.data_ptr(), bt.data_ptr(),
