@@ -616,6 +616,68 @@ def test_staged_refill_returns_the_same_tokens_per_request(dev, dtype, slots, n_
             assert np.array_equal(ref[int(i)], p)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@torch.inference_mode()
+def test_adopt_slots_equals_a_prompt_pass_into_the_slots(dev, dtype):
+    """gsv_t2s_adopt_slots: a prompt pass run AHEAD into a second bound state (its own K/V cache, the library's staging), then
+    adopted by slots of the stepped state, leaves those slots exactly as gsv_t2s_prefill_slots into them does -- K/V rows, kv_len,
+    x_len, step, eos_at, first logits / hidden -- and the steps that follow produce the same tokens; bad arguments are refused."""
+    from gsv_tts_lite_amd import _native as N
+    import ctypes
+    cfg = synth.gpt_config(n_layer=3)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=5, eos_gain=0.0), [(4, 96)], dtype, dev)
+    rt = m._rt[4]
+    reqs = [synth.synth_request(40 + i, 5, 9 + 4 * i, 12 + 5 * i, seed=5, bert="random") for i in range(2)]
+    X, Y, Bt = [_T(r[0], dev) for r in reqs], [_T(r[1], dev) for r in reqs], [_T(r[2], dev) for r in reqs]
+    L = [len(r[0]) + len(r[1]) for r in reqs]
+    slots = [3, 1]
+
+    def snapshot():
+        m._decode(4, 4); m._flush(4)
+        torch.cuda.synchronize()
+        out = {k: rt[k][slots].clone() for k in ("kv_len", "x_len", "step", "eos_at", "logits", "hidden")}
+        out["tok"] = torch.stack([rt["pre_tokens"][s, L[j]: L[j] + 5] for j, s in enumerate(slots)])
+        out["k"] = [rt["k"][:, s, :, : L[j] + 4].clone() for j, s in enumerate(slots)]
+        out["v"] = [rt["v"][:, s, :, : L[j] + 4].clone() for j, s in enumerate(slots)]
+        return out
+
+    def reset():
+        m._set_ctl(rt, 0, 0, False, 1.0)
+        rt["kv_len"].fill_(-1); rt["x_len"].zero_(); rt["k"].zero_(); rt["v"].zero_(); rt["pre_tokens"].zero_()
+
+    reset()
+    xy, xl, yl, _, _ = m.embed_prompt(X, Y, Bt)
+    m.prefill_slots(4, slots, xy, xl, yl)
+    want = snapshot()
+
+    reset()
+    sh = m._ahead_state(2, 96)
+    assert sh["batch"] != 4 and sh["k"].data_ptr() != rt["k"].data_ptr()
+    for k in ("ctl", "fctl"):
+        sh[k].copy_(rt[k])
+    xy, xl, yl, _, _ = m.embed_prompt(X, Y, Bt)
+    src = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+    m.prefill_slots_staged(sh["batch"], src, xy, xl, yl, N.current_stream_ptr(dev))
+    assert int(rt["kv_len"][3]) == -1                       # nothing of the stepped state was touched by the pass
+    m.adopt_slots(4, slots, sh["batch"], [1, 0])
+    got = snapshot()
+    for k in ("kv_len", "x_len", "step", "eos_at", "tok"):
+        assert torch.equal(got[k], want[k]), k
+    for k in ("logits", "hidden"):
+        assert torch.equal(got[k], want[k]), k
+    for j in range(2):
+        assert torch.equal(got["k"][j], want["k"][j]) and torch.equal(got["v"][j], want["v"][j]), j
+
+    lib, h = N.lib(), m._h
+    i32 = lambda *v: (ctypes.c_int32 * len(v))(*v)
+    st = N.current_stream_ptr(dev)
+    assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), 4, i32(0), None, 1, st) != 0                   # the same state
+    assert lib.gsv_t2s_adopt_slots(h, 4, i32(4), sh["batch"], i32(0), None, 1, st) != 0         # destination out of range
+    assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), sh["batch"], i32(sh["batch"]), None, 1, st) != 0
+    assert lib.gsv_t2s_adopt_slots(h, 4, i32(1, 1), sh["batch"], i32(0, 1), None, 2, st) != 0   # one slot twice
+    assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), 77, i32(0), None, 1, st) != 0                  # no such state
+
+
 def test_staged_refill_cuts_a_full_cache_like_the_reference_order_loop(dev):
     """requests that never sample EOS end when kv + check_interval reaches the cache size at a 5-step window boundary
     (t2s_model.py:655-657); where that boundary falls depends on the window a slot was filled at, so the staged loop may cut

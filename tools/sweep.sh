@@ -21,6 +21,7 @@ run timeout 900 python $R/bench.py --workload cb --version v2ProPlus > $O/cb_con
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --sync-refill --no-cpu-baseline > $O/cb_configs2_sync_refill.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --lpt-budget --no-cpu-baseline > $O/cb_configs2_lpt_budget.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32.json 2> /dev/null
+GSV_REFILL_AHEAD=0 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32_staged_loop.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --no-cpu-baseline > $O/cb_bf16_bs64.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --dtype fp8 --no-cpu-baseline > $O/cb_fp8_bs64.json 2> /dev/null
 # N > 1 through the bench's own launcher (no torchrun around it): two ranks on this box's one GPU, gloo
@@ -28,7 +29,7 @@ run timeout 900 python $R/bench.py --gpus 2 --workload cb --share-gpu --dist-bac
 rm -rf /tmp/p2; run timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python $R/bench.py --workload cb --version v2ProPlus --steps 1 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 f=$(find /tmp/p2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f" > $O/rocprofv3_kernel_stats_cb_configs2.csv
 # 4. raw step times
-( for b in 1 4 8 16 17 24 32 33 40 64 128 256; do timeout 300 python $R/tools/step_time.py $b bf16 | grep step; done
+( for b in 1 2 4 8 16 17 24 32 33 40 64 128 256; do timeout 300 python $R/tools/step_time.py $b bf16 | grep step; done
   for b in 64 256; do timeout 300 python $R/tools/step_time.py $b fp8 | grep step; done
   timeout 300 python $R/tools/step_time.py 1 fp32 | grep step ) > $O/step_time.txt 2>&1
 # 5. vocoder: pass times and per-kernel timelines
