@@ -487,8 +487,17 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     constexpr int EPL = Geo<WT>::EPL;
     constexpr int CPR = Geo<WT>::CPR;
     constexpr int LPR = kDh / EPL;         // lanes per K/V row
-    constexpr int RPI = kNT / LPR;         // K/V rows per block iteration (256 bf16, 128 f32)
-    constexpr int KCH = 2;                 // iterations held in registers per chunk (512 positions bf16, 256 f32)
+#ifndef GSV_ATTN_WAVES
+#define GSV_ATTN_WAVES 8
+#endif
+    // waves that run the attention phase (the others wait at its barrier).  The phase is VALU-issue bound and most of a wave's ~200 instructions
+    // are per-wave overhead (running max / sum across the wave, the P.V reduction tree), not per-row work: eight waves with four K/V rows per
+    // thread issue a quarter fewer instructions than sixteen with two (bf16: 0.2735 -> 0.2695 ms per step at one sequence, 0.297 -> 0.288 at 4;
+    // fp32 handles keep sixteen: eight K/V vectors more per thread spill there, 0.433 -> 0.473 ms)
+    constexpr int AW = sizeof(WT) == 2 ? GSV_ATTN_WAVES : kNW;
+    constexpr int RPI = AW * 64 / LPR;     // K/V rows per block iteration (256 bf16, 128 f32 at 16 waves)
+    constexpr int KCH = 2 * kNW / AW;      // iterations held in registers per chunk (512 positions bf16, 256 f32)
+    const bool aw = __builtin_amdgcn_readfirstlane(wid) < AW;
     constexpr int RW = 96 / kNW;           // 6 QKV rows per wave
     const bool owner = tid < kD;
     constexpr bool BF = sizeof(WT) == 2;   // bf16 handle: dots on v_dot2c_f32_bf16, activations as bf16 (hi, lo) pairs in LDS
@@ -544,10 +553,12 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     // K/V rows are loaded UNCONDITIONALLY from a clamped (always valid) row and masked at use: a
     // per-element "load or zero" select makes hipcc branch around each load and drain vmcnt(0)
     raw16 kreg[KCH], vreg[KCH];
+    if (AW == kNW || aw) {
 #pragma unroll
-    for (int it = 0; it < KCH; ++it) kreg[it] = ldg16w<NTKV>(Kp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
+        for (int it = 0; it < KCH; ++it) kreg[it] = ldg16w<NTKV>(Kp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
 #pragma unroll
-    for (int it = 0; it < KCH; ++it) vreg[it] = ldg16w<NTKV>(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
+        for (int it = 0; it < KCH; ++it) vreg[it] = ldg16w<NTKV>(Vp + (size_t)min(rsub + it * RPI, n) * kDh + part * EPL);
+    }
     // Pin "all loads issued, THEN arithmetic": the opaque asm redefines the head of the partial-sum
     // chain, so no add can be scheduled above it, while the memory clobber keeps every load above
     // it.  It only needs the FIRST-issued load to have landed.
@@ -631,6 +642,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
     const bool wave0 = __builtin_amdgcn_readfirstlane(wid) == 0;
+    if (AW == kNW || aw) {
     for (int c0 = 0; c0 == 0 || c0 < n; c0 += KCH * RPI) {
         if (c0 > 0) {
 #pragma unroll
@@ -720,17 +732,19 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         if ((lane & 8) == 0) pacc[wid * 32 + part * 4 + 2 * (lane >> 5) + ((lane >> 4) & 1)] = r1;
     }
     if (lane == 0) { pm[wid] = m_run; pl[wid] = l_run; }
+    }   // aw
     stamp(a.dbg, 4);
     __syncthreads();
     if (wid == 0) {
-        // merge the 16 waves: lane l (mod 16) owns wave l's (max, sum); 2x32 lanes own the 32 dims
-        const float mw = pm[lane & 15], lw = pl[lane & 15];
+        // merge the AW waves: lane l (mod 16) owns wave l's (max, sum); 2x32 lanes own the 32 dims
+        const bool has = (lane & 15) < AW;
+        const float mw = has ? pm[lane & 15] : -INFINITY, lw = has ? pl[lane & 15] : 0.f;
         const float M = row16_max(mw);
         const float den = row16_sum(lw * sm_exp<BF>(mw - M));      // waves with no live rows: exp(-inf) = 0
         const int hf = lane >> 5, d = lane & 31;
         float num = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) num = fmaf(pacc[(hf * 8 + w) * 32 + d], sm_exp<BF>(pm[hf * 8 + w] - M), num);
+        for (int w = 0; w < AW / 2; ++w) num = fmaf(pacc[(hf * (AW / 2) + w) * 32 + d], sm_exp<BF>(pm[hf * (AW / 2) + w] - M), num);
         num = xor32_sum(num);
         if (lane < 32) {
             if constexpr (BF) { uint16_t vh, vl; split_bf16(num * __builtin_amdgcn_rcpf(den), vh, vl); atth[d] = vh; attl[d] = vl; }
