@@ -678,6 +678,30 @@ def test_adopt_slots_equals_a_prompt_pass_into_the_slots(dev, dtype):
     assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), 77, i32(0), None, 1, st) != 0                  # no such state
 
 
+@pytest.mark.parametrize("slots,n_req", [(1, 4), (3, 2), (3, 3), (2, 9)])
+def test_ahead_refill_edge_cases(dev, slots, n_req):
+    """the slot loop with prompt passes run ahead, at its edges: one slot (the ahead state then needs another batch size than the stepped
+    one), fewer requests than slots (nothing to prefill ahead), exactly as many, and more ahead slots than requests left -- every
+    request's tokens equal the reference-order loop's, with a token budget and with EOS ends"""
+    cfg = synth.gpt_config(n_layer=2)
+    w = synth.gpt_weights(cfg, seed=77, eos_gain=2.0)
+    m = _model(cfg, w, [(slots, 128)], torch.float32, dev)
+    rng = np.random.default_rng(slots * 100 + n_req)
+    rs = [synth.synth_request(500 + i, int(rng.integers(2, 6)), int(rng.integers(3, 20)), int(rng.integers(4, 30)), seed=77, bert="random")
+          for i in range(n_req)]
+    X, Y, Bt = [_T(r[0], dev) for r in rs], [_T(r[1], dev) for r in rs], [_T(r[2], dev) for r in rs]
+    for budget in (None, [int(rng.integers(1, 25)) for _ in range(n_req)]):
+        ref, ridx = m.infer_batched(X, Y, Bt, top_k=1, max_new_tokens=budget)
+        want = {int(i): p.cpu().numpy() for i, p in zip(ridx.tolist(), ref)}
+        for ahead in (8, 1):
+            m.refill_ahead = ahead
+            got, gidx = m.infer_batched(X, Y, Bt, top_k=1, max_new_tokens=budget, async_refill=True)
+            assert sorted(gidx.tolist()) == list(range(n_req))
+            assert m.last_stats["refills"] == max(0, n_req - slots)
+            for i, p in zip(gidx.tolist(), got):
+                assert np.array_equal(p.cpu().numpy(), want[int(i)]), (budget is not None, ahead, i)
+
+
 def test_staged_refill_cuts_a_full_cache_like_the_reference_order_loop(dev):
     """requests that never sample EOS end when kv + check_interval reaches the cache size at a 5-step window boundary
     (t2s_model.py:655-657); where that boundary falls depends on the window a slot was filled at, so the staged loop may cut
