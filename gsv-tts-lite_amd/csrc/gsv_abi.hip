@@ -865,7 +865,12 @@ struct AdoptArgs {
 __global__ __launch_bounds__(256) void t2s_adopt_kv_kernel(AdoptArgs a) {
     const int lh = blockIdx.x, r = blockIdx.y, l = lh / kH, hd = lh % kH;
     const int ss = a.src[r], ds = a.dst[r];
-    const size_t n16 = (size_t)a.sg_kv[ss] * kDh * a.esz / 16;          // rows [0, kv_len) of the panel are contiguous
+    // rows [0, kv_len) of the panel are contiguous; a source slot no prompt pass has filled (kv_len 0 since the bind) copies nothing, and no
+    // length read from the staging can run past either cache
+    long long kv = a.sg_kv[ss];
+    kv = kv < 0 ? 0 : (kv > a.Ts ? a.Ts : kv);
+    kv = kv > a.Td ? a.Td : kv;
+    const size_t n16 = (size_t)kv * kDh * a.esz / 16;
     const size_t so = ((((size_t)l * a.Bs + ss) * kH + hd) * a.Ts) * kDh * a.esz;
     const size_t d0 = ((((size_t)l * a.Bd + ds) * kH + hd) * a.Td) * kDh * a.esz;
     const uint4* sp = reinterpret_cast<const uint4*>((blockIdx.z ? a.vs : a.ks) + so);
@@ -1047,6 +1052,8 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     HIPCHK(hipMalloc(&b.sg_logits, sizeof(float) * B * h->cfg.vocab)); HIPCHK(hipMalloc(&b.sg_hidden, sizeof(float) * B * kD));
     HIPCHK(hipMalloc(&b.sg_tok, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(b.sg_step, 0, 4 * B));
+    HIPCHK(hipMemset(b.sg_kv, 0, 8 * B)); HIPCHK(hipMemset(b.sg_x, 0, 8 * B));
+    HIPCHK(hipMemset(b.sg_eos, 0xff, 4 * B));      // -1: no EOS seen
     return GSV_OK;
 }
 

@@ -676,6 +676,12 @@ def test_adopt_slots_equals_a_prompt_pass_into_the_slots(dev, dtype):
     assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), sh["batch"], i32(sh["batch"]), None, 1, st) != 0
     assert lib.gsv_t2s_adopt_slots(h, 4, i32(1, 1), sh["batch"], i32(0, 1), None, 2, st) != 0   # one slot twice
     assert lib.gsv_t2s_adopt_slots(h, 4, i32(0), 77, i32(0), None, 1, st) != 0                  # no such state
+    # a source slot no prompt pass has filled since the bind holds kv_len 0: adopting it copies no row and leaves an empty slot
+    sh3 = m._ahead_state(3, 96)
+    rt["kv_len"].fill_(7)
+    m.adopt_slots(4, [2], sh3["batch"], [2])
+    torch.cuda.synchronize()
+    assert int(rt["kv_len"][2]) == 0 and int(rt["eos_at"][2]) == -1 and int(rt["kv_len"][0]) == 7
 
 
 @pytest.mark.parametrize("slots,n_req", [(1, 4), (3, 2), (3, 3), (2, 9)])
