@@ -19,6 +19,7 @@
 #include "wconv.h"
 #include "wups.h"
 #include "cgemm.h"
+#include "wdma.h"
 #include "voc_kernels.h"
 #include "gsv_error.h"
 
@@ -306,18 +307,69 @@ int run_wconv<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, flo
 }
 
 
+// The resblock convs at 64 / 128 / 256 channels with rows and residual by LDS-DMA (wdma.h).  The inputs `brs[i].X` are the ACTIVATED
+// copies their producers wrote; `act[i]` (null or a buffer) receives lrelu(Y_i, act_slope).  -1 = shape not covered, 0 = launched.
+inline bool wdma_shape(int C, int ld, int n_rows) {
+    static const bool off = getenv("GSV_NO_WDMA") != nullptr;
+    return !off && ld == C && (C == 64 || C == 128 || (C == 256 && n_rows < 16384));
+}
+inline int run_wdma(const Branch* brs, void* const* act, int ld, int n_rows, float out_slope, float act_slope, const void* zeros, void* sink, hipStream_t st) {
+    const int C = brs[0].pc->cout;
+    if (!wdma_shape(C, ld, n_rows) || !zeros || !sink) return -1;
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; ++i) {
+        const PackedConv& q = *brs[i].pc;
+        if (q.cin != C || q.cout != C || q.u != 0 || (q.k != 3 && q.k != 7 && q.k != 11) || q.dil < 1 || q.dil > 5 || q.pad != (q.k - 1) / 2 * q.dil || !q.bias)
+            return -1;
+    }
+    if ((brs[0].res == nullptr) != (brs[1].res == nullptr) || (brs[0].res == nullptr) != (brs[2].res == nullptr)) return -1;
+    if ((act[0] == nullptr) != (act[1] == nullptr) || (act[0] == nullptr) != (act[2] == nullptr)) return -1;
+    std::sort(order, order + 3, [&](int x, int y) { return brs[x].pc->k > brs[y].pc->k; });  // heaviest branch dispatches first
+    const int msp = C == 256 ? 4 : 1;
+    int nblk = 256;
+    const double ovh = C == 64 ? 14.0 : 8.0;     // per-tile overhead in tap units (tools/tg_bench.hip)
+    double tot = 0;
+    for (int i = 0; i < 3; ++i) tot += brs[i].pc->k + ovh;
+    int nb[3], used = 0;
+    for (int i = 0; i < 3; ++i) { nb[i] = std::max(msp, (int)(nblk * (brs[order[i]].pc->k + ovh) / tot) / msp * msp); used += nb[i]; }
+    nb[0] += (nblk - used) / msp * msp;
+    nblk = nb[0] + nb[1] + nb[2];
+    WDmaArgs a;
+    memset(&a, 0, sizeof(a));
+    const Branch &b0 = brs[order[0]], &b1 = brs[order[1]], &b2 = brs[order[2]];
+    a.X0 = (const bf16_t*)b0.X; a.X1 = (const bf16_t*)b1.X; a.X2 = (const bf16_t*)b2.X;
+    a.W0 = (const uint4*)b0.pc->w; a.W1 = (const uint4*)b1.pc->w; a.W2 = (const uint4*)b2.pc->w;
+    a.b0 = b0.pc->bias; a.b1 = b1.pc->bias; a.b2 = b2.pc->bias;
+    a.R0 = (const bf16_t*)b0.res; a.R1 = (const bf16_t*)b1.res; a.R2 = (const bf16_t*)b2.res;
+    a.Y0 = (bf16_t*)b0.Y; a.Y1 = (bf16_t*)b1.Y; a.Y2 = (bf16_t*)b2.Y;
+    a.A0 = (bf16_t*)act[order[0]]; a.A1 = (bf16_t*)act[order[1]]; a.A2 = (bf16_t*)act[order[2]];
+    a.k0 = b0.pc->k; a.k1 = b1.pc->k; a.k2 = b2.pc->k;
+    a.d0 = b0.pc->dil; a.d1 = b1.pc->dil; a.d2 = b2.pc->dil;
+    a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
+    a.ld = ld; a.n_rows = n_rows; a.out_slope = out_slope; a.act_slope = act_slope; a.zeros = zeros; a.sink = sink;
+    auto launch = [&](auto kern, size_t lds) -> int {
+        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
+        HIPCHK(hipGetLastError());
+        return GSV_OK;
+    };
+    if (C == 256) return launch(wdma_kernel<256, 2, 64, 2, 4>, wdma_lds_bytes<256, 2, 64, 2, 4>());
+    if (C == 128) return launch(wdma_kernel<128, 4, 64>, wdma_lds_bytes<128, 4, 64>());
+    return launch(wdma_kernel<64, 2, 128>, wdma_lds_bytes<64, 2, 128>());
+}
+
 // Upsampling layer (transposed conv) on the weights-in-registers kernel (wups.h); -1 = shape not covered (caller
 // falls back to tapgemm), 0 = launched, > 0 = GSV_ERR_*.
 template <typename AT>
-int run_wups(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
-    (void)pc; (void)X; (void)ldx; (void)n_in; (void)Y; (void)ldy; (void)in_slope; (void)st;
+int run_wups(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st, void* Ya = nullptr, float act_slope = 1.f) {
+    (void)pc; (void)X; (void)ldx; (void)n_in; (void)Y; (void)ldy; (void)in_slope; (void)st; (void)Ya; (void)act_slope;
     return -1;
 }
 template <>
-int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st) {
+int run_wups<bf16_t>(const PackedConv& pc, const void* X, int ldx, int n_in, void* Y, int ldy, float in_slope, hipStream_t st, void* Ya, float act_slope) {
     if (pc.u < 1 || getenv("GSV_NO_WUPS")) return -1;
     WUpsArgs a;
-    a.X = (const bf16_t*)X; a.W = (const uint4*)pc.w; a.bias = pc.bias; a.Y = (bf16_t*)Y;
+    a.X = (const bf16_t*)X; a.W = (const uint4*)pc.w; a.bias = pc.bias; a.Y = (bf16_t*)Y; a.Ya = (bf16_t*)Ya; a.act_slope = act_slope;
     a.ldx = ldx; a.ldy = ldy; a.n_in = n_in; a.u = pc.u; a.tpad = pc.pad; a.mtiles = pc.mtiles; a.cout = pc.cout;
     a.cvalid = std::min(ldy, (pc.cout + 15) / 16 * 16); a.in_slope = in_slope;
     auto launch = [&](auto kern, size_t lds, int ms, int bn, int pg, int max_blocks) -> int {

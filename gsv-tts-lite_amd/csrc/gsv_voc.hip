@@ -57,6 +57,8 @@ struct gsv_voc {
     PackedConv conv_pre, cond, conv_post;
     PackedConv cond_all;             // every flow's cond_layer stacked: one launch for the whole flow
     float* post_w = nullptr;         // conv_post weight [C][7] fp32 for conv_post_kernel
+    void* dma_zero = nullptr;        // wdma.h: a zero page (rows outside the sequence) and a sink (stores of rows beyond it)
+    void* dma_sink = nullptr;
     int post_c = 0;
     bool fused_flow = false;
     EncP enc;                        // enc_p in HIP (bf16 mode, when its tensors were loaded)
@@ -105,7 +107,7 @@ struct VocWs {
     float *gc, *condbuf;
     int *seg_flag, *seg_id, *seg_first, *nseg;   // per-frame ge with few distinct columns (voc_kernels.h); seg = null: one row per frame
     const int* seg;
-    void* st[11];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}
+    void* st[15];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}; [11] lrelu(xu), [12..14] lrelu of a branch's state (wdma.h)
     size_t bytes;
 };
 
@@ -131,7 +133,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.nseg = (int*)take(sizeof(int) * 64);
     w.seg = nullptr;
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
-    for (int i = 0; i < 11; ++i) w.st[i] = take(sizeof(AT) * se);
+    for (int i = 0; i < 15; ++i) w.st[i] = take(sizeof(AT) * se);
     w.bytes = off;
     return w;
 }
@@ -293,7 +295,11 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
                 if (wc ? q == 0 : q != 1) HIPCHK(hipMemsetAsync(w.st[q], 0, sizeof(AT) * (size_t)Tn * ldo, st));
         }
         Epi eu; eu.in_slope = 0.1f;
-        int ru = run_wups<AT>(sg.up, x, ldi, Tc, xu, ldo, 0.1f, st);
+        // 64 / 128 / 256 channels: the resblock convs stage their rows by LDS-DMA (wdma.h), so the state x of a branch travels with its
+        // activated copy lrelu(x) -- written by whoever writes x (the transposed conv here, the second conv of a pair below)
+        const bool dma = sizeof(AT) == 2 && v->dma_zero && wdma_shape(sg.cout, ldo, Tn) && !(sg.rb_c && ldo == sg.rb_c);
+        int ru = run_wups<AT>(sg.up, x, ldi, Tc, xu, ldo, 0.1f, st, dma ? w.st[11] : nullptr, 0.1f);
+        if (ru != 0 && dma) return fail(GSV_ERR_STATE, "the transposed conv in front of a wdma stage must run on wups");
         if (ru > 0) return ru;
         if (ru < 0)
             if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
@@ -317,6 +323,7 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
         if (ldo != sg.cout) HIPCHK(hipMemsetAsync(x, 0, sizeof(AT) * (size_t)Tn * ldo, st));
         // the three resblocks (k = 3, 7, 11) advance in lock step: one launch per conv position
         const AT* cur[3] = {xu, xu, xu};
+        const void* cur_act[3] = {w.st[11], w.st[11], w.st[11]};
         for (int d = 0; d < 3; ++d) {
             Branch b1[3], b2[3];
             for (int j = 0; j < 3; ++j) {
@@ -324,6 +331,17 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
                 AT* dst = (AT*)w.st[2 + 3 * j + 1 + (d & 1)];
                 b1[j] = Branch{&sg.rb[j].c1[d], cur[j], t1, nullptr};
                 b2[j] = Branch{&sg.rb[j].c2[d], t1, dst, cur[j]};
+            }
+            if (dma) {
+                Branch a1[3];
+                void* none[3] = {nullptr, nullptr, nullptr};
+                void* act[3] = {d < 2 ? w.st[12] : nullptr, d < 2 ? w.st[13] : nullptr, d < 2 ? w.st[14] : nullptr};
+                for (int j = 0; j < 3; ++j) a1[j] = Branch{b1[j].pc, cur_act[j], b1[j].Y, nullptr};
+                int rd = run_wdma(a1, none, ldo, Tn, 0.1f, 1.0f, v->dma_zero, v->dma_sink, st);
+                if (rd == 0) rd = run_wdma(b2, act, ldo, Tn, 1.0f, 0.1f, v->dma_zero, v->dma_sink, st);
+                if (rd != 0) return rd > 0 ? rd : fail(GSV_ERR_STATE, "wdma declined a conv of a stage it accepted");
+                for (int j = 0; j < 3; ++j) { cur[j] = (const AT*)b2[j].Y; cur_act[j] = act[j]; }
+                continue;
             }
             // bf16, 16..128 channels: weights-in-registers kernel; the first conv writes lrelu(t1), which is
             // the only form its consumer reads, so the second conv stages its input without arithmetic
@@ -916,6 +934,11 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
             v->post_c = ch;
         }
     }
+    if (!rc && sizeof(CT) == 2 && !v->dma_zero) {
+        HIPCHK(hipMalloc(&v->dma_zero, 4096));
+        HIPCHK(hipMemsetAsync(v->dma_zero, 0, 4096, st));
+        HIPCHK(hipMalloc(&v->dma_sink, 4096));
+    }
     if (!rc && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize<CT>(v, temps, st);
     (void)hipStreamSynchronize(st);
     for (float* t : temps) (void)hipFree(t);
@@ -942,6 +965,9 @@ void voc_free(gsv_voc* v) {
     encp_free(v);
     if (v->post_w) (void)hipFree(v->post_w);
     v->post_w = nullptr;
+    if (v->dma_zero) (void)hipFree(v->dma_zero);
+    if (v->dma_sink) (void)hipFree(v->dma_sink);
+    v->dma_zero = v->dma_sink = nullptr;
     for (VocStage& s : v->stages) {
         free_conv(s.up);
         if (s.rb_w) (void)hipFree(s.rb_w);

@@ -25,6 +25,8 @@ struct WUpsArgs {
     int cvalid;           // channels written per row (cout rounded up to the row's 16-channel padding)
     float in_slope;       // leaky-ReLU on the input
     int nwalk;            // row-tile walkers; grid = nwalk * (u / PG) * ceil(mtiles / MS)
+    bf16_t* Ya;           // null, or lrelu(Y, act_slope) of the rounded output next to Y: what the resblocks' first convs contract (wdma.h)
+    float act_slope;
 };
 
 template <int CIN, int MS, int BN, int NTAPS, int PG>
@@ -179,8 +181,17 @@ __global__ __launch_bounds__(256, 1) void wups_kernel(WUpsArgs a) {
                     const int idx = q * 64 + lane, row = idx / 4, pc = idx % 4;
                     const u32x4 o = *reinterpret_cast<const u32x4*>(ro + row * RORS + pc * 16);
                     const int n = tile * BN + wrow + row;
-                    if (n < a.n_in && piece_ok(pc))
-                        *reinterpret_cast<u32x4*>(a.Y + ((size_t)n * a.u + pg * PG + p) * a.ldy + gs * 32 + pc * 8) = o;
+                    if (n < a.n_in && piece_ok(pc)) {
+                        const size_t off = ((size_t)n * a.u + pg * PG + p) * a.ldy + gs * 32 + pc * 8;
+                        *reinterpret_cast<u32x4*>(a.Y + off) = o;
+                        if (a.Ya) {
+                            u32x4 oa;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                oa[e] = pack_bf16x2(lrelu(__uint_as_float(o[e] << 16), a.act_slope), lrelu(__uint_as_float(o[e] & 0xffff0000u), a.act_slope));
+                            *reinterpret_cast<u32x4*>(a.Ya + off) = oa;
+                        }
+                    }
                 }
             }
         }

@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include "wpair_experiment.h"
+#include "../gsv-tts-lite_amd/csrc/wdma.h"
 
 using namespace gsv;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -96,6 +97,60 @@ void run_wconv(const char* name, WConvArgs w, int N, int reps, bf16_t** yref, bf
     fflush(stdout);
 }
 
+
+static inline float bf2f(bf16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+static inline bf16_t lrelu_bf(bf16_t v, float s) { const float f = bf2f(v); return f2bf(fmaxf(f, f * s)); }
+
+// wdma.h: rows and residual by LDS-DMA; input = the activated copy (made on the host here), checked against the same reference
+template <int C, int MS, int BN, int KSP = 1, int MSP = 1>
+void run_wdma(const char* name, WConvArgs w, bf16_t** Xact, int N, int reps, bf16_t** yref, bf16_t** Yd, bf16_t** Ad, size_t ny, int total_blocks, double ovh, const void* zeros, void* sink) {
+    auto kern = wdma_kernel<C, MS, BN, KSP, MSP>;
+    const size_t lds = wdma_lds_bytes<C, MS, BN, KSP, MSP>();
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ks[3] = {w.k0, w.k1, w.k2};
+    double tot = 0; for (int b = 0; b < 3; ++b) tot += ks[b] + ovh;
+    int nb[3]; int used = 0;
+    for (int b = 0; b < 3; ++b) { nb[b] = std::max(MSP, (int)(total_blocks * (ks[b] + ovh) / tot) / MSP * MSP); used += nb[b]; }
+    nb[0] += (total_blocks - used) / MSP * MSP;
+    total_blocks = nb[0] + nb[1] + nb[2];
+    WDmaArgs a; memset(&a, 0, sizeof(a));
+    a.X0 = Xact[0]; a.X1 = Xact[1]; a.X2 = Xact[2]; a.W0 = w.W0; a.W1 = w.W1; a.W2 = w.W2; a.b0 = w.b0; a.b1 = w.b1; a.b2 = w.b2;
+    a.R0 = w.R0; a.R1 = w.R1; a.R2 = w.R2; a.Y0 = Yd[0]; a.Y1 = Yd[1]; a.Y2 = Yd[2]; a.A0 = Ad[0]; a.A1 = Ad[1]; a.A2 = Ad[2];
+    a.k0 = w.k0; a.k1 = w.k1; a.k2 = w.k2; a.d0 = w.d0; a.d1 = w.d1; a.d2 = w.d2; a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
+    a.ld = w.ld; a.n_rows = N; a.out_slope = w.out_slope; a.act_slope = 0.1f; a.zeros = zeros; a.sink = sink;
+    dim3 grid(total_blocks);
+    long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8)); a.dbg = dbg;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const float us = ms * 1e3f / reps;
+    double maxd = 0, maxa = 0; int nbad = 0;
+    std::vector<bf16_t> y(ny), ya(ny);
+    for (int b = 0; b < 3; ++b) {
+        CK(hipMemcpy(y.data(), Yd[b], ny * 2, hipMemcpyDeviceToHost));
+        if (Ad[b]) CK(hipMemcpy(ya.data(), Ad[b], ny * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ny; ++i) {
+            const float fa = bf2f(y[i]), fb = bf2f(yref[b][i]);
+            if (fabsf(fa - fb) > 0.0f && nbad < 6) { printf("  bad br %d n %zu m %zu got %g want %g\n", b, i / C, i % C, fa, fb); ++nbad; }
+            maxd = std::max(maxd, (double)fabsf(fa - fb));
+            if (Ad[b]) maxa = std::max(maxa, (double)fabsf(bf2f(ya[i]) - bf2f(lrelu_bf(y[i], 0.1f))));
+        }
+        CK(hipMemset(Yd[b], 0, ny * 2));
+        if (Ad[b]) CK(hipMemset(Ad[b], 0, ny * 2));
+    }
+    { long long hdb[64]; CK(hipMemcpy(hdb, dbg, sizeof(hdb), hipMemcpyDeviceToHost)); printf("  stamps (k=%d, block 0, wave 0):", ks[0]); for (int i = 1; i < 21 && hdb[i]; ++i) printf(" %lld", hdb[i] - hdb[i - 1]); printf("\n"); }
+    double flops = 0;
+    for (int b = 0; b < 3; ++b) flops += 2.0 * C * C * ks[b] * N;
+    printf("%-20s ovh %5.1f grid %5d (%d/%d/%d) lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g  act-copy maxdiff %.3g\n", name, ovh, total_blocks, nb[0], nb[1], nb[2], lds, us,
+           flops / us * 1e-6, maxd, maxa);
+    fflush(stdout);
+}
+
 template <int C, int MS, int BNW, int BNP>
 void run_pair(const char* name, WConvArgs w1, int N, int reps, bf16_t** Xd, bf16_t** T1d, bf16_t** Yd, Conv* cv, size_t ny, int blocks_w, int blocks_p, double ovh) {
     // reference: c1 (lrelu in, lrelu out) then c2 (+ residual) with the single-conv kernel; both convs use the same weights here
@@ -158,7 +213,8 @@ int main(int argc, char** argv) {
     const int nbr = argc > 3 ? atoi(argv[3]) : 3;
     const int reps = 20;
     const int ks[3] = {11, 7, 3};
-    const int dil = 5;
+    const int dil = argc > 4 ? atoi(argv[4]) : 5;
+    const bool with_act = argc > 5 ? atoi(argv[5]) != 0 : true;
     const int mtiles = cdiv(C, 32);
     const int ld = C;
     srand(1);
@@ -236,18 +292,31 @@ int main(int argc, char** argv) {
     w.Y0 = Y[0]; w.Y1 = Y[1]; w.Y2 = Y[2];
     w.k0 = 11; w.k1 = 7; w.k2 = 3; w.d0 = w.d1 = w.d2 = dil;
     w.ld = ld; w.n_rows = N; w.in_slope = 0.1f; w.out_slope = 1.0f;
+    bf16_t *XA[3], *AO[3]; void *zeros, *sink;
+    {
+        std::vector<bf16_t> ha(hx.size());
+        for (size_t i = 0; i < hx.size(); ++i) ha[i] = lrelu_bf(hx[i], 0.1f);
+        for (int b = 0; b < 3; ++b) {
+            CK(hipMalloc(&XA[b], ha.size() * 2)); CK(hipMemcpy(XA[b], ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+            AO[b] = nullptr;
+            if (with_act) { CK(hipMalloc(&AO[b], ha.size() * 2)); CK(hipMemset(AO[b], 0, ha.size() * 2)); }
+        }
+        CK(hipMalloc(&zeros, 4096)); CK(hipMemset(zeros, 0, 4096)); CK(hipMalloc(&sink, 65536));
+    }
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
+    if (C == 128) for (double ov : {8.0, 4.0, 2.0}) run_wdma<128, 4, 64>("wdma 128 bn64", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 256) for (double ov : {8.0, 4.0}) run_wdma<256, 2, 64, 2, 4>("wdma 256 ks2 ms4", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 64) for (double ov : {14.0, 8.0, 4.0}) run_wdma<64, 2, 128>("wdma 64 bn128", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, 256, 14.0);
     if (C == 256) for (int nb : {256, 512}) for (double ov : {8.0, 4.0}) run_wconv<256, 2, 64, 2, 4>("wconv 256 ks2 ms4", w, N, reps, yrp, Y, ny, nb, ov);
     if (C == 192) for (int nb : {256, 512}) for (double ov : {8.0, 4.0}) run_wconv<192, 2, 64, 2, 3>("wconv 192 ks2 ms3", w, N, reps, yrp, Y, ny, nb, ov);
     if (C == 96) for (int nb : {256, 512, 768}) run_wconv<96, 4, 64>("wconv 96 bn64", w, N, reps, yrp, Y, ny, nb, 8.0);
     if (C == 48) for (int nb : {512, 768, 1024}) for (double ov : {14.0, 30.0}) run_wconv<48, 2, 64>("wconv 48 bn64", w, N, reps, yrp, Y, ny, nb, ov);
-    for (int nb : {512, 768, 1024, 1536, 2048}) {
+    if (C <= 32) for (int nb : {512, 768, 1024, 1536, 2048}) {
         if (C == 32) run_wconv<32, 1, 256>("wconv 32 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
         if (C == 32) run_wconv<32, 1, 128>("wconv 32 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
         if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
         if (C == 16) run_wconv<16, 1, 128>("wconv 16 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
-        if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, nb, 14.0);
-        if (C == 64) run_wconv<64, 2, 64>("wconv 64 bn64", w, N, reps, yrp, Y, ny, nb, 14.0);
     }
     return 0;
 }
