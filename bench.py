@@ -50,6 +50,11 @@ KV_BYTES_PER_POS = 2 * 24 * 512            # x dtype bytes: K and V rows of 24 l
 CB_REQUESTS_PER_GPU, CB_SLOTS = 256, 32
 
 
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
@@ -84,6 +89,10 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CI on a 1-GPU box)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--stub-decoder", action="store_true", help="cb, CPU ranks over gloo, NO kernels: the control path of the multi-GPU run (own "
+                    "launcher, shared request cursor, token exchange, vocoder batches dealt over the ranks, rank-0 gather, max over ranks) with a "
+                    "stub slot loop and a stub vocoder; its line says so and is not a measurement (tests/test_bench_world8_gloo.py)")
+    ap.add_argument("--stub-die-rank", type=int, default=-1, help=argparse.SUPPRESS)   # that rank exits before its first collective (launcher test)
     return ap.parse_args()
 
 
@@ -249,26 +258,71 @@ def _profile_traffic(out, a):
 
 
 def self_launch(a):
-    """`python bench.py --gpus N` with no launcher around it: re-run this command as N ranks (one per GPU) under
-    torch.distributed.run on 127.0.0.1 and pass its output through.  Returns the child's exit code."""
+    """`python bench.py --gpus N` with no launcher around it: this process starts the N ranks itself, one per GPU -- RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in each child's environment, device affinity = LOCAL_RANK (setup_dist selects
+    cuda:LOCAL_RANK and checks it; every rank keeps ALL devices visible: RCCL's xGMI peer paths want to see the peers, so no
+    HIP_VISIBLE_DEVICES mask) -- passes their output through and WATCHES them: a rank that dies takes the others down with a message,
+    instead of leaving them in a collective or on the store cursor until a timeout.  Returns the exit code."""
     import socket
     import subprocess
-    if not a.share_gpu and torch.cuda.device_count() < a.gpus:
+    if not (a.share_gpu or a.stub_decoder) and torch.cuda.device_count() < a.gpus:
         raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s)" % (a.gpus, torch.cuda.device_count()))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log("launching %d ranks: %s" % (a.gpus, " ".join(cmd[1:])))
-    return subprocess.call(cmd, env=env)
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", "4")
+    base.update({"WORLD_SIZE": str(a.gpus), "LOCAL_WORLD_SIZE": str(a.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks (own launcher, 127.0.0.1:%d): %s" % (a.gpus, port, " ".join(cmd[1:])))
+    procs = []
+    for r in range(a.gpus):
+        env = dict(base)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "GROUP_RANK": "0"})
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc, dead = 0, None
+    try:
+        while any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                c = p.poll()
+                if c is not None and c != 0 and dead is None:
+                    dead, rc = r, c
+            if dead is not None:
+                break
+            time.sleep(0.05)
+        if dead is None:
+            for r, p in enumerate(procs):
+                if p.returncode != 0 and rc == 0:
+                    dead, rc = r, p.returncode
+    finally:
+        if dead is not None:
+            alive = [r for r, p in enumerate(procs) if p.poll() is None]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print("[bench] rank %d exited with code %d; the other ranks%s were stopped (they would have waited for it in a collective "
+                  "or on the shared request cursor)" % (dead, rc, " " + str(alive) if alive else ""), file=sys.stderr, flush=True)
+    return rc if rc != 0 else 0
 
 
 def setup_dist(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if a.stub_decoder:
+        if a.workload != "cb" or a.dist_backend != "gloo":
+            raise SystemExit("--stub-decoder is the CPU control-path run: --workload cb --dist-backend gloo")
+        if rank == a.stub_die_rank:
+            sys.exit(3)
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return world, rank, torch.device("cpu"), dist
     if a.share_gpu and a.dist_backend == "nccl" and world > 1:
         raise SystemExit("--share-gpu needs --dist-backend gloo: RCCL wants one device per rank")
     if world != a.gpus:      # a line that says n_gpus: 1 for a --gpus 8 request is worse than no line
@@ -290,6 +344,8 @@ def setup_dist(a):
             dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if not a.share_gpu and torch.cuda.current_device() != local:      # one process per GPU, the GPU its LOCAL_RANK names
+        raise SystemExit("rank %d: LOCAL_RANK %d but the current device is %d" % (rank, local, torch.cuda.current_device()))
     return world, rank, dev, dist
 
 
@@ -304,17 +360,17 @@ def timed_region(steps, warmup, step_fn, dev, dist):
     for i in range(warmup):
         step_fn(i, None)
     log("warmup done")
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     t0 = time.perf_counter()
     for i in range(steps):
         step_fn(warmup + i, i)
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    _sync(dev)
     return scheduler.max_over_ranks(time.perf_counter() - t0, device=dev)
 
 
@@ -413,12 +469,12 @@ def run_single(a):
                     first = list(range(CB_SLOTS))
                     ts = []
                     for _ in range(9):
-                        torch.cuda.synchronize(dev); q0 = time.perf_counter()
+                        _sync(dev); q0 = time.perf_counter()
                         with torch.inference_mode():
                             xy_, xl_, yl_, _, _ = w.t2s.embed_prompt([w.xs[c] for c in first], [w.ys[c] for c in first], [w.bs[c] for c in first])
                             w.t2s.prefill(CB_SLOTS, 0, xy_, xl_, yl_)
                             w.t2s._decode(CB_SLOTS, 1)
-                        torch.cuda.synchronize(dev); ts.append(time.perf_counter() - q0)
+                        _sync(dev); ts.append(time.perf_counter() - q0)
                     cb32["ttft_ms_p50_first_batch"] = sorted(ts[2:])[len(ts[2:]) // 2] * 1e3
                     cb32["ttft_first_batch_note"] = "%d prompts (%d positions in all) in one packed prompt pass + the first decode step" % (
                         len(first), int(sum(int(w.xs[c].shape[0]) + int(w.ys[c].shape[0]) for c in first)))
@@ -443,7 +499,7 @@ def run_single(a):
         # ---- p50 TTFT: prefill + first sample available on the host (ref-audio caches warm)
         tt = []
         for _ in range(a.ttft_runs):
-            torch.cuda.synchronize(dev)
+            _sync(dev)
             s0 = time.perf_counter()
             xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
             t2s.prefill(1, 0, xy, xl, yl)
@@ -504,19 +560,19 @@ def run_single(a):
             if a.no_extras:
                 raise RuntimeError("--no-extras")
             for _ in range(2):   # default-parameter sampling
-                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                _sync(dev); s0 = time.perf_counter()
                 tk = t2s.infer(x, y, bert, top_k=15, repetition_penalty=1.35, max_new_tokens=N_NEW)
-                torch.cuda.synchronize(dev); dt = time.perf_counter() - s0
+                _sync(dev); dt = time.perf_counter() - s0
             out["sampled_top_k15_ms_per_token"] = dt * 1e3 / max(1, int(tk.shape[-1]))
             z50, m50 = z_p[:, :, :50].contiguous(), mask[:, :, :50].contiguous()
             ta = []
             for _ in range(10):   # time to first audio: prefill + first 25-token chunk + 50-frame vocoder pass
-                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                _sync(dev); s0 = time.perf_counter()
                 xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
                 t2s.prefill(1, 0, xy, xl, yl)
                 t2s._decode(1, 25)
                 voc.flow_dec(z50, m50, ge)
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 ta.append((time.perf_counter() - s0) * 1e3)
             out["ttfa_ms_p50"] = float(np.median(ta))
             # end to end as SURVEY 8(d) words it (GPT + enc_p + flow_dec): the utterance's OWN tokens through SynthesizerTrn.decode
@@ -528,22 +584,22 @@ def run_single(a):
             txt = torch.from_numpy(synth.synth_request(rank * 100003, N_PROMPT_PH, N_TEXT_PH, N_PROMPT_TOK, seed=1234)[3])[None].to(dev)
             for _ in range(2):
                 vq.decode(t2s.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW), txt, ge, noise_scale=0.5)
-            torch.cuda.synchronize(dev); s0 = time.perf_counter()
+            _sync(dev); s0 = time.perf_counter()
             nrep, t_dec = 5, 0.0
             for _ in range(nrep):
                 tk = t2s.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
-                torch.cuda.synchronize(dev); s1 = time.perf_counter()
+                _sync(dev); s1 = time.perf_counter()
                 au, _ = vq.decode(tk, txt, ge, noise_scale=0.5)
-                torch.cuda.synchronize(dev); t_dec += time.perf_counter() - s1
+                _sync(dev); t_dec += time.perf_counter() - s1
             s2 = time.perf_counter()
             ta = []
             for _ in range(10):   # time to first audio through the REAL first-chunk path: prefill + 25 tokens + decode() of them (50 frames)
-                torch.cuda.synchronize(dev); q0 = time.perf_counter()
+                _sync(dev); q0 = time.perf_counter()
                 xy, xl, yl, _, _ = t2s.embed_prompt([x[0]], [y[0]], [bert[0]])
                 t2s.prefill(1, 0, xy, xl, yl)
                 t2s._decode(1, 25)
                 vq.decode(tk[:, :, :25], txt, ge, noise_scale=0.5)
-                torch.cuda.synchronize(dev)
+                _sync(dev)
                 ta.append((time.perf_counter() - q0) * 1e3)
             out["ttfa_decode_ms_p50"] = float(np.median(ta))
             out["value_with_enc_p"] = nrep * N_NEW / (s2 - s0)
@@ -558,10 +614,10 @@ def run_single(a):
             ge10 = ge.expand(-1, -1, T10).contiguous()
             for _ in range(2):
                 voc.flow_dec(z10, m10, ge10)
-            torch.cuda.synchronize(dev); s0 = time.perf_counter()
+            _sync(dev); s0 = time.perf_counter()
             for _ in range(3):
                 voc.flow_dec(z10, m10, ge10)
-            torch.cuda.synchronize(dev)
+            _sync(dev)
             t10 = (time.perf_counter() - s0) / 3
             vb10, vf10 = vocoder_algorithmic(a.version, sbytes)
             out["roofline_vocoder_batch10"] = {
@@ -577,13 +633,13 @@ def run_single(a):
                 t2f.initialize_runtime(torch.float32, dev, GPT_CACHE)
                 vof = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.float32, dev)
                 t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW); vof.flow_dec(z_p, mask, ge)
-                torch.cuda.synchronize(dev); s0 = time.perf_counter()
+                _sync(dev); s0 = time.perf_counter()
                 for _ in range(3):
                     t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
-                torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                _sync(dev); t1 = time.perf_counter()
                 for _ in range(3):
                     vof.flow_dec(z_p, mask, ge)
-                torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                _sync(dev); t2 = time.perf_counter()
                 out["fp32_parity_mode"] = {
                     "ar_tokens_per_s": 3 * N_NEW / (t1 - s0), "ar_ms_per_token": (t1 - s0) / 3 / N_NEW * 1e3,
                     "vocoder_ms": (t2 - t1) / 3 * 1e3, "tokens_per_s_end_to_end": 3 * N_NEW / (t2 - s0),
@@ -606,6 +662,49 @@ def run_single(a):
 
 
 # ================================================================================================ configs[2] / [3] / [4]
+class _StubDecoder:
+    """--stub-decoder: the product decoder's slot-loop INTERFACE (infer_batched(..., source=, slots=, max_new_tokens=)) without a GPU:
+    request i runs for max_new_tokens[i] steps in one of `slots` slots and returns that many tokens (value i mod 1024); a finished
+    slot pulls the next request from the shared source -- the dealing, not the arithmetic, is what the control-path run exercises."""
+    refill_ahead = 0
+
+    def __init__(self, dev):
+        self.device = dev
+        self.last_stats = {"steps": 0, "kv_rows": 0, "passes": 0}
+
+    def infer_batched(self, xs, ys, berts, source=None, slots=4, max_new_tokens=None, **kw):
+        live, pred, idx, steps = {}, [], [], 0
+        for s_ in range(slots):
+            c = source.next()
+            if c is None:
+                break
+            live[s_] = [c, int(max_new_tokens[c])]
+        while live:
+            steps += 1
+            if steps % 64 == 0:
+                time.sleep(0.0005 * (1 + int(os.environ.get("RANK", "0")) % 3))     # ranks of unequal speed: the cursor deals on demand
+            for s_ in list(live):
+                live[s_][1] -= 1
+                if live[s_][1] <= 0:
+                    c = live[s_][0]
+                    pred.append(torch.full((int(max_new_tokens[c]),), c % 1024, dtype=torch.int64))
+                    idx.append(c)
+                    n = source.next()
+                    if n is None:
+                        del live[s_]
+                    else:
+                        live[s_] = [n, int(max_new_tokens[n])]
+        self.last_stats = {"steps": steps, "kv_rows": 0, "passes": 0}
+        return pred, torch.tensor(idx, dtype=torch.int64)
+
+
+class _StubVocoder:
+    samples_per_frame = 640
+
+    def flow_dec(self, z, m, ge):
+        return torch.zeros(1, 1, z.shape[2] * self.samples_per_frame)
+
+
 class CBWorkload:
     """Continuous batching through the multi-GPU engine, the vocoder stage and the rank-0 gather included: what `--workload cb`
     times, and what every `--workload single` line carries as its `cb32` sub-record (v2Pro, 32 slots and 256 requests per GPU:
@@ -621,12 +720,15 @@ class CBWorkload:
         self.vdtype = torch.bfloat16 if dtype_name == "fp8" else self.dtype      # fp8 operands exist in the GPT batched step only
         self.sbytes = 4 if dtype_name == "fp32" else 2
         cfg = synth.gpt_config()
-        gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)      # lengths come from the per-request budgets below, not from EOS
         self.hps = synth.sovits_hps(version)
         gin = self.hps["model"]["gin_channels"]
-        self.t2s = Text2SemanticDecoder(cfg)
-        self.t2s.load_state_dict(gw)
-        self.t2s.initialize_runtime(self.dtype, dev, [(slots, 512), (slots, 1024)])     # SURVEY.md 8(d) buckets
+        if a.stub_decoder:
+            self.t2s, voc = _StubDecoder(dev), _StubVocoder()
+        else:
+            gw = synth.gpt_weights(cfg, seed=1234, eos_gain=0.0)      # lengths come from the per-request budgets below, not from EOS
+            self.t2s = Text2SemanticDecoder(cfg)
+            self.t2s.load_state_dict(gw)
+            self.t2s.initialize_runtime(self.dtype, dev, [(slots, 512), (slots, 1024)])     # SURVEY.md 8(d) buckets
         if voc is None:
             sw = synth.sovits_weights(self.hps, seed=1234, hot_path_only=True)
             voc = _VocoderNative(self.hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, self.vdtype, dev)
@@ -664,7 +766,7 @@ class CBWorkload:
             pos = 0
             for i in batches[b]:
                 n_ = 2 * int(lengths[i]) * voc.samples_per_frame
-                audio[i] = o[pos:pos + n_]
+                audio[i] = o[pos:pos + n_] if not self.a.stub_decoder else torch.full((n_,), float(i))   # stub: samples name their request
                 pos += n_
             tot += T
         return audio, tot
@@ -703,16 +805,20 @@ class CBWorkload:
 
     def step(self, i, timed_idx):
         a, dev, eng, acc, t2s = self.a, self.dev, self.eng, self.acc, self.t2s
-        torch.cuda.synchronize(dev); s0 = time.perf_counter()
+        _sync(dev); s0 = time.perf_counter()
         if (not a.overlap):
             pred, idx = eng.run_gpt(self.xs, self.ys, self.bs, costs=self.costs, top_k=1, max_new_tokens=self.new_tok, async_refill=not a.sync_refill)
-            torch.cuda.synchronize(dev); s1 = time.perf_counter()
+            _sync(dev); s1 = time.perf_counter()
             # every rank learns every request's tokens (ids: a few hundred KB), vocodes the batches dealt to it, and the
             # samples meet on rank 0 -- what TTS.infer_batched does between its GPT and its return (tts.py)
             tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, self.n_req, dst=None)
             eng._retire_cursors(None)
             audio, frames = self.vocode(tokens)
             full = eng.exchange(audio, self.n_req, dst=0)
+            if a.stub_decoder and full is not None:      # the control-path run checks what the gather delivered: every request, once, in order
+                for r_, t in enumerate(full):
+                    assert t.numel() == 2 * int(self.new_tok[r_]) * self.voc.samples_per_frame and (t.numel() == 0 or bool((t == float(r_)).all())), r_
+                acc["stub_ordered"] = acc.get("stub_ordered", 0) + len(full)
             if timed_idx is not None and full is not None:
                 acc["gathered_samples"] += int(sum(t.numel() for t in full))
             del full, audio
@@ -721,11 +827,28 @@ class CBWorkload:
                                                 max_new_tokens=self.new_tok, async_refill=not a.sync_refill)
             s1 = time.perf_counter()
             frames = int(sum(res.values()))
-        torch.cuda.synchronize(dev); s2 = time.perf_counter()
+        _sync(dev); s2 = time.perf_counter()
         if timed_idx is not None:
             acc["tok"] += int(sum(len(p) for p in pred)); acc["frames"] += frames
             acc["t_ar"] += s1 - s0; acc["t_voc"] += s2 - s1; acc["mine"] += len(pred)
             acc["steps"] += t2s.last_stats["steps"]; acc["kv_rows"] += t2s.last_stats["kv_rows"]; acc["timed"] += 1
+            acc["passes"] = acc.get("passes", 0) + int(t2s.last_stats.get("passes", 0))
+
+    def refill_label(self):
+        """what the slot loop that was measured does when a slot ends -- read from the decoder, not assumed"""
+        a, t2s = self.a, self.t2s
+        if a.sync_refill:
+            return "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)"
+        ahead = int(getattr(t2s, "refill_ahead", 0))
+        passes = self.acc.get("passes", 0) / max(1, self.acc["timed"])
+        if ahead <= 0:
+            return ("staged (GSV_REFILL_AHEAD=0): the prompt pass of a finished slot runs on a side stream, the slot joins at the next window "
+                    "after it; %.0f packed prompt passes per step on this rank" % passes)
+        sh = getattr(t2s, "_ahead", None)
+        mem = 0 if sh is None else sum(v.numel() * v.element_size() for v in sh.values() if torch.is_tensor(v))
+        return ("ahead: up to %d of the next requests are prefilled on a side stream into a second bound state (%d slots, %.0f MB of its own K/V "
+                "cache and state) and adopted by the slot that ends (gsv_t2s_adopt_slots); %.0f packed prompt passes per step on this rank"
+                % (ahead, 0 if sh is None else int(sh["slots"]), mem / 1e6, passes))
 
     def record(self, elapsed, steps, warmup):
         """every rank calls it (one all-reduce of the totals); -> the record (value = whole-job tokens/s over all ranks)"""
@@ -746,8 +869,7 @@ class CBWorkload:
                                    "(greedy, 50..400 new tokens per request), flow/Generator over every utterance in time-concatenated batches of 10"
                                    % (which, self.version, self.requests, self.slots),
                        "requests_per_step": self.n_req, "gpt_cache": [(self.slots, 512), (self.slots, 1024)],
-                       "refill": "reference order: every slot waits for the prompt pass (t2s_model.py:696-722)" if a.sync_refill else
-                                 "staged: the prompt pass of a finished slot runs on a side stream, the slot joins at the next window after it",
+                       "refill": self.refill_label(),
                        "queue_order": "longest first by prompt rows + token budget" if a.lpt_budget else "longest first by text length (the budgets are independent of it)",
                        "vocoder": "after the slot loop, length-balanced batches (TTS.py:705-764)" if (not a.overlap) else
                                   "overlapped with the slot loop on a side stream, batches of 10 in completion order",
@@ -763,6 +885,10 @@ class CBWorkload:
             "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
             "rank0_requests_served_per_step": acc["mine"] / steps,
         }
+        if a.stub_decoder:
+            out["data"] = "STUB: no kernels ran (--stub-decoder: CPU ranks, stub slot loop and vocoder); this line proves the control path, it measures nothing"
+            out["stub_requests_gathered_in_order_on_rank0"] = acc.get("stub_ordered", 0)
+            return out
         if self.rank == 0:
             # step-level roofline of the batched decode step on this rank: weights once per step + the K/V rows read
             wbytes = GPT_PARAMS * 2
@@ -810,7 +936,7 @@ def run_cb(a):
             wl = [50 + 17 * i for i in range(10)]
             vq.decode(torch.zeros(1, 1, sum(wl), dtype=torch.int64, device=dev), torch.cat([xs[i][40:] for i in range(10)])[None],
                       w.ge.expand(-1, -1, sum(wl)), noise_scale=0.5, cuda_graph=False)
-            torch.cuda.synchronize(dev)
+            _sync(dev)
             if dist is not None:
                 dist.barrier()
             q0 = time.perf_counter()
@@ -818,7 +944,7 @@ def run_cb(a):
             tokens = eng.exchange({int(i): p for i, p in zip(idx.tolist(), pred)}, n_req, dst=None)
             eng._retire_cursors(None)
             w.vocode_decode(tokens, vq)
-            torch.cuda.synchronize(dev)
+            _sync(dev)
             from gsv_tts_lite_amd import scheduler
             dt = scheduler.max_over_ranks(time.perf_counter() - q0, device=dev)
             out["value_with_enc_p"] = float(sum(len(p) for p in tokens)) / dt
@@ -834,12 +960,12 @@ def run_cb(a):
             first = list(range(min(a.slots, n_req)))
             ts = []
             for _ in range(12):
-                torch.cuda.synchronize(dev); q0 = time.perf_counter()
+                _sync(dev); q0 = time.perf_counter()
                 with torch.inference_mode():
                     xy, xl, yl, _, _ = t2s.embed_prompt([xs[c] for c in first], [ys[c] for c in first], [bs[c] for c in first])
                     t2s.prefill(a.slots, 0, xy, xl, yl)
                     t2s._decode(a.slots, 1)
-                torch.cuda.synchronize(dev); ts.append(time.perf_counter() - q0)
+                _sync(dev); ts.append(time.perf_counter() - q0)
             out["ttft_ms_p50_first_batch"] = sorted(ts[2:])[len(ts[2:]) // 2] * 1e3
             out["ttft_first_batch_note"] = "%d prompts (%d positions in all) in one packed prompt pass + the first decode step" % (
                 len(first), int(sum(int(xs[c].shape[0]) + int(ys[c].shape[0]) for c in first)))
@@ -864,6 +990,8 @@ def main():
     if a.cpu_baseline_worker:
         cpu_baseline_worker(a.cpu_baseline_worker, a.version)
         return
+    if a.stub_decoder:
+        a.no_extras = a.no_cpu_baseline = True
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
     if a.workload == "cb":

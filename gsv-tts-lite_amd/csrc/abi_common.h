@@ -41,6 +41,17 @@ int fail(int code, const char* fmt, ...) {
 
 namespace {
 
+// Device memory a HANDLE owns (packed weights, biases, scratch) is requested through these two calls, never through hipMalloc /
+// hipFree directly: a translation unit that keeps its handles' memory in an arena (gsv_abi.hip: GSV_DEV_ALLOC_ARENA, one arena per
+// GPT handle) routes them there; elsewhere they are the runtime's allocator.
+#ifdef GSV_DEV_ALLOC_ARENA
+template <typename T> inline hipError_t gsv_dev_malloc(T** p, size_t n) { return gsv_arena::amalloc((void**)p, n); }
+inline hipError_t gsv_dev_free(void* p) { return gsv_arena::afree(p); }
+#else
+template <typename T> inline hipError_t gsv_dev_malloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t gsv_dev_free(void* p) { return hipFree(p); }
+#endif
+
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -74,13 +85,13 @@ int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_
     if (pc.nphase > 10 || pc.ntaps > 12) return fail(GSV_ERR_ARG, "tapgemm: too many phases/taps");
     const size_t elems = (size_t)pc.nphase * pc.ntaps * pc.mtiles * (cin / KS) * 64 * (KS / 2);
     // + one all-zero fragment: what the pipelined loop fetches for iterations past the end
-    HIPCHK(hipMalloc(&pc.w, (elems + 64 * (KS / 2)) * sizeof(CT)));
+    HIPCHK(gsv_dev_malloc(&pc.w, (elems + 64 * (KS / 2)) * sizeof(CT)));
     HIPCHK(hipMemsetAsync((CT*)pc.w + elems, 0, 64 * (KS / 2) * sizeof(CT), st));
     const int blocks = (int)std::min<size_t>(2048, (elems + 255) / 256);
     hipLaunchKernelGGL((tapgemm_pack_kernel<CT>), dim3(blocks), dim3(256), 0, st, src, (CT*)pc.w, cout, cin, k, sm, sc,
                        sk, pc.nphase, pc.ntaps, u, pad, pc.mtiles);
     if (bias_src) {
-        HIPCHK(hipMalloc(&pc.bias, sizeof(float) * cout));
+        HIPCHK(gsv_dev_malloc(&pc.bias, sizeof(float) * cout));
         hipLaunchKernelGGL(scale_copy_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, bias_src, pc.bias, (size_t)cout,
                            bias_scale);
     }
@@ -89,10 +100,10 @@ int pack_conv(PackedConv& pc, const float* src, int cout, int cin, int k, int64_
 }
 
 void free_conv(PackedConv& pc) {
-    if (pc.w) (void)hipFree(pc.w);
-    if (pc.cg) (void)hipFree(pc.cg);
+    if (pc.w) (void)gsv_dev_free(pc.w);
+    if (pc.cg) (void)gsv_dev_free(pc.cg);
     pc.cg = nullptr;
-    if (pc.bias) (void)hipFree(pc.bias);
+    if (pc.bias) (void)gsv_dev_free(pc.bias);
     pc.w = nullptr; pc.bias = nullptr;
 }
 
@@ -237,7 +248,7 @@ inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slo
 // the plane-order copy of a wide resblock conv's weights (torch layout [C][C][k] fp32 in)
 inline int pack_cgemm(PackedConv& pc, const float* w, int C, int k, hipStream_t st) {
     if (!(C == 384 || C == 256 || C == 192)) return GSV_OK;
-    if (!pc.cg) HIPCHK(hipMalloc(&pc.cg, sizeof(bf16_t) * (size_t)C * C * k));
+    if (!pc.cg) HIPCHK(gsv_dev_malloc(&pc.cg, sizeof(bf16_t) * (size_t)C * C * k));
     if (C == 384) hipLaunchKernelGGL(cgemm_pack_kernel<384>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);
     else if (C == 256) hipLaunchKernelGGL(cgemm_pack_kernel<256>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);
     else hipLaunchKernelGGL(cgemm_pack_kernel<192>, dim3(1024), dim3(256), 0, st, w, (bf16_t*)pc.cg, k);

@@ -49,6 +49,8 @@ static hipError_t amalloc(void** p, size_t n) {
         }
     }
     if (reuse) {
+        // never reached under a stream capture (hipDeviceSynchronize would invalidate it): pieces come back only from a re-bind or a
+        // re-load, and neither is called from the captured step
         // kernels or graph replays on ANY stream (the side refill stream's staging, a hot-swapped conv) may still read the
         // piece's old contents: hipFree would have synchronised the device before the address could come back, so does this
         // (re-bind / re-load only: never on a step's path)
@@ -108,8 +110,7 @@ struct Scope {
     ~Scope() { g_cur = prev; }
 };
 }  // namespace gsv_arena
-#define hipMalloc(p, n) gsv_arena::amalloc((void**)(p), (n))
-#define hipFree(p) gsv_arena::afree((void*)(p))
+#define GSV_DEV_ALLOC_ARENA 1   // abi_common.h: this unit's gsv_dev_malloc / gsv_dev_free are the arena's
 
 #include "abi_common.h"
 #include "t2s_decode.h"
@@ -167,7 +168,7 @@ struct T2SBound {
 
 void t2s_free_staging(T2SBound& b) {
     for (void* p : {(void*)b.sg_kv, (void*)b.sg_x, (void*)b.sg_step, (void*)b.sg_eos, (void*)b.sg_logits, (void*)b.sg_hidden, (void*)b.sg_tok})
-        if (p) (void)hipFree(p);
+        if (p) (void)gsv_dev_free(p);
     b.sg_kv = b.sg_x = nullptr; b.sg_step = b.sg_eos = nullptr; b.sg_logits = b.sg_hidden = nullptr; b.sg_tok = nullptr;
 }
 
@@ -200,8 +201,8 @@ namespace {
 // e4m3 fragments + per-output-channel scales of one [cout][cin] linear (GSV_FP8 handles)
 int t2s_pack_fp8(const float* data, int cout, int cin, void** frag, float** scale, hipStream_t st) {
     const int mtiles = cdiv(cout, 32);
-    if (!*scale) HIPCHK(hipMalloc(scale, sizeof(float) * mtiles * 32));
-    if (!*frag) HIPCHK(hipMalloc(frag, (size_t)mtiles * (cin / 32) * 64 * 16));
+    if (!*scale) HIPCHK(gsv_dev_malloc(scale, sizeof(float) * mtiles * 32));
+    if (!*frag) HIPCHK(gsv_dev_malloc(frag, (size_t)mtiles * (cin / 32) * 64 * 16));
     HIPCHK(hipMemsetAsync(*scale, 0, sizeof(float) * mtiles * 32, st));
     hipLaunchKernelGGL(fp8_row_scale_kernel, dim3(cdiv(cout, 4)), dim3(256), 0, st, data, cin, *scale, cout);
     hipLaunchKernelGGL(fp8_pack_kernel, dim3(1024), dim3(256), 0, st, data, (const float*)*scale, (uint32_t*)*frag, cout, cin, mtiles);
@@ -211,7 +212,7 @@ int t2s_pack_fp8(const float* data, int cout, int cin, void** frag, float** scal
 
 // GSV_FP8 handles: the paired 16 x 16 x 32 e4m3 fragments of t2s_small.h (scales from t2s_pack_fp8, which runs first)
 int t2s_pack16_f8(void** dst, const float* data, const float* scale, int N, int K, hipStream_t st) {
-    if (!*dst) HIPCHK(hipMalloc(dst, (size_t)N * K));
+    if (!*dst) HIPCHK(gsv_dev_malloc(dst, (size_t)N * K));
     hipLaunchKernelGGL(pack16_f8_kernel, dim3(1024), dim3(256), 0, st, data, scale, (uint32_t*)*dst, N, K);
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -221,7 +222,7 @@ int t2s_pack16_f8(void** dst, const float* data, const float* scale, int N, int 
 template <typename WT>
 int t2s_pack16(void** dst, const float* data, int N, int K, hipStream_t st) {
     if (sizeof(WT) != 2) return GSV_OK;
-    if (!*dst) HIPCHK(hipMalloc(dst, sizeof(bf16_t) * (size_t)N * K));
+    if (!*dst) HIPCHK(gsv_dev_malloc(dst, sizeof(bf16_t) * (size_t)N * K));
     hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, st, data, (bf16_t*)*dst, N, K);
     HIPCHK(hipGetLastError());
     return GSV_OK;
@@ -233,14 +234,14 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
     auto want = [&](int64_t n) { return numel == n ? GSV_OK : fail(GSV_ERR_ARG, "layer %d %s: numel %lld, expected %lld", l, key.c_str(), (long long)numel, (long long)n); };
     auto copy_f32 = [&](float** dst, int64_t n, unsigned bit) -> int {
         if (int rc = want(n)) return rc;
-        if (!*dst) HIPCHK(hipMalloc(dst, sizeof(float) * n));
+        if (!*dst) HIPCHK(gsv_dev_malloc(dst, sizeof(float) * n));
         HIPCHK(hipMemcpyAsync(*dst, data, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
         L.have |= bit;
         return GSV_OK;
     };
     if (key == "qkv.weight") {
         if (int rc = want(3LL * kD * kD)) return rc;
-        if (!L.wqkv_p) HIPCHK(hipMalloc(&L.wqkv_p, sizeof(WT) * 3 * kD * kD));
+        if (!L.wqkv_p) HIPCHK(gsv_dev_malloc(&L.wqkv_p, sizeof(WT) * 3 * kD * kD));
         hipLaunchKernelGGL((pack_qkv_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.wqkv_p);
         float* keep = L.g_qkv.bias; L.g_qkv.bias = nullptr;
         free_conv(L.g_qkv);
@@ -252,14 +253,14 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         L.have |= 1u << 0;
     } else if (key == "qkv.bias") {
         if (int rc = want(3 * kD)) return rc;
-        if (!L.bqkv_p) HIPCHK(hipMalloc(&L.bqkv_p, sizeof(float) * 3 * kD));
+        if (!L.bqkv_p) HIPCHK(gsv_dev_malloc(&L.bqkv_p, sizeof(float) * 3 * kD));
         hipLaunchKernelGGL(pack_qkv_bias_kernel, dim3(6), dim3(256), 0, st, data, L.bqkv_p);
-        if (!L.g_qkv.bias) HIPCHK(hipMalloc(&L.g_qkv.bias, sizeof(float) * 3 * kD));
+        if (!L.g_qkv.bias) HIPCHK(gsv_dev_malloc(&L.g_qkv.bias, sizeof(float) * 3 * kD));
         HIPCHK(hipMemcpyAsync(L.g_qkv.bias, data, sizeof(float) * 3 * kD, hipMemcpyDeviceToDevice, st));
         L.have |= 1u << 1;
     } else if (key == "out_proj.weight") {
         if (int rc = want((int64_t)kD * kD)) return rc;
-        if (!L.wo_p) HIPCHK(hipMalloc(&L.wo_p, sizeof(WT) * kD * kD));
+        if (!L.wo_p) HIPCHK(gsv_dev_malloc(&L.wo_p, sizeof(WT) * kD * kD));
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(512), dim3(256), 0, st, data, (WT*)L.wo_p, kH, kDh);
         free_conv(L.g_out);
         if (int rc = pack_conv<WT>(L.g_out, data, kD, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
@@ -269,7 +270,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = copy_f32(&L.bo, kD, 1u << 3)) return rc;
     } else if (key == "mlp.0.weight") {
         if (int rc = want((int64_t)kF * kD)) return rc;
-        if (!L.w1) HIPCHK(hipMalloc(&L.w1, sizeof(WT) * kF * kD));
+        if (!L.w1) HIPCHK(gsv_dev_malloc(&L.w1, sizeof(WT) * kF * kD));
         hipLaunchKernelGGL((convert_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w1, (size_t)kF * kD);
         free_conv(L.g_w1);
         if (int rc = pack_conv<WT>(L.g_w1, data, kF, kD, 1, kD, 1, 0, 1, 0, 0, nullptr, 1.f, st)) return rc;
@@ -281,10 +282,10 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = copy_f32(&L.b1, kF, 1u << 5)) return rc;
     } else if (key == "mlp.2.weight") {
         if (int rc = want((int64_t)kD * kF)) return rc;
-        if (!L.w2_p) HIPCHK(hipMalloc(&L.w2_p, sizeof(WT) * kD * kF));
+        if (!L.w2_p) HIPCHK(gsv_dev_malloc(&L.w2_p, sizeof(WT) * kD * kF));
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p, kNJ, kFJ);
         if (sizeof(WT) == 2) {
-            if (!L.w2_p64) HIPCHK(hipMalloc(&L.w2_p64, sizeof(WT) * kD * kF));
+            if (!L.w2_p64) HIPCHK(gsv_dev_malloc(&L.w2_p64, sizeof(WT) * kD * kF));
             hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p64, kNJFine, kF / kNJFine);
         }
         free_conv(L.g_w2);
@@ -315,14 +316,14 @@ int t2s_load_io_tensor(gsv_t2s* h, const std::string& name, const float* data, i
     const gsv_t2s_config& c = h->cfg;
     auto copy_f32 = [&](float** dst, int64_t n, unsigned bit) -> int {
         if (numel != n) return fail(GSV_ERR_ARG, "%s: numel %lld, expected %lld", name.c_str(), (long long)numel, (long long)n);
-        if (!*dst) HIPCHK(hipMalloc(dst, sizeof(float) * n));
+        if (!*dst) HIPCHK(gsv_dev_malloc(dst, sizeof(float) * n));
         HIPCHK(hipMemcpyAsync(*dst, data, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
         h->have_io |= bit;
         return GSV_OK;
     };
     if (name == "ar_predict_layer.weight") {
         if (numel != (int64_t)c.vocab * kD) return fail(GSV_ERR_ARG, "%s: bad numel", name.c_str());
-        if (!h->predict) HIPCHK(hipMalloc(&h->predict, sizeof(WT) * c.vocab * kD));
+        if (!h->predict) HIPCHK(gsv_dev_malloc(&h->predict, sizeof(WT) * c.vocab * kD));
         hipLaunchKernelGGL((convert_kernel<WT>), dim3(512), dim3(256), 0, st, data, (WT*)h->predict, (size_t)c.vocab * kD);
         h->have_io |= 1u << 0;
     } else if (name == "ar_audio_embedding.word_embeddings.weight") {
@@ -354,13 +355,13 @@ int t2s_load_io_tensor(gsv_t2s* h, const std::string& name, const float* data, i
 int t2s_ensure_scratch(gsv_t2s* h, int B) {
     if (B <= h->scratch_b) return GSV_OK;
     for (void* p : {(void*)h->xcur, (void*)h->xbuf, (void*)h->x1buf, (void*)h->ypart, (void*)h->zpart, (void*)h->tokpart})
-        if (p) (void)hipFree(p);
-    HIPCHK(hipMalloc(&h->xcur, sizeof(float) * B * kD));
-    HIPCHK(hipMalloc(&h->xbuf, sizeof(float) * B * kD));
-    HIPCHK(hipMalloc(&h->x1buf, sizeof(float) * B * kD));
-    HIPCHK(hipMalloc(&h->ypart, sizeof(float) * B * kH * kD));
-    HIPCHK(hipMalloc(&h->zpart, sizeof(float) * B * kNJ * kD));
-    HIPCHK(hipMalloc(&h->tokpart, sizeof(TokPart) * B * kNP));
+        if (p) (void)gsv_dev_free(p);
+    HIPCHK(gsv_dev_malloc(&h->xcur, sizeof(float) * B * kD));
+    HIPCHK(gsv_dev_malloc(&h->xbuf, sizeof(float) * B * kD));
+    HIPCHK(gsv_dev_malloc(&h->x1buf, sizeof(float) * B * kD));
+    HIPCHK(gsv_dev_malloc(&h->ypart, sizeof(float) * B * kH * kD));
+    HIPCHK(gsv_dev_malloc(&h->zpart, sizeof(float) * B * kNJ * kD));
+    HIPCHK(gsv_dev_malloc(&h->tokpart, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
     h->scratch_b = B;
     // graphs captured against the old scratch pointers are stale
@@ -555,8 +556,7 @@ int t2s_gemm_chain(gsv_t2s* h, int M, float* x0, const ChainBufs& c, bool f8, At
     // (bgemm_wide_kernel: 128 rows staged once per block, a wave per column tile over the full K, weights three groups ahead)
     static const int wide_min = getenv("GSV_WIDE_MIN_M") ? atoi(getenv("GSV_WIDE_MIN_M")) : kWideMinM;
     const bool wide = prompt && !f8 && M >= wide_min;
-    auto run_wide = [&](auto kern, bool w2, BGemmArgs ba) -> int {
-        HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
+    auto run_wide = [&](auto kern, bool w2, BGemmArgs ba) -> int {   // its LDS attribute is set once, at gsv_t2s_finalize
         const int rgroups = cdiv(M, 32 * kWideRT), cgroups = cdiv(ba.mtiles, 4 * kWideTPW);
         // column groups per block: the block count that costs the fewest rounds of (stage the rows once + walk the groups)
         int gpb = 1;
@@ -981,13 +981,13 @@ int gsv_t2s_destroy(gsv_t2s* h) {
         for (void* p : {L.wqkv_p, L.wo_p, L.w1, L.w2_p, L.w2_p64, L.p16_qkv, L.p16_out, L.p16_w1, L.p16_w2, L.p8_qkv, L.p8_w1, L.p8_w2, (void*)L.bqkv_p, (void*)L.bo, (void*)L.b1, (void*)L.b2,
                         (void*)L.ln1g, (void*)L.ln1b, (void*)L.ln2g, (void*)L.ln2b, L.f8_qkv, L.f8_w1, L.f8_w2,
                         (void*)L.s_qkv, (void*)L.s_w1, (void*)L.s_w2})
-            if (p) (void)hipFree(p);
+            if (p) (void)gsv_dev_free(p);
         free_conv(L.g_qkv); L.g_out.bias = nullptr; free_conv(L.g_out); L.g_w1.bias = nullptr; free_conv(L.g_w1);
         L.g_w2.bias = nullptr; free_conv(L.g_w2);
     }
     for (void* p : {h->predict, (void*)h->emb_audio, (void*)h->emb_text, (void*)h->pe_audio, (void*)h->pe_text,
                     (void*)h->xcur, (void*)h->xbuf, (void*)h->x1buf, (void*)h->ypart, (void*)h->zpart, (void*)h->tokpart})
-        if (p) (void)hipFree(p);
+        if (p) (void)gsv_dev_free(p);
     free_conv(h->g_bert);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     gsv_arena::release(h->arena);
@@ -1022,6 +1022,10 @@ int gsv_t2s_finalize(gsv_t2s* h, void* stream) {
     if (h->have_io != 0x7fu) return fail(GSV_ERR_STATE, "embedding/predict tensors incomplete (mask 0x%x)", h->have_io);
     if (h->cfg.dtype == GSV_BF16) {
         HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
+        // the wide prompt-pass GEMMs (every instantiation t2s_batched_layers launches): once here, not per launch (5 x n_layer calls per pass)
+        HIPCHK(hipFuncSetAttribute((const void*)bgemm_wide_kernel<PRO_NONE, float, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
+        HIPCHK(hipFuncSetAttribute((const void*)bgemm_wide_kernel<PRO_LN, float, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
+        HIPCHK(hipFuncSetAttribute((const void*)bgemm_wide_kernel<PRO_NONE, bf16_t, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideLds));
         if (int rc = t2s_multi_lds_attr<bf16_t>()) return rc;
     } else {
         HIPCHK(hipFuncSetAttribute((const void*)t2s_prefill_attn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPrefillLdsMax));
@@ -1047,13 +1051,26 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
     b.st.eos_host = nullptr;
     t2s_free_staging(b);
     const size_t B = (size_t)st->batch;
-    HIPCHK(hipMalloc(&b.sg_kv, 8 * B)); HIPCHK(hipMalloc(&b.sg_x, 8 * B));
-    HIPCHK(hipMalloc(&b.sg_step, 4 * B)); HIPCHK(hipMalloc(&b.sg_eos, 4 * B));
-    HIPCHK(hipMalloc(&b.sg_logits, sizeof(float) * B * h->cfg.vocab)); HIPCHK(hipMalloc(&b.sg_hidden, sizeof(float) * B * kD));
-    HIPCHK(hipMalloc(&b.sg_tok, sizeof(TokPart) * B * kNP));
+    HIPCHK(gsv_dev_malloc(&b.sg_kv, 8 * B)); HIPCHK(gsv_dev_malloc(&b.sg_x, 8 * B));
+    HIPCHK(gsv_dev_malloc(&b.sg_step, 4 * B)); HIPCHK(gsv_dev_malloc(&b.sg_eos, 4 * B));
+    HIPCHK(gsv_dev_malloc(&b.sg_logits, sizeof(float) * B * h->cfg.vocab)); HIPCHK(gsv_dev_malloc(&b.sg_hidden, sizeof(float) * B * kD));
+    HIPCHK(gsv_dev_malloc(&b.sg_tok, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(b.sg_step, 0, 4 * B));
     HIPCHK(hipMemset(b.sg_kv, 0, 8 * B)); HIPCHK(hipMemset(b.sg_x, 0, 8 * B));
     HIPCHK(hipMemset(b.sg_eos, 0xff, 4 * B));      // -1: no EOS seen
+    return GSV_OK;
+}
+
+int gsv_t2s_unbind_state(gsv_t2s* h, int batch) {
+    if (!h) return fail(GSV_ERR_ARG, "null handle");
+    GSV_ARENA_SCOPE(h);
+    auto it = h->bound.find(batch);
+    if (it == h->bound.end()) return GSV_OK;
+    T2SBound& b = it->second;
+    if (b.graph) (void)hipGraphExecDestroy(b.graph);
+    if (b.graph_ft) (void)hipGraphExecDestroy(b.graph_ft);
+    t2s_free_staging(b);
+    h->bound.erase(it);
     return GSV_OK;
 }
 
@@ -1150,6 +1167,8 @@ int gsv_t2s_adopt_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int
     if (d == sb) return fail(GSV_ERR_ARG, "adopt_slots: source and destination are the same state");
     if (!slots_dst || !slots_src || nrows < 1 || nrows > batch_dst || nrows > batch_src) return fail(GSV_ERR_ARG, "adopt_slots: need 1..batch slot pairs (host arrays)");
     if (d->st.k_cache == sb->st.k_cache || d->st.v_cache == sb->st.v_cache) return fail(GSV_ERR_ARG, "adopt_slots: the two states share their KV cache");
+    // a source row longer than the destination cache could not be copied whole, and the state kernel would still publish its length
+    if (sb->st.max_kv > d->st.max_kv) return fail(GSV_ERR_ARG, "adopt_slots: the source cache (%d positions) is longer than the destination's (%d)", sb->st.max_kv, d->st.max_kv);
     for (int i = 0; i < nrows; ++i) {
         if (slots_dst[i] < 0 || slots_dst[i] >= batch_dst || slots_src[i] < 0 || slots_src[i] >= batch_src) return fail(GSV_ERR_ARG, "adopt_slots: slot out of range");
         for (int j = 0; j < i; ++j) if (slots_dst[j] == slots_dst[i]) return fail(GSV_ERR_ARG, "adopt_slots: destination slot %d listed twice", slots_dst[i]);

@@ -1071,7 +1071,9 @@ int gsv_voc_flow_dec_graph(gsv_voc* v, const float* z_p, const float* y_mask, co
             auto old = v->graphs.begin();
             for (auto jt = v->graphs.begin(); jt != v->graphs.end(); ++jt)
                 if (jt->second.last_use < old->second.last_use) old = jt;
-            HIPCHK(hipStreamSynchronize(S(stream)));       // its last replay was enqueued on the caller's stream
+            // its last replay may have been enqueued on ANY stream (a per-request side stream of the engine), not only the caller's:
+            // eviction is rare, so the whole device drains before the exec goes
+            HIPCHK(hipDeviceSynchronize());
             (void)hipGraphExecDestroy(old->second.exec);
             v->graphs.erase(old);
         }

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(NW * 64) void bgemm_kernel(BGemmArgs a) {
 #define GSV_WIDE_PD 3
 #endif
 constexpr int kWideRT = GSV_WIDE_RT, kWideTPW = GSV_WIDE_TPW, kWidePD = GSV_WIDE_PD;
+static_assert(kWideRT % 2 == 0, "bgemm_wide_kernel stages its fp32 rows two row tiles at a time: an odd GSV_WIDE_RT writes past the stage");
 template <int PRO, typename XT, typename OT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bgemm_wide_kernel(BGemmArgs a) {
     constexpr int RT = kWideRT, TPW = kWideTPW, PD = kWidePD;

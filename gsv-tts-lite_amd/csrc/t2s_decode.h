@@ -1063,7 +1063,32 @@ __device__ __forceinline__ int t2s_sample_wave(const float* __restrict__ lg, int
     uint32_t removed = 0u;
     const bool compact = k > 0 && k < V && k <= 64;      // the k entries taken are handed to lanes 0 .. k-1 as they are found
     float cx = -INFINITY; int cv = 0x7fffffff;
-    if (k > 0 && k < V) {
+    if (k > 64 && k < V) {
+        // many taken entries (up to V - 1): k rounds of arg-max would be O(k) dependent wave reductions.  The pivot is the k-th
+        // largest entry = the largest t with #{x >= t} >= k, found by bisection over the ORDER-PRESERVING bit pattern of a float
+        // (sign flipped for positives, all bits for negatives; -inf entries count as entries, as they do for torch.topk): 32 counts.
+        unsigned key[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const unsigned b = __float_as_uint(x[i]);
+            key[i] = lane + 64 * i < V ? (b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u)) : 0u;   // 0: below every real entry (-inf is 0x007fffff)
+        }
+        unsigned lo = 0u, hi = 0xffffffffu;              // count(key >= lo) >= k always holds at lo = 0 once slots beyond V are excluded
+        for (int it = 0; it < 32; ++it) {
+            const unsigned mid = lo + ((hi - lo) >> 1) + ((hi - lo) & 1u);     // upper middle: the search ends on lo
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) c += (lane + 64 * i < V && key[i] >= mid) ? 1 : 0;
+            if ((int)wave_sum((float)c) >= k) lo = mid; else hi = mid - 1u;   // counts <= V: exact in fp32
+            if (lo == hi) break;
+        }
+        const unsigned pb = lo ^ ((lo >> 31) ? 0x80000000u : 0xffffffffu);
+        pivot = __uint_as_float(pb);
+        float bv = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) bv = fmaxf(bv, x[i]);
+        top = wave_max(bv);
+    } else if (k > 0 && k < V) {
         for (int r = 0; r < k; ++r) {
             float bv = -INFINITY; int bs = -1;
 #pragma unroll

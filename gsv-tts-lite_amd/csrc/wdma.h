@@ -48,12 +48,13 @@ struct WDmaArgs {
 // `__builtin_amdgcn_global_load_lds` hipcc books the instruction as a FLAT access that may touch LDS, and while one is pending every
 // LDS wait it places is `lgkmcnt(0)` -- the MFMA loop's counted B-fragment waits (three groups in flight) became full drains
 // (7.7k instead of 6.2k cycles per 128-channel tile).  Hidden in asm, the DMA is invisible to that bookkeeping; the waits on it
-// are the explicit ones below.  One wait state between the M0 write and its use.
+// are the explicit ones below.  One wait state between the M0 write and its use; five in front of the statement, because its
+// scalar base may come fresh from a v_readfirstlane and hipcc pads nothing inside an asm string.
 __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_addr) {   // scalar base + per-lane byte offset
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ void dma16(const void* vaddr, unsigned lds_addr) {                  // per-lane 64-bit address
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(vaddr) : "memory", "m0");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(vaddr) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {   // wave-uniform LDS byte address of a __shared__ pointer
     typedef __attribute__((address_space(3))) const unsigned char lds_uc;

@@ -51,9 +51,10 @@ class RequestSource:
     """Hands out global request indices in `order`.  Single process: sequentially.  Multi-rank: `chunk` at a time
     from a cursor shared through `store` (every rank constructs the source with the same `order` and `key`)."""
 
-    def __init__(self, order: Sequence[int], store=None, key: str = "gsv/cursor", chunk: int = 2):
+    def __init__(self, order: Sequence[int], store=None, key: str = "gsv/cursor", chunk: int = 2, world: int = 1):
         self.order = list(order)
         self.store, self.key, self.chunk = store, key, max(1, int(chunk))
+        self.world = max(1, int(world))      # ranks pulling from the cursor (fair_share)
         self._local: List[int] = []
         self._pos = 0            # store-less cursor
         self.taken: List[int] = []
@@ -72,6 +73,18 @@ class RequestSource:
         i = self._local.pop(0)
         self.taken.append(i)
         return i
+
+    def fair_share(self) -> int:
+        """How many more requests this rank may take AHEAD of its free slots without starving the others: what is left of the
+        queue over the ranks that pull from it, rounded up.  A rank that prefills ahead (t2s._infer_batched_ahead) asks before each
+        packed prompt pass; without the cap one rank could hold `refill_ahead` requests of the queue's tail while other ranks'
+        slots sit empty.  One read of the shared cursor (`add(key, 0)`), once per pass."""
+        if self.store is None:
+            left = len(self.order) - self._pos
+        else:
+            left = len(self.order) - int(self.store.add(self.key, 0))
+        left = max(0, left) + len(self._local)
+        return -(-left // self.world)
 
 
 _RUN_COUNTER = itertools.count()
@@ -150,7 +163,7 @@ class ContinuousBatchingEngine:
             return RequestSource([i for i in order if i in mine], None, chunk=len(order) or 1)
         key = "gsv/cursor/%d" % run
         self._cursor_keys.append(key)
-        return RequestSource(order, self.store, key=key, chunk=self.chunk)
+        return RequestSource(order, self.store, key=key, chunk=self.chunk, world=self.world)
 
     def _retire_cursors(self, dst: Optional[int] = None):
         """a finished run's cursor key leaves the rendezvous store (a long-lived server would grow it by one key per

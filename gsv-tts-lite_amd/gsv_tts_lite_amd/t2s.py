@@ -59,24 +59,6 @@ def _sine_pe(n_pos, dim):
     return pe
 
 
-def sample_from_logits(logits, top_k=15, top_p=1.0, temperature=1.0, generator=None):
-    """Stochastic tail of GPT/utils.py:29-59 on logits that already carry suppression and the
-    repetition penalty (both applied on device by the logits kernel)."""
-    if top_p is not None and top_p < 1.0:
-        sl, si = torch.sort(logits, descending=True)
-        cum = torch.cumsum(torch.softmax(sl, dim=-1), dim=-1)
-        rem = cum > top_p
-        rem[:, 0] = False
-        logits = logits.masked_fill(rem.scatter(1, si, rem), -float("inf"))
-    logits = logits / max(temperature, 1e-5)
-    if top_k is not None:
-        v, _ = torch.topk(logits, min(top_k, logits.size(-1)))
-        logits = torch.where(logits < v[:, -1:], -float("inf"), logits)
-    probs = torch.softmax(logits, dim=-1)
-    q = torch.empty_like(probs).exponential_(1, generator=generator)
-    return torch.argmax(probs / q, dim=-1)
-
-
 class Text2SemanticDecoder:
     def __init__(self, config):
         m = config["model"]
@@ -96,9 +78,8 @@ class Text2SemanticDecoder:
         self.step_priority = int(os.environ.get("GSV_STEP_PRIO", "0"))     # ... and of the stream the slot loop's steps run on
         self.refill_ahead = int(os.environ.get("GSV_REFILL_AHEAD", "8"))   # async_refill: requests prefilled AHEAD of the slots that will run them (0: the park / prompt pass / commit loop)
         self.use_graph = True
-        self.fuse_token_step = os.environ.get("GSV_FUSE_TOKEN", "1") != "0"  # greedy / host-sampled steps: layer 0's attention kernel does the token kernel's work (<= 16 sequences)
+        self.fuse_token_step = os.environ.get("GSV_FUSE_TOKEN", "1") != "0"  # greedy steps: layer 0's attention kernel does the token kernel's work (<= 16 sequences)
         self._eos_pipe = None
-        self.device_sampling = True   # top-k / temperature sampling inside the captured step (top_p < 1: host path)
         self._weights = None
         self._h = None
         self._rt = {}
@@ -336,6 +317,10 @@ class Text2SemanticDecoder:
         sh = getattr(self, "_ahead", None)
         if sh is not None and sh["key"] == key:
             return sh
+        if sh is not None:                    # a state of another shape: the handle must not keep pointers into tensors about to go
+            torch.cuda.synchronize(self.device)
+            N.check(N.lib().gsv_t2s_unbind_state(self._h, int(sh["batch"])))
+            self._ahead = None
         S = n_slots
         while S in self._rt:
             S += 1
@@ -386,7 +371,7 @@ class Text2SemanticDecoder:
 
     def _set_ctl(self, rt, mode, suppress_steps, rep_enabled, rep, top_k=0, temperature=1.0, seed=0, top_p=1.0,
                  suppress_first=False):
-        """mode 0 = greedy on device, 1 = host-sampled tokens (tok_override), 2 = device sampling; suppress_first: the
+        """mode 0 = greedy on device, 2 = device sampling (1, host-sampled tokens through tok_override, is the C ABI's and unused here); suppress_first: the
         prefill's sample never takes 280 / 486 / EOS whatever suppress_steps is (infer / infer_stream, t2s_model.py:415-416)"""
         lo, hi = int(seed) & 0x7fffffff, (int(seed) >> 31) & 0x7fffffff
         rt["fused_ok"] = int(mode) != 2
@@ -396,12 +381,10 @@ class Text2SemanticDecoder:
                                       dtype=torch.float32))
 
     def _sampling_mode(self, top_k, top_p, generator):
-        """(mode, seed): greedy stays the device argmax; top-p / temperature / top-k sampling runs on device unless
-        device sampling is switched off (then: host-sampled tokens, one step per launch)."""
+        """(mode, seed): greedy is the device argmax; every other setting (temperature, top-k up to the whole vocabulary, top-p)
+        is sampled on device inside the captured step (csrc/t2s_decode.h::t2s_sample_wave).  There is no host sampling path."""
         if top_k == 1:
             return 0, 0
-        if not self.device_sampling or (top_k is not None and top_k > 256):
-            return 1, 0
         if generator is not None:   # the caller's generator (CPU or device) seeds the device noise stream
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
         else:
@@ -427,7 +410,6 @@ class Text2SemanticDecoder:
         if max_new_tokens is not None:
             n_iter = max(1, min(n_iter, int(max_new_tokens)))
         mode, seed = self._sampling_mode(top_k, top_p, generator)
-        greedy = mode != 1   # the device loop serves greedy and device sampling alike
         rep_on = repetition_penalty != 1.0
         self._set_ctl(rt, mode, initial_suppression_steps, rep_on, repetition_penalty, top_k, temperature, seed, top_p,
                       suppress_first=True)
@@ -440,61 +422,45 @@ class Text2SemanticDecoder:
         self.prefill(1, 0, xy, xl, yl)
         done = 0
         eos_at = -1
-        if greedy:
-            # The reference tests for EOS on the host every `check_interval` steps (t2s_model.py:451-453).  Same
-            # cadence here, but the test of chunk i is read AFTER chunk i+1 has been enqueued (async copy of the
-            # flag into pinned memory + an event), so the GPU never idles on the host round trip.  A chunk that
-            # runs past the EOS costs nothing observable: tokens are cut at the first EOS anyway (:459-462).
-            # The flag itself is not copied either: the kernels publish eos_at to a host-mapped mirror
-            # (gsv_t2s_set_eos_mirror), the host reads its own memory once the window's event has fired.  (A device-to-host
-            # copy between the windows cost 0 - 15 us per token, bimodal from run to run.)  The pending sample of a window
-            # becomes a token at the next step, so an EOS is seen at most one window late; only the last window is flushed.
-            if self._eos_pipe is None:
-                self._eos_pipe = [torch.cuda.Event() for _ in range(2)]
-            mirror = rt["eos_host"]
-            pending = None
-            pending_done = 0
-            k = 0
-            while done < n_iter:
-                n = min(check_interval, n_iter - done)
-                self._decode(1, n)
-                done += n
-                if done >= n_iter:
-                    self._flush(1)
-                ev = self._eos_pipe[k]
-                k ^= 1
-                ev.record()
-                if pending is not None:
-                    if os.environ.get("GSV_EV_SPIN"):
-                        while not pending.query():
-                            pass
-                    else:
-                        pending.synchronize()
-                    # the mirror may already hold an EOS of the window enqueued AFTER the one just waited for (the GPU runs
-                    # ahead of this read): only an EOS recorded by a step of the waited-for windows counts, so the number of
-                    # windows a run executes -- and with it the state it leaves behind -- does not depend on timing
-                    e = int(mirror[0])
-                    if 0 <= e < pending_done:
-                        break
-                pending = ev
-                pending_done = done
-            torch.cuda.current_stream(self.device).synchronize()
-            eos_at = int(mirror[0])
-        else:
-            while done < n_iter:
-                tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
-                rt["tok_override"].copy_(tok)
-                self._decode(1, 1)
-                done += 1
-                if done % check_interval == 0:
-                    eos_at = int(rt["eos_at"][0].item())
-                    if eos_at >= 0:
-                        break
-            if eos_at < 0:
-                tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
-                rt["tok_override"].copy_(tok)
+        # The reference tests for EOS on the host every `check_interval` steps (t2s_model.py:451-453).  Same
+        # cadence here, but the test of chunk i is read AFTER chunk i+1 has been enqueued (async copy of the
+        # flag into pinned memory + an event), so the GPU never idles on the host round trip.  A chunk that
+        # runs past the EOS costs nothing observable: tokens are cut at the first EOS anyway (:459-462).
+        # The flag itself is not copied either: the kernels publish eos_at to a host-mapped mirror
+        # (gsv_t2s_set_eos_mirror), the host reads its own memory once the window's event has fired.  (A device-to-host
+        # copy between the windows cost 0 - 15 us per token, bimodal from run to run.)  The pending sample of a window
+        # becomes a token at the next step, so an EOS is seen at most one window late; only the last window is flushed.
+        if self._eos_pipe is None:
+            self._eos_pipe = [torch.cuda.Event() for _ in range(2)]
+        mirror = rt["eos_host"]
+        pending = None
+        pending_done = 0
+        k = 0
+        while done < n_iter:
+            n = min(check_interval, n_iter - done)
+            self._decode(1, n)
+            done += n
+            if done >= n_iter:
                 self._flush(1)
-                eos_at = int(rt["eos_at"][0].item())
+            ev = self._eos_pipe[k]
+            k ^= 1
+            ev.record()
+            if pending is not None:
+                if os.environ.get("GSV_EV_SPIN"):
+                    while not pending.query():
+                        pass
+                else:
+                    pending.synchronize()
+                # the mirror may already hold an EOS of the window enqueued AFTER the one just waited for (the GPU runs
+                # ahead of this read): only an EOS recorded by a step of the waited-for windows counts, so the number of
+                # windows a run executes -- and with it the state it leaves behind -- does not depend on timing
+                e = int(mirror[0])
+                if 0 <= e < pending_done:
+                    break
+            pending = ev
+            pending_done = done
+        torch.cuda.current_stream(self.device).synchronize()
+        eos_at = int(mirror[0])
         # sample s_i sits at kv position Lp + i; s_0 (the prefill sample) is never returned
         n_valid = done if eos_at < 0 else min(done, eos_at - 1)
         out = rt["pre_tokens"][0, Lp + 1: Lp + 1 + n_valid].clone()
@@ -533,15 +499,9 @@ class Text2SemanticDecoder:
         while done < n_iter:
             with torch.inference_mode():
                 to_boundary = stream_chunk - done % stream_chunk
-                n = min(5 if mode != 1 else 1, to_boundary, n_iter - done)
-                if mode == 1:
-                    tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
-                    rt["tok_override"].copy_(tok)
+                n = min(5, to_boundary, n_iter - done)
                 self._decode(1, n)
                 done += n
-                if mode == 1:
-                    tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
-                    rt["tok_override"].copy_(tok)
                 self._flush(1)      # materialises sample s_done; idempotent
                 eos_at = int(rt["eos_at"][0].item())
                 if eos_at >= 0:     # s_eos_at is the EOS: the reference breaks at idx = eos_at
@@ -810,8 +770,12 @@ class Text2SemanticDecoder:
                 keep.clear()
             if not force and len(free_src) < max(1, S // 2) and ready:
                 return                  # a pass of few rows costs what a pass of many costs: wait until half the slots are free
+            # N ranks pull from one queue: near its end a rank takes ahead no more than its share of what is left
+            # (engine.RequestSource.fair_share), so the tail is not parked in one rank's ahead slots while others idle
+            share = getattr(getattr(nxt, "__self__", None), "fair_share", None)
+            quota = len(free_src) if share is None else max(1, min(len(free_src), share()))
             group = []
-            while free_src and not exhausted:
+            while free_src and not exhausted and len(group) < quota:
                 cur = nxt()
                 if cur is None:
                     exhausted = True
@@ -1002,8 +966,7 @@ class Text2SemanticDecoder:
         if actual == 0:
             return [], torch.zeros(0, dtype=torch.int64, device=dev)
         mode, seed = self._sampling_mode(top_k, top_p, generator)
-        greedy = mode != 1
-        if async_refill and mode != 1 and self.refill_ahead > 0:
+        if async_refill and self.refill_ahead > 0:
             # bound BEFORE the first prompt pass: binding a state may re-allocate the handle's per-slot scratch (pending tokens)
             self._ahead_state(max(1, min(self.refill_ahead, batch_size)), max(caps))
         self._set_ctl(rt, mode, 0, False, 1.0, top_k, temperature, seed, top_p)
@@ -1024,7 +987,7 @@ class Text2SemanticDecoder:
         if mode == 2:       # device sampling: the noise stream of a slot is its REQUEST (placement-invariant samples)
             rt["tok_override"].zero_()
             rt["tok_override"][:actual] = torch.tensor([c + 1 for c in first], dtype=torch.int64, device=dev)
-        if async_refill and mode != 1:      # host-sampled tokens need every refill's logits at once: reference order
+        if async_refill:
             try:
                 loop = self._infer_batched_ahead if self.refill_ahead > 0 else self._infer_batched_staged
                 return loop(x, y, bert_feature, batch_size, first, nxt, exhausted,
@@ -1033,12 +996,6 @@ class Text2SemanticDecoder:
             finally:    # also on an exception (a prompt that does not fit): no prompt pass may outlive the call
                 if getattr(self, "_refill_stream", None) is not None:
                     self._refill_stream.synchronize()
-
-        have_tok = False
-
-        def draw():
-            tok = sample_from_logits(rt["logits"], top_k, top_p, temperature, generator)
-            rt["tok_override"].copy_(tok)
 
         pred, orig = [], []
         self.last_stats = {"slots": batch_size, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0}
@@ -1050,16 +1007,9 @@ class Text2SemanticDecoder:
         since = 0
         while not stop:
             # the reference tests after steps 1, 6, 11, ... of each 1000-iteration inner loop
-            if greedy:
-                n = 1 if idx == 0 else check_interval
-                n = min(n, 1000 - idx) if idx else 1
-                self._decode(batch_size, n)
-            else:
-                n = 1
-                if not have_tok:
-                    draw()
-                have_tok = False
-                self._decode(batch_size, 1)
+            n = 1 if idx == 0 else check_interval
+            n = min(n, 1000 - idx) if idx else 1
+            self._decode(batch_size, n)
             for b in range(batch_size):
                 steps[b] += n
             self.last_stats["steps"] += n
@@ -1070,9 +1020,6 @@ class Text2SemanticDecoder:
                 idx = 0
             if last % check_interval != 0:
                 continue
-            if not greedy:
-                draw()
-                have_tok = True
             self._flush(batch_size)
             kv = rt["kv_len"].clone()
             samples = rt["pre_tokens"][rows, kv.clamp(max=rt["T"])]
@@ -1142,7 +1089,4 @@ class Text2SemanticDecoder:
                 if mode == 2:
                     rt["tok_override"][torch.tensor([i for i, _ in refill], device=dev)] = \
                         torch.tensor([c + 1 for _, c in refill], dtype=torch.int64, device=dev)
-                if not greedy:  # every refilled slot needs its own first sample, drawn in slot order (t2s_model.py:713-714)
-                    for i, _ in refill:
-                        rt["tok_override"][i] = sample_from_logits(rt["logits"][i: i + 1], top_k, top_p, temperature, generator)[0]
         return pred, torch.tensor(orig, device=dev)

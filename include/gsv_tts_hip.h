@@ -98,6 +98,10 @@ typedef struct {
     float* fctl;            /* [4]   {repetition_penalty, temperature, top_p, -} */
 } gsv_t2s_state;
 int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st);
+/* Forgets the state bound for `batch`: its captured steps are destroyed and its staging goes back to the handle, so the caller may
+ * free the tensors the state pointed at (the reference rebuilds its runtime the same way: initialize_runtime, t2s_model.py:210-298,
+ * drops the old buckets).  The caller makes sure nothing of that state is still running.  Unknown batch: GSV_OK. */
+int gsv_t2s_unbind_state(gsv_t2s* h, int batch);
 /* Optional: `host_mapped` [batch] int32 in host memory the device can write (hipHostMalloc / a pinned torch tensor), or
  * NULL to turn it off.  Every kernel that sets state.eos_at[slot] then also publishes the value there (system-scope store),
  * so the host loop of t2s_model.py:451-453 reads the EOS flag from its own memory after an event instead of enqueuing a

@@ -190,6 +190,9 @@ def gen_sample(sample):
         (dict(top_k=5, top_p=0.8, temperature=0.7, repetition_penalty=1.2), True),
         (dict(top_k=15, top_p=1.0, temperature=1.0, repetition_penalty=1.35), False),
         (dict(top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=1.35), True),
+        # many kept entries / the whole vocabulary: the device sampler finds the k-th largest by bisection from k = 65 on
+        (dict(top_k=300, top_p=1.0, temperature=0.9, repetition_penalty=1.35), True),
+        (dict(top_k=1025, top_p=1.0, temperature=1.0, repetition_penalty=1.0), False),
     ]):
         lg = (g.standard_normal((3, 1025)) * 3).astype(np.float32)
         lg[:, [280, 486]] = -np.inf

@@ -298,25 +298,66 @@ def test_device_sampler_matches_its_restatement_and_the_reference_distribution(d
         assert int(rt["pre_tokens"][0, 3].item()) == orc.device_sample(logits, 0, 1.0, 99, 0, 3, 2)[0]
 
 
+@pytest.mark.parametrize("top_k", [64, 65, 300, 1024, 1025])
+def test_device_sampler_with_many_kept_entries(golden_dir, dev, top_k):
+    """top_k beyond 64 up to the whole vocabulary stays on the device (from 65 on the k-th largest entry is found by bisection
+    over the floats' order-preserving bit pattern instead of k arg-max rounds; there is no host sampling path): on the logits of
+    the reference's own top_k = 300 / 1025 cases (sample.npz c4 / c5, whose probabilities pin oracle.logits_to_probs) and on
+    logits with ties AT the pivot and fewer finite entries than k, draw by draw against oracle.device_sample, and never a token
+    outside the kept set."""
+    from oracle import oracle as orc
+    g = np.load(os.path.join(golden_dir, "sample.npz"))
+    cfg = synth.gpt_config(n_layer=1)
+    m = _model(cfg, synth.gpt_weights(cfg, seed=5), [(1, 64)], torch.float32, dev)
+    rt = m._rt[1]
+    V = 1025
+    rng = np.random.default_rng(top_k)
+    tie = (rng.standard_normal(V) * 2.0).astype(np.float32)
+    if top_k < V:
+        piv = np.sort(tie)[::-1][top_k - 1]
+        tie[[3, 900]] = piv                                # two more entries exactly at the pivot: all of them stay
+    few = np.full(V, -np.inf, np.float32)
+    few[rng.choice(V, 40, replace=False)] = (rng.standard_normal(40) * 3).astype(np.float32)   # 40 finite entries < k
+    cases = [g["c4_logits"][0], g["c5_logits"][1], tie, few]
+    temp = 0.9
+    with torch.inference_mode():
+        for ci, logits in enumerate(cases):
+            logits = logits.astype(np.float32)
+            ref_p = orc.device_sample_probs(logits, top_k, temp)
+            rt["logits"][0].copy_(torch.from_numpy(logits))
+            rt["kv_len"].fill_(3); rt["x_len"].fill_(1); rt["step"].fill_(2)
+            bad = 0
+            for s_ in range(300):
+                seed = 7919 * s_ + 31 * ci + 5
+                m._set_ctl(rt, 2, 0, False, 1.0, top_k, temp, seed)
+                m._flush(1)
+                tok = int(rt["pre_tokens"][0, 3].item())
+                assert ref_p[tok] > 0, (ci, s_, tok)
+                want, margin = orc.device_sample(logits, top_k, temp, seed, 0, 3, 2)
+                if tok != want:
+                    assert margin < 1e-4, (ci, s_, tok, want, margin)
+                    bad += 1
+            assert bad <= 2, (ci, bad)
+
+
 def test_device_and_host_sampling_paths_agree_on_rules(dev):
-    """default-parameter inference (top_k=15, repetition penalty) through the device sampler and through the
-    host (tok_override) path: both deterministic under a seeded generator, tokens in range, no suppressed
-    token in the first steps; infer_batched with slot refill runs on the device sampler."""
+    """default-parameter inference (top_k=15, repetition penalty) and a wide top_k = 400 through the device sampler (the only
+    sampling path): deterministic under a seeded generator, tokens in range, no suppressed token in the first steps;
+    infer_batched with slot refill runs on it too."""
     cfg = synth.gpt_config(n_layer=4)
     w = synth.gpt_weights(cfg, seed=3)
     m = _model(cfg, w, [(1, 96), (2, 96)], torch.float32, dev)
     x, y, bert, _ = synth.synth_request(9, 6, 10, 14, seed=3)
-    for device_sampling in (True, False):
-        m.device_sampling = device_sampling
+    assert not hasattr(m, "device_sampling")
+    for top_k in (15, 400):
         outs = []
         for _ in range(2):
-            gen = torch.Generator(device=dev); gen.manual_seed(4321)   # the host path draws its noise on the device
-            tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=15, generator=gen)[0, 0].cpu().numpy()
+            gen = torch.Generator(device=dev); gen.manual_seed(4321)
+            tok = m.infer(_T(x, dev)[None], _T(y, dev)[None], _T(bert, dev)[None], top_k=top_k, generator=gen)[0, 0].cpu().numpy()
             outs.append(tok)
             assert tok.min() >= 0 and tok.max() < 1025 and len(tok) > 0
             assert not set(tok[:8].tolist()) & {280, 486, 1024}
-        assert np.array_equal(outs[0], outs[1]), device_sampling
-    m.device_sampling = True
+        assert np.array_equal(outs[0], outs[1]), top_k
     gen = torch.Generator(device="cpu"); gen.manual_seed(1)
     pred, idx = m.infer_batched([_T(x, dev)] * 5, [_T(y, dev)] * 5, [_T(bert, dev)] * 5, top_k=15, generator=gen)
     assert sorted(idx.tolist()) == [0, 1, 2, 3, 4] and all(len(p) > 0 and int(p.max()) < 1025 for p in pred)

@@ -24,7 +24,7 @@ def _load(golden_dir, name):
 
 def test_sampling_matches_reference(golden_dir):
     g = _load(golden_dir, "sample.npz")
-    for i in range(4):
+    for i in range(6):
         top_k, top_p, temp, rep = g["c%d_kw" % i]
         prev = g["c%d_prev" % i] if ("c%d_prev" % i) in g.files else None
         kw = dict(top_k=int(top_k), top_p=float(top_p), temperature=float(temp), repetition_penalty=float(rep))
