@@ -153,12 +153,21 @@ __device__ __forceinline__ void lane_x(const float* xs, float (&xr)[8]) {
 // instruction; its other operand must be bf16 too, so an activation enters as the PAIR hi + lo (hi = the value truncated to bf16,
 // lo = bf16(value - hi), which is exact before its rounding): 16 significant bits, a relative error <= 2^-17 per term -- far inside
 // the half rounding of the partial rows -- for one instruction per MAC and no unpack.  fp32 handles keep the fp32 FMA chain.
+// Round 5: the lo half is gone (kPairAct = false).  An activation enters a dot as ONE bf16 value, rounded to nearest -- what the
+// reference's own bf16 path multiplies (its activations ARE bf16 tensors), half the dot instructions of every GEMV of the step
+// (the kernels are vector-issue bound: profiles/r04_pmc_decode_b1_wave_cycles.txt), no lo arrays in LDS.  The bf16-mode oracle rounds
+// the same operands (ORC_R_LIN in the decode step: the input rows of QKV / out-proj / W1 / W2 and the query of the score dots).
+#ifndef GSV_PAIR_ACT
+#define GSV_PAIR_ACT 0      // 1: the (hi, lo) pair of rounds 3-4, an A/B build only (the bf16-mode oracle describes 0)
+#endif
+constexpr bool kPairAct = GSV_PAIR_ACT != 0;
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2c(uint32_t w, uint32_t x, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, x), acc, false);
 }
 // value -> (hi, lo) bf16 bit patterns
 __device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) {
+    if constexpr (!kPairAct) { hi = f32_to_bf16(v); lo = 0; return; }
     const uint32_t b = __float_as_uint(v);
     hi = (uint16_t)(b >> 16);
     lo = f32_to_bf16(v - __uint_as_float(b & 0xffff0000u));
@@ -168,12 +177,17 @@ struct XPair { raw16 hi, lo; };
 __device__ __forceinline__ XPair xpair_load(const uint16_t* __restrict__ vh, const uint16_t* __restrict__ vl, int first) {
     XPair x;
     x.hi = *reinterpret_cast<const raw16*>(vh + first);
-    x.lo = *reinterpret_cast<const raw16*>(vl + first);
+    if constexpr (kPairAct) x.lo = *reinterpret_cast<const raw16*>(vl + first); else x.lo = raw16{};
     return x;
 }
 // 8 weights (one 16-byte load) . 8 activations
 __device__ __forceinline__ float dot8(const raw16& w, const XPair& x) {
     float a = 0.f, b = 0.f;
+    if constexpr (!kPairAct) {     // two chains of two: a dependent dot2c issues every other slot
+        a = dot2c(w[0], x.hi[0], a); b = dot2c(w[1], x.hi[1], b);
+        a = dot2c(w[2], x.hi[2], a); b = dot2c(w[3], x.hi[3], b);
+        return a + b;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a = dot2c(w[j], x.hi[j], a); b = dot2c(w[j], x.lo[j], b); }
     return a + b;
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         v = ln512<BF>(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     }
     if (owner) {
-        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
+        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; if constexpr (kPairAct) xl[tid] = vl; }
         else xs[tid] = v;
         if (h == 0) a.xout[(size_t)b * kD + tid] = v;
     }
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
                 if (row < 64) Kp[(size_t)nw * kDh + row - 32] = s; else Vp[(size_t)nw * kDh + row - 64] = s;
             }
             if constexpr (BF) {
-                if (row < 32) { uint16_t vh, vl; split_bf16(val, vh, vl); qh[row] = vh; ql[row] = vl; }
+                if (row < 32) { uint16_t vh, vl; split_bf16(val, vh, vl); qh[row] = vh; if constexpr (kPairAct) ql[row] = vl; }
                 else if (row < 64) kn[row - 32] = s;     // the new key is a bf16 value: it enters the score dot as it is
                 else qkv[row] = val;
             } else {
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
         for (int w = 0; w < AW / 2; ++w) num = fmaf(pacc[(hf * (AW / 2) + w) * 32 + d], sm_exp<BF>(pm[hf * (AW / 2) + w] - M), num);
         num = xor32_sum(num);
         if (lane < 32) {
-            if constexpr (BF) { uint16_t vh, vl; split_bf16(num * __builtin_amdgcn_rcpf(den), vh, vl); atth[d] = vh; attl[d] = vl; }
+            if constexpr (BF) { uint16_t vh, vl; split_bf16(num * __builtin_amdgcn_rcpf(den), vh, vl); atth[d] = vh; if constexpr (kPairAct) attl[d] = vl; }
             else att[d] = num / den;
         }
     }
@@ -820,7 +834,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
     const float v = ln512<BF>(owner ? ps.finish(stage) : 0.f, owner, ps.lng, ps.lnb, red);
     stamp(a.dbg, 15);
     if (owner) {
-        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; xl[tid] = vl; }
+        if constexpr (BF) { uint16_t vh, vl; split_bf16(v, vh, vl); xh[tid] = vh; if constexpr (kPairAct) xl[tid] = vl; }
         else xs[tid] = v;
         if (j == 0) a.x1out[(size_t)b * kD + tid] = v;
     }
@@ -841,7 +855,7 @@ __global__ __launch_bounds__(kNT) void t2s_ffn_kernel(FfnArgs<WT> a) {
         const float tot = wave_sumN<RW>(acc);
         if ((lane & (64 / RW - 1)) == 0) {
             const float hv = fmaxf(tot + b1r, 0.f);
-            if constexpr (BF) { uint16_t vh, vl; split_bf16(hv, vh, vl); hbh[wid * RW + oi] = vh; hbl[wid * RW + oi] = vl; }
+            if constexpr (BF) { uint16_t vh, vl; split_bf16(hv, vh, vl); hbh[wid * RW + oi] = vh; if constexpr (kPairAct) hbl[wid * RW + oi] = vl; }
             else hb[wid * RW + oi] = hv;
         }
     }

@@ -307,7 +307,7 @@ __device__ __forceinline__ void battn2_rest(const BatchAttnArgs<bf16_t>& a, int 
     if (tid < 32) {
         uint16_t vh, vl;
         split_bf16(rq, vh, vl);
-        qh[tid] = vh; ql[tid] = vl;
+        qh[tid] = vh; if constexpr (kPairAct) ql[tid] = vl;
         const bf16_t kq = f32_to_bf16(rk), vq = f32_to_bf16(rv);
         knb[tid] = kq; vn[tid] = bf16_to_f32(vq);
         const int nw = n64 < 0 ? a.T - 1 : n;     // parked slot (kv_len < 0): away from the rows a staged refill writes

