@@ -284,7 +284,7 @@ int t2s_load_layer_tensor(gsv_t2s* h, int l, const std::string& key, const float
         if (int rc = want((int64_t)kD * kF)) return rc;
         if (!L.w2_p) HIPCHK(gsv_dev_malloc(&L.w2_p, sizeof(WT) * kD * kF));
         hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p, kNJ, kFJ);
-        if (sizeof(WT) == 2) {
+        {
             if (!L.w2_p64) HIPCHK(gsv_dev_malloc(&L.w2_p64, sizeof(WT) * kD * kF));
             hipLaunchKernelGGL((pack_col_panel_kernel<WT>), dim3(1024), dim3(256), 0, st, data, (WT*)L.w2_p64, kNJFine, kF / kNJFine);
         }
@@ -360,7 +360,7 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     HIPCHK(gsv_dev_malloc(&h->xbuf, sizeof(float) * B * kD));
     HIPCHK(gsv_dev_malloc(&h->x1buf, sizeof(float) * B * kD));
     HIPCHK(gsv_dev_malloc(&h->ypart, sizeof(float) * B * kH * kD));
-    HIPCHK(gsv_dev_malloc(&h->zpart, sizeof(float) * B * kNJ * kD));
+    HIPCHK(gsv_dev_malloc(&h->zpart, sizeof(float) * B * kNJFine * kD));   // 64 fp32 slice partials per sequence at most
     HIPCHK(gsv_dev_malloc(&h->tokpart, sizeof(TokPart) * B * kNP));
     HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
     h->scratch_b = B;
@@ -417,6 +417,7 @@ void t2s_launch_attn(gsv_t2s* h, const gsv_t2s_state& s, int l, const float* xsr
     }
     if (l == 0 && fused_token) hipLaunchKernelGGL((t2s_attn_kernel<WT, 2>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (l == 0) hipLaunchKernelGGL((t2s_attn_kernel<WT, 0>), dim3(kH, B), dim3(kNT), lds, st, a);
+    else if (ffn_slices<WT>(B) == kNJFine && sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine, sizeof(WT) == 4>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (ffn_slices<WT>(B) == kNJFine) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJFine>), dim3(kH, B), dim3(kNT), lds, st, a);
     else if (sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_attn_kernel<WT, 1, kNJ, sizeof(WT) == 4>), dim3(kH, B), dim3(kNT), lds, st, a);
     else hipLaunchKernelGGL((t2s_attn_kernel<WT, 1>), dim3(kH, B), dim3(kNT), lds, st, a);
@@ -434,7 +435,8 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     else if (B > ffn_single_max_b) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
     else if (ffn_slices<WT>(B) == kNJFine) {
         f.w2p = (const WT*)L.w2_p64;
-        hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
+        if (sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine, sizeof(WT) == 4>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
+        else hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJFine>), dim3(kNJFine, B), dim3(kNT), 0, st, f);
     } else if (sizeof(WT) == 4 && l >= h->nt_from_layer) hipLaunchKernelGGL((t2s_ffn_kernel<WT, kNJ, sizeof(WT) == 4>), dim3(kNJ, B), dim3(kNT), 0, st, f);
     else hipLaunchKernelGGL((t2s_ffn_kernel<WT>), dim3(kNJ, B), dim3(kNT), 0, st, f);
 }
@@ -1251,7 +1253,7 @@ int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped) {
 }
 
 int gsv_t2s_batched_min(gsv_t2s* h) { return h && h->cfg.dtype == GSV_BF16 ? h->batched_min : 0x7fffffff; }
-int gsv_t2s_ffn_slices(gsv_t2s* h, int batch) { return h && h->cfg.dtype == GSV_BF16 ? ffn_slices<bf16_t>(batch) : kNJ; }
+int gsv_t2s_ffn_slices(gsv_t2s* h, int batch) { return !h ? kNJ : (h->cfg.dtype == GSV_F32 ? ffn_slices<float>(batch) : ffn_slices<bf16_t>(batch)); }
 
 size_t gsv_t2s_device_bytes(gsv_t2s* h) {
     if (!h) return 0;

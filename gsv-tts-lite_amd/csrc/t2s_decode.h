@@ -36,7 +36,11 @@ constexpr int kFJ = kF / kNJ;  // hidden units per slice
 // to half): gsv_t2s_ffn_slices reports it and the oracle sums the same slices.
 constexpr int kNJFine = 64;
 constexpr int kFineMaxB = 4;
-template <typename WT> inline int ffn_slices(int B) { return sizeof(WT) == 2 && B <= kFineMaxB ? kNJFine : kNJ; }
+// fp32 handles (round 5): the same switch.  Their blocks pull twice the bytes (an FFN block 288 KB at 32 slices, 144 KB at 64), and a
+// launch costs ~2.5 us + bytes / 60 GB/s; the fp32 sum order is not the reference's either way (it sums 2 048 products in one dot).
+// GSV_F32_FINE=0 keeps 32 slices (A/B).
+inline bool f32_fine() { static const bool on = !(getenv("GSV_F32_FINE") && atoi(getenv("GSV_F32_FINE")) == 0); return on; }
+template <typename WT> inline int ffn_slices(int B) { return (sizeof(WT) == 2 || f32_fine()) && B <= kFineMaxB ? kNJFine : kNJ; }
 constexpr int kNP = 16;        // logits slices per sequence
 constexpr float kEps = 1e-5f;
 
@@ -553,7 +557,10 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) row_load<WT, NT>(wp + (size_t)r * kD, wq[r]);
     Panel<WT, kDh> po;
-    po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
+    // fp32 handles: the out-proj panel (16 registers) is requested BEHIND the q / k / v rows' dots, when their 48 weight registers are
+    // free -- at kernel entry the two together spilled 11 registers (and a spilled load is a wait at the top of the kernel); the panel has
+    // the whole attention phase to land
+    if constexpr (BF) po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
     const int oi = sumN_index<8>();
     const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
     // ... and now kv_len (the opaque asm keeps its first use -- and with it the wait -- down here, behind the weight loads)
@@ -638,6 +645,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_kernel(AttnArgs<WT> a) {
     }
     __syncthreads();
     stamp(a.dbg, 3);
+    if constexpr (!BF) po.template issue<NT>(a.wo + (size_t)h * kD * kDh);
 
     // ---- single-pass attention over [0, n]: every thread owns the same rows of K and of V, so the
     //      scores never leave registers; each wave keeps a running (max, sum, P.V) and the 16 waves
