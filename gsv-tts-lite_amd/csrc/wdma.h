@@ -156,9 +156,15 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
         }
     };
     const bool epi = kh == 0;                     // the wave that owns the tile's epilogue
+    // Two epilogues.  KSP > 1 (256 channels: 88 fragments + the partial-tile exchange leave no registers) keeps the PATCH form:
     // residual -> the wave's patch: vector q of lane l is patch bytes [16 (64 q + l), +16) = (row, slot); piece = slot ^ ((row >> 2) & 3)
+#ifdef WDMA_FORCE_PATCH
+    constexpr bool DIRECT = false;                  // A/B build
+#else
+    constexpr bool DIRECT = KSP == 1;
+#endif
     const unsigned rl = lds_addr_of(ro);
-    auto issue_r = [&](int nb0) {
+    auto issue_r_patch = [&](int nb0) {
 #pragma unroll
         for (int q = 0; q < NVR; ++q) {
             const int idx = q * 64 + lane, row = idx >> 2, pc = (idx & 3) ^ ((row >> 2) & 3);
@@ -166,12 +172,34 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
             dma16(R + (size_t)n * ld + gs * 32 + pc * 8, rl + q * 1024);
         }
     };
+    // KSP = 1: the epilogue without the LDS transposition (round 5; the patch form above cost 2.2k cycles per tile, most of it the dependent
+    // chain ds_write -> ds_read -> store at one wave per SIMD).  A lane of the D fragment owns 16 consecutive channels of one row =
+    // two 16-byte pieces (p0, p1 for hf = 0; p2, p3 for hf = 1).  Stored as they are, an instruction would write 16 bytes and skip
+    // 16; ONE v_permlane32_swap per dword hands lane (j, 1) piece p1 and lane (j, 0) piece p2, so that the first store instruction
+    // writes bytes [0, 32) of the slice's 64-byte row and the second [32, 64): 32-byte runs, no LDS, and the residual comes in by
+    // plain loads in the same swapped order (the swap is its own inverse).  Arithmetic and rounding points are the patch form's.
+    u32x4 rF[WN], rS[WN];
+    auto issue_r_direct = [&](int nb0) {
+#pragma unroll
+        for (int k = 0; k < WN; ++k) {
+            const int n = min(nb0 + wrow + k * 32 + j, n_rows - 1);
+            const bf16_t* rp = R + (size_t)n * ld + gs * 32 + hf * 8;
+            rF[k] = *reinterpret_cast<const u32x4*>(rp);
+            rS[k] = *reinterpret_cast<const u32x4*>(rp + 16);
+        }
+    };
+    float bb[16];                                   // the lane's 16 biases (registers: the staging vectors of wconv.h are gone)
+    auto issue_r = [&](int nb0) { if constexpr (DIRECT) issue_r_direct(nb0); else issue_r_patch(nb0); };
 
     issue_x(blk, xbuf0);
     load_weights();
     if (tid < MS * 32) bl[tid] = bias_raw;
     wait_vm<0>();
     lds_barrier();
+    if constexpr (DIRECT) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bb[q] = bl[ms * 32 + 16 * hf + q];
+    }
     int cur = 0, nst = 0;
     auto stamp = [&]() { if (dbg && blk == 0 && tid == 0 && nst < 60) dbg[nst] = (long long)__builtin_readcyclecounter(); ++nst; };
     const unsigned c0 = (unsigned)(kh * KSW * 32 + hf * 16);
@@ -235,6 +263,7 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
         }
 
         stamp();
+        if constexpr (!DIRECT) {
         if (epi) {
             // the residual rows have landed when only the next tile's row DMAs (issued behind them) are outstanding
             if (R) { if (has_next) wait_vm<NPASS>(); else wait_vm<0>(); }
@@ -290,6 +319,54 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
                 }
             }
         }
+
+        } else {
+        if (epi) {
+            unsigned char* snk = reinterpret_cast<unsigned char*>(a.sink) + tid * 16;
+#pragma unroll
+            for (int k = 0; k < WN; ++k) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = acc[k][q] + bb[q];
+                if (a.out_slope != 1.0f) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = lrelu(v[q], a.out_slope);
+                }
+                if (R) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {    // back from the stored order: ra = this lane's channels 0-7, rb = 8-15
+                        const auto t = __builtin_amdgcn_permlane32_swap(rF[k][e], rS[k][e], false, false);
+                        const unsigned ra = t[0], rb = t[1];
+                        v[2 * e] += __uint_as_float(ra << 16);
+                        v[2 * e + 1] += __uint_as_float(ra & 0xffff0000u);
+                        v[8 + 2 * e] += __uint_as_float(rb << 16);
+                        v[8 + 2 * e + 1] += __uint_as_float(rb & 0xffff0000u);
+                    }
+                }
+                u32x4 oF, oS;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto t = __builtin_amdgcn_permlane32_swap(pack_bf16x2(v[2 * e], v[2 * e + 1]), pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]), false, false);
+                    oF[e] = t[0]; oS[e] = t[1];
+                }
+                const int n = nb0 + wrow + k * 32 + j;
+                const bool ok = n < n_rows;
+                const size_t off = ((size_t)n * ld + gs * 32 + hf * 8) * 2;
+                *reinterpret_cast<u32x4*>(ok ? reinterpret_cast<unsigned char*>(Y) + off : snk) = oF;
+                *reinterpret_cast<u32x4*>(ok ? reinterpret_cast<unsigned char*>(Y) + off + 32 : snk) = oS;
+                if (A) {
+                    u32x4 aF, aS;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        aF[e] = pack_bf16x2(lrelu(__uint_as_float(oF[e] << 16), a.act_slope), lrelu(__uint_as_float(oF[e] & 0xffff0000u), a.act_slope));
+                        aS[e] = pack_bf16x2(lrelu(__uint_as_float(oS[e] << 16), a.act_slope), lrelu(__uint_as_float(oS[e] & 0xffff0000u), a.act_slope));
+                    }
+                    *reinterpret_cast<u32x4*>(ok ? reinterpret_cast<unsigned char*>(A) + off : snk) = aF;
+                    *reinterpret_cast<u32x4*>(ok ? reinterpret_cast<unsigned char*>(A) + off + 32 : snk) = aS;
+                }
+            }
+        }
+        }   // DIRECT
 
         stamp();
         // next tile's rows: this wave's DMAs are older than its stores of this tile
