@@ -228,6 +228,18 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def _step_traffic(slots, dtype_name):
+    """fabric bytes of ONE batched decode step (32 sequences, bf16) from the committed PMC passes, or None when the kernels changed since
+    (profiles/traffic.json "batched_step_b32": tools/pmc_traffic.py, a pass of tools/step_time.py 32 bf16)"""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if slots != 32 or dtype_name != "bf16" or tr.get("_meta", {}).get("csrc_sha16") != csrc_sha16():
+            return None
+        return tr.get("batched_step_b32")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def _profile_traffic(out, a):
     """HBM traffic per launch from the committed PMC passes (profiles/traffic.json): counters cannot be read in-process.  The file
     is stamped with the commit and the csrc hash it was measured at; when the kernels changed since, traffic stays null."""
@@ -899,7 +911,7 @@ class CBWorkload:
             by = acc["steps"] * wbytes + acc["kv_rows"] * KV_BYTES_PER_POS * self.sbytes
             gbs = by / acc["t_ar"] / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": None,
+                               "traffic": _step_traffic(self.slots, self.dtype_name),
                                "kernel": ("batched decode step (5 launches per layer: GEMMs on 16 x 16 x 32 MFMA tiles + attention per (head, sequence), csrc/t2s_small.h)" if self.slots >= t2s.batched_min else
                                           "decode step, 2 launches per layer with 2 / 4 sequences per block (csrc/t2s_decode_multi.h)" if self.slots > 16
                                           else "decode step, 2 launches per layer (csrc/t2s_decode.h)"),

@@ -5,7 +5,9 @@ Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZ
 FETCH_SIZE tallies the 128-B requests of a wide coalesced stream at 64 B, i.e. reports exactly 1/2 of the
 bytes fetched -> doubled here; WRITE_SIZE is taken as is (uncalibrated).  Infinity-Cache hits are
 counted, so for weight sets that fit the 256 MiB cache this is fabric traffic, not DRAM traffic.
-usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<step_fetch.csv> <step_write.csv>]
+The optional second pair is a PMC pass of `tools/step_time.py 32 bf16` (the batched decode step of the cb32 record): every kernel's
+traffic summed and divided by the steps run (one t2s_token_kernel launch per step, prompt-pass kernels excluded) -> "batched_step_b32"."""
 import csv, json, re, sys
 from collections import defaultdict
 
@@ -36,7 +38,8 @@ flat = {k: v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in
 # whole flow + Generator pass: every launch of the vocoder-only kernel classes, divided by the number of passes
 # (one conv_post / one cl->cf per pass)
 def _is_voc(full):
-    return ("wconv_kernel" in full or "wups_kernel" in full or "flowfuse_kernel" in full or "avg3_kernel" in full or "conv_post_kernel" in full
+    return ("wconv_kernel" in full or "wdma_kernel" in full or "cgemm_kernel" in full or "rbfuse_kernel" in full or "wups_kernel" in full
+            or "flowfuse_kernel" in full or "flowstage_kernel" in full or "flowmerge_" in full or "avg3_kernel" in full or "conv_post_kernel" in full
             or "cf_to_cl_kernel" in full or ("tapgemm_kernel<unsigned short, unsigned short" in full)
             or "rowgemm_kernel<unsigned short, float, 16>" in full)   # cond GEMV (gin 1024); <.., 8> is also the prefill's W2
 passes = sum(len(v) for k, v in fetch.items() if "conv_post_kernel" in k)
@@ -44,6 +47,18 @@ if passes:
     tot = sum(2.0 * 1024.0 * sum(v) for k, v in fetch.items() if _is_voc(k)) + sum(1024.0 * sum(v) for k, v in write.items() if _is_voc(k))
     flat["vocoder_pass"] = tot / passes
     flat["vocoder_passes_counted"] = passes
+step_meta = None
+if len(sys.argv) > 5:
+    sf, sw = per_kernel(sys.argv[4]), per_kernel(sys.argv[5])
+    # the decode steps only: the chain's kernels, the token / logits / final-LN kernels; the prompt pass (bgemm / prefill / embed) is set-up
+    def _is_step(full):
+        return any(t in full for t in ("sgemm_", "t2s_batch_attn", "t2s_token_kernel", "t2s_logits_kernel", "ln_rows_kernel"))
+    steps = sum(len(v) for k, v in sf.items() if "t2s_token_kernel" in k)
+    if steps:
+        tot = sum(2.0 * 1024.0 * sum(v) for k, v in sf.items() if _is_step(k)) + sum(1024.0 * sum(v) for k, v in sw.items() if _is_step(k))
+        flat["batched_step_b32"] = tot / steps
+        step_meta = {"steps_counted": steps, "kernels": sorted({short(k) for k in sf if _is_step(k)}),
+                     "command": "GSV_PROMPT_TOK=250 tools/step_time.py 32 bf16 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (kv ~ 350-450)"}
 import hashlib, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
@@ -54,6 +69,8 @@ for f in sorted(os.listdir(d)):
 stamp = os.path.join(root, ".commit_stamp")      # written by tools/gpu.sh before the snapshot leaves (the GPU box has no .git)
 meta = {"commit": open(stamp).read().strip() if os.path.exists(stamp) else None, "csrc_sha16": h.hexdigest()[:16],
         "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-cb32 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE"}
+if step_meta:
+    meta["batched_step_b32"] = step_meta
 json.dump({"_meta": meta, "_detail": out, **flat}, open(sys.argv[3], "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k]["launches"])[:12]:
     print("%-28s launches %6d  fetch %10.0f B  write %9.0f B" % (k, out[k]["launches"], out[k]["fetch_bytes_per_launch"], out[k]["write_bytes_per_launch"]))

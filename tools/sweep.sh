@@ -14,8 +14,13 @@ f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$c; run timeout 900 rocprofv3 --pmc $c --output-format csv -d /tmp/pm_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-cb32 > /dev/null 2> $O/pmc_$c.log
 done
+# ... and the batched decode step of the cb32 record (32 sequences, kv ~ 350-450)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/ps_$c; GSV_PROMPT_TOK=250 run timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/ps_$c -- python $R/tools/step_time.py 32 bf16 > /dev/null 2> $O/pmc_step_$c.log
+done
 ff=$(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-[ -n "$ff" ] && [ -n "$fw" ] && python $R/tools/pmc_traffic.py "$ff" "$fw" $O/traffic.json > $O/traffic_table.txt 2>&1
+sf=$(find /tmp/ps_FETCH_SIZE -name "*counter_collection.csv" | head -1); sw=$(find /tmp/ps_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+[ -n "$ff" ] && [ -n "$fw" ] && python $R/tools/pmc_traffic.py "$ff" "$fw" $O/traffic.json $sf $sw > $O/traffic_table.txt 2>&1
 # 3. continuous batching lines
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus > $O/cb_configs2.json 2> $O/cb_configs2.log
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --sync-refill --no-cpu-baseline > $O/cb_configs2_sync_refill.json 2> /dev/null
@@ -31,7 +36,8 @@ f=$(find /tmp/p2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "
 # 4. raw step times
 ( for b in 1 2 4 8 16 17 24 32 33 40 64 128 256; do timeout 300 python $R/tools/step_time.py $b bf16 | grep step; done
   for b in 64 256; do timeout 300 python $R/tools/step_time.py $b fp8 | grep step; done
-  timeout 300 python $R/tools/step_time.py 1 fp32 | grep step ) > $O/step_time.txt 2>&1
+  for b in 1 2 4; do timeout 300 python $R/tools/step_time.py $b fp32 | grep step; done
+  GSV_PROMPT_TOK=250 timeout 300 python $R/tools/step_time.py 32 bf16 | grep step | sed 's/$/   <- kv 350-450 (GSV_PROMPT_TOK=250): the kv the cb32 slot loop runs at/' ) > $O/step_time.txt 2>&1
 # 5. vocoder: pass times and per-kernel timelines
 timeout 600 python $R/tools/voc_time.py 2>&1 | grep "T=" > $O/voc_time.txt
 for v in v2Pro v2ProPlus; do
