@@ -22,6 +22,33 @@ def short(name):
     m = re.search(r"gsv::(\w+)", name)
     return m.group(1) if m else name[:40]
 
+def step_entry(fetch_csv, write_csv):
+    """(bytes per batched decode step, meta) from a PMC pass of tools/step_time.py 32 bf16"""
+    sf, sw = per_kernel(fetch_csv), per_kernel(write_csv)
+    # the decode steps only: the chain's kernels, the token / logits / final-LN kernels; the prompt pass (bgemm / prefill / embed) is set-up
+    def _is_step(full):
+        return any(t in full for t in ("sgemm_", "t2s_batch_attn", "t2s_token_kernel", "t2s_logits_kernel", "ln_rows_kernel"))
+    steps = sum(len(v) for k, v in sf.items() if "t2s_token_kernel" in k)
+    if not steps:
+        return None, None
+    tot = sum(2.0 * 1024.0 * sum(v) for k, v in sf.items() if _is_step(k)) + sum(1024.0 * sum(v) for k, v in sw.items() if _is_step(k))
+    per = {short(k): (2.0 * 1024.0 * sum(v) / len(v) + 1024.0 * sum(sw.get(k, [0.0])) / max(1, len(sw.get(k, [0.0])))) for k, v in sf.items() if _is_step(k)}
+    return tot / steps, {"steps_counted": steps, "bytes_per_launch": per,
+                         "command": "GSV_NO_GRAPH=1 GSV_STEPS=20 GSV_PROMPT_TOK=250 tools/step_time.py 32 bf16 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE "
+                                    "(kv 350-375; eager launches: the FETCH_SIZE pass of the graph-replayed chain hangs under the profiler)"}
+
+if sys.argv[1] == "--add-step":      # tools/pmc_traffic.py --add-step <traffic.json> <step_fetch.csv> <step_write.csv>
+    tr = json.load(open(sys.argv[2]))
+    val, m = step_entry(sys.argv[3], sys.argv[4])
+    if val is None:
+        sys.exit("no decode step found in the counter files")
+    tr["batched_step_b32"] = val
+    tr["_meta"]["batched_step_b32"] = m
+    json.dump(tr, open(sys.argv[2], "w"), indent=1)
+    print("batched decode step at 32 sequences: %.1f MB per step over %d steps" % (val / 1e6, m["steps_counted"]))
+    for k, v in sorted(m["bytes_per_launch"].items(), key=lambda kv: -kv[1]):
+        print("  %-28s %10.0f B per launch" % (k, v))
+    sys.exit(0)
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 out = {}
 for k, v in fetch.items():
@@ -49,16 +76,9 @@ if passes:
     flat["vocoder_passes_counted"] = passes
 step_meta = None
 if len(sys.argv) > 5:
-    sf, sw = per_kernel(sys.argv[4]), per_kernel(sys.argv[5])
-    # the decode steps only: the chain's kernels, the token / logits / final-LN kernels; the prompt pass (bgemm / prefill / embed) is set-up
-    def _is_step(full):
-        return any(t in full for t in ("sgemm_", "t2s_batch_attn", "t2s_token_kernel", "t2s_logits_kernel", "ln_rows_kernel"))
-    steps = sum(len(v) for k, v in sf.items() if "t2s_token_kernel" in k)
-    if steps:
-        tot = sum(2.0 * 1024.0 * sum(v) for k, v in sf.items() if _is_step(k)) + sum(1024.0 * sum(v) for k, v in sw.items() if _is_step(k))
-        flat["batched_step_b32"] = tot / steps
-        step_meta = {"steps_counted": steps, "kernels": sorted({short(k) for k in sf if _is_step(k)}),
-                     "command": "GSV_PROMPT_TOK=250 tools/step_time.py 32 bf16 under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (kv ~ 350-450)"}
+    val, step_meta = step_entry(sys.argv[4], sys.argv[5])
+    if val is not None:
+        flat["batched_step_b32"] = val
 import hashlib, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()

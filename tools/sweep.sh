@@ -16,7 +16,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # ... and the batched decode step of the cb32 record (32 sequences, kv ~ 350-450)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/ps_$c; GSV_PROMPT_TOK=250 run timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/ps_$c -- python $R/tools/step_time.py 32 bf16 > /dev/null 2> $O/pmc_step_$c.log
+  # eager launches, 20 steps: the FETCH_SIZE pass of the graph-replayed chain hangs under the profiler (r04, r05)
+  rm -rf /tmp/ps_$c; GSV_NO_GRAPH=1 GSV_STEPS=20 GSV_PROMPT_TOK=250 run timeout 200 rocprofv3 --pmc $c --output-format csv -d /tmp/ps_$c -- python $R/tools/step_time.py 32 bf16 > /dev/null 2> $O/pmc_step_$c.log
 done
 ff=$(find /tmp/pm_FETCH_SIZE -name "*counter_collection.csv" | head -1); fw=$(find /tmp/pm_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 sf=$(find /tmp/ps_FETCH_SIZE -name "*counter_collection.csv" | head -1); sw=$(find /tmp/ps_WRITE_SIZE -name "*counter_collection.csv" | head -1)
