@@ -185,8 +185,8 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
 /* Batch size from which gsv_t2s_decode runs the batched chain (INT_MAX on fp32 handles: never).  Tests mirror the
  * choice in the oracle, whose reduced-precision modes round the operands each path rounds. */
 int gsv_t2s_batched_min(gsv_t2s* h);
-/* FFN slices per sequence of the two-launches-per-layer step at this batch size: 32 slices of 64 hidden units, or -- bf16
- * handles at <= 4 sequences -- 64 slices of 32.  Each slice's partial 512-vector crosses the kernel boundary rounded to half on
+/* FFN slices per sequence of the two-launches-per-layer step at this batch size: 32 slices of 64 hidden units, or -- at
+ * <= 4 sequences -- 64 slices of 32 (fp32 handles too: their partials stay fp32).  Each slice's partial 512-vector crosses the kernel boundary rounded to half on
  * bf16 handles, so the count is part of the arithmetic; the bf16-mode oracle sums the same slices (oracle.py). */
 int gsv_t2s_ffn_slices(gsv_t2s* h, int batch);
 /* Device memory the handle owns, in bytes (its arena's blocks: repacked weights, fragments, scratch, the staging of every
