@@ -249,3 +249,40 @@ def test_per_frame_ge_runs_on_its_distinct_columns(dev):
     z = torch.from_numpy(synth.hashed_uniform("seg.z%d" % T, (1, 192, T), 11)).to(dev)
     m = torch.ones(1, 1, T, device=dev)
     assert torch.equal(v.flow_dec(z, m, cols([(0, T)])), v.flow_dec(z, m, g[0]))
+
+
+def test_wdma_pass_equals_the_wconv_pass_bit_for_bit(dev, tmp_path):
+    """csrc/wdma.h (rows and residual by LDS-DMA, the activated copies written by their producers, the swizzled LDS map, the
+    register epilogue) against the path it replaced (wconv.h: rows through registers, leaky-ReLU at staging; GSV_NO_WDMA=1):
+    the same arithmetic at the same rounding points, so flow + Generator must return the SAME samples -- at a length that is not
+    a multiple of any tile (edge tiles, zero page, sink), at the bench length, and for a ten-utterance batch that hands the
+    256-channel stage to cgemm.  The switch is read once per process: two child processes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from gsv_tts_lite_amd import synth\n"
+        "from gsv_tts_lite_amd.sovits import _VocoderNative\n"
+        "dev = torch.device('cuda:0'); hps = synth.sovits_hps('v2Pro')\n"
+        "w = synth.sovits_weights(hps, seed=21, hot_path_only=True)\n"
+        "v = _VocoderNative(hps['model'], {k: torch.from_numpy(a) for k, a in w.items()}, torch.bfloat16, dev)\n"
+        "ge = torch.from_numpy(synth.synth_ge(2, 1024, 21)).to(dev)\n"
+        "out = {}\n"
+        "for T in (137, 500, 3301):\n"
+        "    z = torch.from_numpy(synth.hashed_uniform('wdma.z%%d' %% T, (1, 192, T), 21)).to(dev)\n"
+        "    g = ge if T < 1000 else ge.expand(-1, -1, T).contiguous()\n"
+        "    out['t%%d' %% T] = v.flow_dec(z, torch.ones(1, 1, T, device=dev), g).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % (root, os.path.join(root, "gsv-tts-lite_amd")))
+    outs = []
+    for tag, extra in (("wdma", {}), ("wconv", {"GSV_NO_WDMA": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ); env.pop("GSV_NO_WDMA", None); env.update(extra)
+        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        a, b = outs[0][k], outs[1][k]
+        assert np.isfinite(a).all() and a.shape == b.shape and np.abs(a).max() > 1e-3, k
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
