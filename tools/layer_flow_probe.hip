@@ -15,9 +15,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NT = 1024;
 
 // rows: partial rows to read (row bytes = 64 lanes x 16 B = 1 KB per wave-load; `wpr` wave-loads per row); NW: weight wave-loads per wave
-template <int PR, int NW, int ORDER, int ST = 0>   // ST: flavour of the partial-row store (0 plain, 1 nt, 2 sc1, 3 sc0 sc1)
+// RED = 1 (F launch of the last-arriver form, NJ 64 half rows): the block writes its row through (sc0 sc1), drains, takes a ticket; the LAST
+// arriver reads all 64 rows back (sc0 sc1 loads, 4 per wave in flight) and writes ONE reduced row (2 KB) to `red`; the A launch of that
+// form reads 2 KB of `red` instead of 64 KB of partial rows.
+template <int PR, int NW, int ORDER, int ST = 0, int RED = 0>   // ST: flavour of the partial-row store (0 plain, 1 nt, 2 sc1, 3 sc0 sc1)
 __global__ __launch_bounds__(NT) void flow(const u32x4* __restrict__ part, int wpr, const u32x4* __restrict__ W, size_t w_block_u4,
-                                           u32x4* __restrict__ out, int out_wpr, long long* __restrict__ cyc) {
+                                           u32x4* __restrict__ out, int out_wpr, long long* __restrict__ cyc, unsigned* ticket = nullptr,
+                                           u32x4* red = nullptr, int nj = 64) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long long t0 = clock64();
     u32x4 p[PR], w[NW];
@@ -63,6 +67,31 @@ __global__ __launch_bounds__(NT) void flow(const u32x4* __restrict__ part, int w
         else if (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(s) : "memory");
         else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(s) : "memory");
     }
+    if (RED == 1) {
+        __shared__ int last;
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = ((old + 1u) % (unsigned)nj) == 0u;
+        }
+        __syncthreads();
+        if (last) {
+            const u32x4* r0 = out + (size_t)(wid * 4) * 64 + lane;      // 64 rows of 1 KB over 16 waves: 4 per wave, all in flight
+            u32x4 v0, v1, v2, v3;
+            asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(r0), "v"(r0 + 64), "v"(r0 + 128), "v"(r0 + 192) : "memory");
+            __shared__ u32x4 acc[16][64];
+            acc[wid][lane] = v0 + v1 + v2 + v3;
+            __syncthreads();
+            if (wid < 2) {
+                u32x4 t = acc[wid][lane];
+                for (int i = 2 + wid; i < 16; i += 2) t += acc[i][lane];
+                red[wid * 64 + lane] = t;
+            }
+        }
+    }
     if (cyc && b == 0 && (tid == 0 || tid == 960)) {
         long long* c = cyc + (tid ? 4 : 0);
         c[0] = t1 - t0; c[1] = t2 - t0; c[2] = t3 - t0; c[3] = clock64() - t0;
@@ -74,6 +103,7 @@ int main(int argc, char** argv) {
     const int NJ = argc > 2 ? atoi(argv[2]) : 64;
     const int half = argc > 3 ? atoi(argv[3]) : 1;
     const int stf = argc > 4 ? atoi(argv[4]) : 0;
+    const int reduce = argc > 5 ? atoi(argv[5]) : 0;    // 1: the last-arriver form (NJ 64, half rows)
     const int n_layers = 24;
     const int wpr = half ? 1 : 2;                    // wave-loads (KB) per partial row
     const size_t a_w_u4 = 176 * 64, f_w_u4 = (size_t)(4096 / NJ) * 64;   // per-block weight bytes / 16: 176 KB, 64 or 128 KB
@@ -83,6 +113,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&Y, 16 * wpr * 1024)); CK(hipMemset(Y, 0, 16 * wpr * 1024));
     CK(hipMalloc(&Z, NJ * wpr * 1024)); CK(hipMemset(Z, 0, NJ * wpr * 1024));
     long long* cyc; CK(hipMalloc(&cyc, 16 * 8)); CK(hipMemset(cyc, 0, 16 * 8));
+    unsigned* tickets; CK(hipMalloc(&tickets, n_layers * 256)); CK(hipMemset(tickets, 0, n_layers * 256));
+    u32x4* RED; CK(hipMalloc(&RED, 2048)); CK(hipMemset(RED, 0, 2048));
+    if (reduce && !(NJ == 64 && half)) { printf("the last-arriver form is written for NJ 64, half rows\n"); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     // A: NJ*wpr partial wave-loads over 16 waves; 176 weight wave-loads over 16 waves = 11.  F: 16*wpr over 16 waves; 4096/NJ over 16 waves
@@ -94,6 +127,7 @@ int main(int argc, char** argv) {
                     else if (stf == 3) hipLaunchKernelGGL((flow<PR, 11, 0, 3>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); \
                     else hipLaunchKernelGGL((flow<PR, 11, 0, 4>), dim3(16), dim3(NT), 0, st, Z, wpr, w, a_w_u4, Y, wpr, c); } while (0)
         const int pr = NJ * wpr / 16;
+        if (reduce) { hipLaunchKernelGGL((flow<1, 11, 0, 0>), dim3(16), dim3(NT), 0, st, RED, wpr, w, a_w_u4, Y, wpr, c); return; }   // every wave reads 1 KB of the 2 KB row
         if (pr == 2) LA(2); else if (pr == 4) LA(4); else LA(8);
     };
     auto launchF = [&](int l, long long* c) {
@@ -103,6 +137,7 @@ int main(int argc, char** argv) {
                         else if (stf == 2) hipLaunchKernelGGL((flow<PR, NW, 0, 2>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
                         else if (stf == 3) hipLaunchKernelGGL((flow<PR, NW, 0, 3>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); \
                         else hipLaunchKernelGGL((flow<PR, NW, 0, 4>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c); } while (0)
+        if (reduce) { hipLaunchKernelGGL((flow<1, 4, 0, 3, 1>), dim3(NJ), dim3(NT), 0, st, Y, wpr, w, f_w_u4, Z, wpr, c, tickets + l * 64, RED, NJ); return; }
         if (NJ == 64) { if (wpr == 1) LF(1, 4); else LF(2, 4); }
         else { if (wpr == 1) LF(1, 8); else LF(2, 8); }
     };
