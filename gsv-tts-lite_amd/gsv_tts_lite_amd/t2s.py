@@ -259,7 +259,7 @@ class Text2SemanticDecoder:
             xi = xs[0].to(device=dev, dtype=torch.int64).reshape(1, lx).contiguous()
             yi = ys[0].to(device=dev, dtype=torch.int64).reshape(1, ly).contiguous()
             bt = berts[0].to(device=dev, dtype=torch.float32).reshape(1, lx, 1024).contiguous()
-        else:
+        elif n < 4:
             xi = torch.zeros(n, lx, dtype=torch.int64, device=dev)
             yi = torch.zeros(n, ly, dtype=torch.int64, device=dev)
             bt = torch.zeros(n, lx, 1024, dtype=torch.float32, device=dev)
@@ -267,6 +267,19 @@ class Text2SemanticDecoder:
                 xi[i, : xln[i]] = xs[i].to(dev)
                 yi[i, : yln[i]] = ys[i].to(dev)
                 bt[i, : xln[i]] = berts[i].to(device=dev, dtype=torch.float32)
+        else:
+            # from four requests on: the padded batches by ONE concatenation + ONE indexed store per tensor (the row positions are built on the host and cross in
+            # one copy): a slice copy per request and tensor was 3 n small launches -- 0.7 ms of host time in front of a 32-prompt pass
+            pos_x = np.concatenate([i * lx + np.arange(k) for i, k in enumerate(xln)])
+            pos_y = np.concatenate([i * ly + np.arange(k) for i, k in enumerate(yln)])
+            pos = torch.from_numpy(np.concatenate([pos_x, pos_y])).to(dev)
+            px, py = pos[: len(pos_x)], pos[len(pos_x):]
+            xi = torch.zeros(n * lx, dtype=torch.int64, device=dev)
+            yi = torch.zeros(n * ly, dtype=torch.int64, device=dev)
+            bt = torch.zeros(n * lx, 1024, dtype=torch.float32, device=dev)
+            xi[px] = torch.cat([t.to(dev).reshape(-1) for t in xs]).to(torch.int64)
+            yi[py] = torch.cat([t.to(dev).reshape(-1) for t in ys]).to(torch.int64)
+            bt[px] = torch.cat([t.to(device=dev, dtype=torch.float32).reshape(-1, 1024) for t in berts])
         lens_d = lens.to(dev)           # one host-to-device copy for both length vectors
         xl, yl = lens_d[0], lens_d[1]
         xy = torch.empty(n, lmax, self.model_dim, dtype=torch.float32, device=dev)
