@@ -431,7 +431,11 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     f.w1 = (const WT*)L.w1; f.b1 = L.b1; f.w2p = (const WT*)L.w2_p; f.zpart = (typename Geo<WT>::PT*)h->zpart; f.dbg = (l == h->cfg.n_layer - 1) ? h->dbg : nullptr;
     const int B = s.batch;
     static const int ffn_single_max_b = getenv("GSV_FFN_SINGLE_MAX_B") ? atoi(getenv("GSV_FFN_SINGLE_MAX_B")) : 8;   // tuning aid
-    if (B > 16 && sizeof(WT) == 2) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B);
+    bool four = false;
+    if constexpr (sizeof(WT) == 2) {     // four sequences per block: bf16 handles only (an fp32 instantiation would spill 53 registers and is never launched)
+        if (B > 16) { hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B); four = true; }
+    }
+    if (four) {}
     else if (B > ffn_single_max_b) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
     else if (ffn_slices<WT>(B) == kNJFine) {
         f.w2p = (const WT*)L.w2_p64;
@@ -449,7 +453,8 @@ int t2s_multi_lds_attr() {
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<2>())));
-    HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<4>())));
+    if constexpr (sizeof(WT) == 2)      // four sequences per block: bf16 handles only (t2s_launch_ffn); no fp32 instantiation exists
+        HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<4>())));
     return GSV_OK;
 }
 

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
 #pragma unroll
     for (int it = 0; it < KCH; ++it) vreg[it] = ldg16(Vp[0] + (size_t)min(rsub + it * RPI, n[0]) * kDh + part * EPL);
     Panel<WT, kDh> po;
-    po.issue(a.wo + (size_t)h * kD * kDh);
+    // fp32 handles: the out-proj panel is requested behind the q / k / v dots, when their weight registers are free (t2s_decode.h: at entry
+    // the two together spill)
+    if constexpr (sizeof(WT) == 2) po.issue(a.wo + (size_t)h * kD * kDh);
     const int oi = sumN_index<8>();
     const float bq = a.bqkv[h * 96 + wid * RW + min(oi, RW - 1)];
     if constexpr (MODE == 0) asm volatile("" : "+v"(xd[0]) : : "memory");
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(kNT) void t2s_attn_multi_kernel(AttnArgs<WT> a, int
         }
     }
     __syncthreads();
+    if constexpr (sizeof(WT) == 4) po.issue(a.wo + (size_t)h * kD * kDh);
 
     // ---- single-pass attention per sequence; per-wave (max, sum, P.V) parked per sequence, merged once at the end
     const float scale = 0.17677669529663687f;
