@@ -9,6 +9,7 @@
 #include <algorithm>
 #include "wpair_experiment.h"
 #include "../gsv-tts-lite_amd/csrc/wdma.h"
+#include "wpipe_experiment.h"
 
 using namespace gsv;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -151,6 +152,58 @@ void run_wdma(const char* name, WConvArgs w, bf16_t** Xact, int N, int reps, bf1
     fflush(stdout);
 }
 
+// wpipe.h: eight waves, the contraction of a tile split between the two waves of a SIMD (not bit-identical to the one-wave walk: counts differences)
+template <int C, int MS, int BN>
+void run_wpipe(const char* name, WConvArgs w, bf16_t** Xact, int N, int reps, bf16_t** yref, bf16_t** Yd, bf16_t** Ad, size_t ny, int total_blocks, double ovh, const void* zeros, void* sink) {
+    auto kern = wpipe_kernel<C, MS, BN>;
+    const size_t lds = wpipe_lds_bytes<C, MS, BN>();
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int ks[3] = {w.k0, w.k1, w.k2};
+    double tot = 0; for (int b = 0; b < 3; ++b) tot += ks[b] + ovh;
+    int nb[3]; int used = 0;
+    for (int b = 0; b < 3; ++b) { nb[b] = std::max(1, (int)(total_blocks * (ks[b] + ovh) / tot)); used += nb[b]; }
+    nb[0] += total_blocks - used;
+    WDmaArgs a; memset(&a, 0, sizeof(a));
+    a.X0 = Xact[0]; a.X1 = Xact[1]; a.X2 = Xact[2]; a.W0 = w.W0; a.W1 = w.W1; a.W2 = w.W2; a.b0 = w.b0; a.b1 = w.b1; a.b2 = w.b2;
+    a.R0 = w.R0; a.R1 = w.R1; a.R2 = w.R2; a.Y0 = Yd[0]; a.Y1 = Yd[1]; a.Y2 = Yd[2]; a.A0 = Ad[0]; a.A1 = Ad[1]; a.A2 = Ad[2];
+    a.k0 = w.k0; a.k1 = w.k1; a.k2 = w.k2; a.d0 = w.d0; a.d1 = w.d1; a.d2 = w.d2; a.nb0 = nb[0]; a.nb1 = nb[1]; a.nb2 = nb[2];
+    a.ld = w.ld; a.n_rows = N; a.out_slope = w.out_slope; a.act_slope = 0.1f; a.zeros = zeros; a.sink = sink;
+    dim3 grid(total_blocks);
+    long long* dbg; CK(hipMalloc(&dbg, 80 * 8)); CK(hipMemset(dbg, 0, 80 * 8)); a.dbg = dbg;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, grid, dim3(512), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(512), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const float us = ms * 1e3f / reps;
+    double maxd = 0, maxa = 0; size_t ndiff = 0; int nbad = 0;
+    std::vector<bf16_t> y(ny), ya(ny);
+    for (int b = 0; b < 3; ++b) {
+        CK(hipMemcpy(y.data(), Yd[b], ny * 2, hipMemcpyDeviceToHost));
+        if (Ad[b]) CK(hipMemcpy(ya.data(), Ad[b], ny * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ny; ++i) {
+            const float fa = bf2f(y[i]), fb = bf2f(yref[b][i]);
+            if (fa != fb) ++ndiff;
+            if (fabsf(fa - fb) > 0.02f * (1.f + fabsf(fb)) && nbad < 6) { printf("  bad br %d n %zu m %zu got %g want %g\n", b, i / C, i % C, fa, fb); ++nbad; }
+            maxd = std::max(maxd, (double)fabsf(fa - fb));
+            if (Ad[b]) maxa = std::max(maxa, (double)fabsf(bf2f(ya[i]) - bf2f(lrelu_bf(y[i], 0.1f))));
+        }
+        CK(hipMemset(Yd[b], 0, ny * 2));
+        if (Ad[b]) CK(hipMemset(Ad[b], 0, ny * 2));
+    }
+    { long long hdb[64]; CK(hipMemcpy(hdb, dbg, sizeof(hdb), hipMemcpyDeviceToHost));
+      printf("  front stamps:"); for (int i = 1; i < 30 && hdb[i]; ++i) printf(" %lld", hdb[i] - hdb[i - 1]); printf("\n");
+      { long long hw[8]; CK(hipMemcpy(hw, dbg + 64, sizeof(hw), hipMemcpyDeviceToHost)); printf("  wave -> simd:"); for (int i = 0; i < 8; ++i) printf(" %lld(w%lld)", (hw[i] >> 4) & 3, hw[i] & 15); printf("\n"); }
+      printf("  back  stamps:"); for (int i = 31; i < 60 && hdb[i]; ++i) printf(" %lld", hdb[i] - hdb[i - 1]); printf("\n"); }
+    double flops = 0;
+    for (int b = 0; b < 3; ++b) flops += 2.0 * C * C * ks[b] * N;
+    printf("%-20s ovh %5.1f grid %5d (%d/%d/%d) lds %6zu  %8.1f us  %7.1f TF/s  maxdiff %.3g (%zu of %zu differ by an ulp)  act-copy maxdiff %.3g\n", name, ovh, total_blocks, nb[0], nb[1], nb[2], lds, us,
+           flops / us * 1e-6, maxd, ndiff, 3 * ny, maxa);
+    fflush(stdout);
+}
+
 template <int C, int MS, int BNW, int BNP>
 void run_pair(const char* name, WConvArgs w1, int N, int reps, bf16_t** Xd, bf16_t** T1d, bf16_t** Yd, Conv* cv, size_t ny, int blocks_w, int blocks_p, double ovh) {
     // reference: c1 (lrelu in, lrelu out) then c2 (+ residual) with the single-conv kernel; both convs use the same weights here
@@ -253,7 +306,9 @@ int main(int argc, char** argv) {
     const int span = 10 * dil;
     const size_t ny = hx.size();
     printf("C=%d N=%d branches=%d\n", C, N, nbr);
+#ifndef TG_FAST
     run<1, 1, 256, 1, 1, 4>("ref 1x1 kc256", a, C, N, span, reps, nullptr, ny, nbr);
+#endif
     std::vector<bf16_t> yref(ny);
     CK(hipMemcpy(yref.data(), Y[0], ny * 2, hipMemcpyDeviceToHost));
     std::vector<bf16_t> yr[3]; bf16_t* yrp[3];
@@ -303,8 +358,16 @@ int main(int argc, char** argv) {
         }
         CK(hipMalloc(&zeros, 4096)); CK(hipMemset(zeros, 0, 4096)); CK(hipMalloc(&sink, 65536));
     }
+#ifdef TG_FAST
+    (void)span;
+    if (C == 128) for (double ov : {8.0, 4.0}) run_wpipe<128, 4, 64>("wpipe 128 bn64", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 64) for (double ov : {14.0, 8.0}) run_wpipe<64, 2, 128>("wpipe 64 bn128", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    return 0;
+#else
     if (C == 128) run_wconv<128, 4, 64>("wconv 128 bn64", w, N, reps, yrp, Y, ny, 256, 8.0);
     if (C == 128) for (double ov : {8.0, 4.0, 2.0}) run_wdma<128, 4, 64>("wdma 128 bn64", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 128) for (double ov : {8.0, 4.0, 2.0, 1.0}) run_wpipe<128, 4, 64>("wpipe 128 bn64", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
+    if (C == 64) for (double ov : {14.0, 8.0, 4.0, 2.0}) run_wpipe<64, 2, 128>("wpipe 64 bn128", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
     if (C == 256) for (double ov : {8.0, 4.0}) run_wdma<256, 2, 64, 2, 4>("wdma 256 ks2 ms4", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
     if (C == 64) for (double ov : {14.0, 8.0, 4.0}) run_wdma<64, 2, 128>("wdma 64 bn128", w, XA, N, reps, yrp, Y, AO, ny, 256, ov, zeros, sink);
     if (C == 64) run_wconv<64, 2, 128>("wconv 64 bn128", w, N, reps, yrp, Y, ny, 256, 14.0);
@@ -318,5 +381,6 @@ int main(int argc, char** argv) {
         if (C == 16) run_wconv<16, 1, 256>("wconv 16 bn256", w, N, reps, yrp, Y, ny, nb, 50.0);
         if (C == 16) run_wconv<16, 1, 128>("wconv 16 bn128", w, N, reps, yrp, Y, ny, nb, 50.0);
     }
+#endif
     return 0;
 }
