@@ -844,6 +844,11 @@ class CBWorkload:
             acc["tok"] += int(sum(len(p) for p in pred)); acc["frames"] += frames
             acc["t_ar"] += s1 - s0; acc["t_voc"] += s2 - s1; acc["mine"] += len(pred)
             acc["steps"] += t2s.last_stats["steps"]; acc["kv_rows"] += t2s.last_stats["kv_rows"]; acc["timed"] += 1
+            # slot-steps as the loop ran them: the tail of the queue continues on smaller bound states (t2s.py `compact`)
+            acc["slot_steps"] = acc.get("slot_steps", 0) + int(t2s.last_stats.get("slot_steps", t2s.last_stats["steps"] * self.slots))
+            acc["compacted_steps"] = acc.get("compacted_steps", 0) + sum(1 for _ in t2s.last_stats.get("compactions", []))
+            if t2s.last_stats.get("compactions"):
+                acc["compactions"] = [list(c) for c in t2s.last_stats["compactions"]]
             acc["passes"] = acc.get("passes", 0) + int(t2s.last_stats.get("passes", 0))
 
     def refill_label(self):
@@ -865,7 +870,7 @@ class CBWorkload:
     def record(self, elapsed, steps, warmup):
         """every rank calls it (one all-reduce of the totals); -> the record (value = whole-job tokens/s over all ranks)"""
         a, acc, world, dev, t2s = self.a, self.acc, self.world, self.dev, self.t2s
-        tot = torch.tensor([acc["tok"], acc["frames"], acc["mine"], acc["steps"] * self.slots], dtype=torch.float64, device=dev)
+        tot = torch.tensor([acc["tok"], acc["frames"], acc["mine"], acc.get("slot_steps", acc["steps"] * self.slots)], dtype=torch.float64, device=dev)
         if self.dist is not None:
             self.dist.all_reduce(tot)
         tok_all, frames_all, slot_steps_all = float(tot[0]), float(tot[1]), float(tot[3])
@@ -893,6 +898,11 @@ class CBWorkload:
             "audio_s_per_s_end_to_end": frames_all / 50.0 / elapsed,
             "tokens_per_step": tok_all / steps, "mean_tokens_per_request": tok_all / steps / self.n_req,
             "idle_slot_steps_frac": 1.0 - tok_all / max(slot_steps_all, 1.0),
+            "idle_slot_steps_frac_without_tail_compaction": 1.0 - acc["tok"] / max(acc["steps"] * self.slots, 1.0),
+            "tail_compaction": {"levels": list(getattr(t2s, "tail_levels", [])),
+                                "moves_of_the_last_step_on_rank0 (window, from slots, to slots, live requests)": acc.get("compactions", []),
+                                "note": "queue empty and nothing prefilled ahead: the live requests continue on a smaller bound state "
+                                        "(gsv_t2s_move_slots); the reference keeps stepping the full batch (t2s_model.py:684-694)"},
             "rank0_ar_tokens_per_s": acc["tok"] / acc["t_ar"],
             "rank0_vocoder_audio_s_per_s": acc["frames"] / 50.0 / max(acc["t_voc"], 1e-9) if (not a.overlap) else None,
             "rank0_requests_served_per_step": acc["mine"] / steps,

@@ -896,6 +896,49 @@ __global__ __launch_bounds__(256) void t2s_adopt_state_kernel(AdoptArgs a) {
     }
 }
 
+// Live slots of one stepped state move into slots of another (gsv_t2s_move_slots: the tail of a continuous-batching run continues on a
+// smaller batch size): K/V rows [0, kv_len), the token history, the penalty set and everything a step reads of the previous one.
+struct MoveArgs {
+    short dst[kAdoptMax], src[kAdoptMax];
+    const unsigned char *ks, *vs; unsigned char *kd, *vd;
+    int Bs, Ts, Bd, Td, esz, V, n;
+    const int64_t *s_kv, *s_x, *s_pre, *s_ovr; const int32_t *s_step, *s_eos; const float *s_logits, *s_hidden; const unsigned char* s_seen;
+    int64_t *d_kv, *d_x, *d_pre, *d_ovr; int32_t *d_step, *d_eos, *d_eos_host; float *d_logits, *d_hidden; unsigned char* d_seen;
+    TokPart* tokpart;                 // ONE array per handle, indexed by slot: source and destination rows may overlap
+};
+__global__ __launch_bounds__(256) void t2s_move_kv_kernel(MoveArgs a) {
+    const int lh = blockIdx.x, r = blockIdx.y, l = lh / kH, hd = lh % kH;
+    const int ss = a.src[r], ds = a.dst[r];
+    long long kv = a.s_kv[ss];
+    kv = kv < 0 ? 0 : (kv > a.Ts ? a.Ts : kv);
+    kv = kv > a.Td ? a.Td : kv;
+    const size_t n16 = (size_t)kv * kDh * a.esz / 16;
+    const size_t so = ((((size_t)l * a.Bs + ss) * kH + hd) * a.Ts) * kDh * a.esz;
+    const size_t d0 = ((((size_t)l * a.Bd + ds) * kH + hd) * a.Td) * kDh * a.esz;
+    const uint4* sp = reinterpret_cast<const uint4*>((blockIdx.z ? a.vs : a.ks) + so);
+    uint4* dp = reinterpret_cast<uint4*>((blockIdx.z ? a.vd : a.kd) + d0);
+    for (size_t i = threadIdx.x; i < n16; i += 256) dp[i] = sp[i];
+}
+__global__ __launch_bounds__(256) void t2s_move_state_kernel(MoveArgs a) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == a.n) {          // the last block: the pending tokens, read whole before any is written (one array)
+        __shared__ TokPart tp[kAdoptMax * kNP];
+        for (int i = tid; i < a.n * kNP; i += 256) tp[i] = a.tokpart[(size_t)a.src[i / kNP] * kNP + i % kNP];
+        __syncthreads();
+        for (int i = tid; i < a.n * kNP; i += 256) a.tokpart[(size_t)a.dst[i / kNP] * kNP + i % kNP] = tp[i];
+        return;
+    }
+    const int ss = a.src[blockIdx.x], s = a.dst[blockIdx.x];
+    for (int v = tid; v < a.V; v += 256) { a.d_logits[(size_t)s * a.V + v] = a.s_logits[(size_t)ss * a.V + v]; a.d_seen[(size_t)s * a.V + v] = a.s_seen[(size_t)ss * a.V + v]; }
+    for (int c = tid; c < kD; c += 256) a.d_hidden[(size_t)s * kD + c] = a.s_hidden[(size_t)ss * kD + c];
+    const int np = (a.Ts < a.Td ? a.Ts : a.Td) + 1;
+    for (int t = tid; t < np; t += 256) a.d_pre[(size_t)s * (a.Td + 1) + t] = a.s_pre[(size_t)ss * (a.Ts + 1) + t];
+    if (tid == 0) {
+        a.d_kv[s] = a.s_kv[ss]; a.d_x[s] = a.s_x[ss]; a.d_step[s] = a.s_step[ss]; a.d_eos[s] = a.s_eos[ss]; a.d_ovr[s] = a.s_ovr[ss];
+        eos_publish(a.d_eos_host, s, a.s_eos[ss]);
+    }
+}
+
 }  // namespace
 
 // One class of decode-step kernels (all layers' launches of it) captured into a hipGraph and replayed `iters` times
@@ -1192,6 +1235,35 @@ int gsv_t2s_adopt_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int
         hipLaunchKernelGGL(t2s_adopt_kv_kernel, dim3(h->cfg.n_layer * kH, n, 2), dim3(256), 0, S(stream), a);
         hipLaunchKernelGGL(t2s_adopt_state_kernel, dim3(n), dim3(256), 0, S(stream), a);
     }
+    HIPCHK(hipGetLastError());
+    return GSV_OK;
+}
+
+int gsv_t2s_move_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int batch_src, const int32_t* slots_src, int nrows, void* stream) {
+    if (!h || !h->finalized) return fail(GSV_ERR_STATE, "handle not finalized");
+    T2SBound* d = t2s_find(h, batch_dst);
+    T2SBound* sb = t2s_find(h, batch_src);
+    if (!d || !sb) return fail(GSV_ERR_STATE, "no state bound for batch %d", d ? batch_src : batch_dst);
+    if (d == sb) return fail(GSV_ERR_ARG, "move_slots: source and destination are the same state");
+    if (!slots_dst || !slots_src || nrows < 1 || nrows > batch_dst || nrows > batch_src || nrows > kAdoptMax)
+        return fail(GSV_ERR_ARG, "move_slots: need 1..min(batch, %d) slot pairs (host arrays)", kAdoptMax);
+    if (d->st.k_cache == sb->st.k_cache || d->st.v_cache == sb->st.v_cache) return fail(GSV_ERR_ARG, "move_slots: the two states share their KV cache");
+    if (sb->st.max_kv > d->st.max_kv) return fail(GSV_ERR_ARG, "move_slots: the source cache (%d positions) is longer than the destination's (%d)", sb->st.max_kv, d->st.max_kv);
+    for (int i = 0; i < nrows; ++i) {
+        if (slots_dst[i] < 0 || slots_dst[i] >= batch_dst || slots_src[i] < 0 || slots_src[i] >= batch_src) return fail(GSV_ERR_ARG, "move_slots: slot out of range");
+        for (int j = 0; j < i; ++j)
+            if (slots_dst[j] == slots_dst[i] || slots_src[j] == slots_src[i]) return fail(GSV_ERR_ARG, "move_slots: slot listed twice");
+    }
+    MoveArgs a;
+    a.ks = (const unsigned char*)sb->st.k_cache; a.vs = (const unsigned char*)sb->st.v_cache; a.kd = (unsigned char*)d->st.k_cache; a.vd = (unsigned char*)d->st.v_cache;
+    a.Bs = batch_src; a.Ts = sb->st.max_kv; a.Bd = batch_dst; a.Td = d->st.max_kv; a.esz = h->cfg.dtype == GSV_F32 ? 4 : 2; a.V = h->cfg.vocab; a.n = nrows;
+    a.s_kv = sb->st.kv_len; a.s_x = sb->st.x_len; a.s_pre = sb->st.pre_tokens; a.s_ovr = sb->st.tok_override; a.s_step = sb->st.step; a.s_eos = sb->st.eos_at;
+    a.s_logits = sb->st.logits; a.s_hidden = sb->st.hidden; a.s_seen = (const unsigned char*)sb->st.seen;
+    a.d_kv = d->st.kv_len; a.d_x = d->st.x_len; a.d_pre = d->st.pre_tokens; a.d_ovr = d->st.tok_override; a.d_step = d->st.step; a.d_eos = d->st.eos_at; a.d_eos_host = d->st.eos_host;
+    a.d_logits = d->st.logits; a.d_hidden = d->st.hidden; a.d_seen = (unsigned char*)d->st.seen; a.tokpart = h->tokpart;
+    for (int i = 0; i < nrows; ++i) { a.dst[i] = (short)slots_dst[i]; a.src[i] = (short)slots_src[i]; }
+    hipLaunchKernelGGL(t2s_move_kv_kernel, dim3(h->cfg.n_layer * kH, nrows, 2), dim3(256), 0, S(stream), a);
+    hipLaunchKernelGGL(t2s_move_state_kernel, dim3(nrows + 1), dim3(256), 0, S(stream), a);
     HIPCHK(hipGetLastError());
     return GSV_OK;
 }

@@ -18,7 +18,7 @@ GSV_F32, GSV_BF16, GSV_FP8 = 0, 1, 2
 EXPORTS = [
     "gsv_version", "gsv_last_error",
     "gsv_t2s_create", "gsv_t2s_destroy", "gsv_t2s_load_tensor", "gsv_t2s_finalize", "gsv_t2s_bind_state", "gsv_t2s_unbind_state",
-    "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_set_eos_mirror", "gsv_t2s_prefill_slots", "gsv_t2s_prefill_slots_staged", "gsv_t2s_commit_slots", "gsv_t2s_adopt_slots", "gsv_t2s_decode_hidden",
+    "gsv_t2s_embed_prompt", "gsv_t2s_prefill_workspace", "gsv_t2s_prefill", "gsv_t2s_set_eos_mirror", "gsv_t2s_prefill_slots", "gsv_t2s_prefill_slots_staged", "gsv_t2s_commit_slots", "gsv_t2s_adopt_slots", "gsv_t2s_move_slots", "gsv_t2s_decode_hidden",
     "gsv_t2s_decode", "gsv_t2s_flush", "gsv_t2s_time_kernels", "gsv_t2s_set_debug", "gsv_t2s_batched_min", "gsv_t2s_ffn_slices", "gsv_t2s_device_bytes",
     "gsv_voc_create", "gsv_voc_destroy", "gsv_voc_load_tensor", "gsv_voc_finalize", "gsv_voc_workspace",
     "gsv_voc_flow_dec", "gsv_voc_flow_dec_graph", "gsv_voc_resample_linear", "gsv_voc_flow", "gsv_voc_dec", "gsv_voc_has_enc_p", "gsv_voc_enc_workspace", "gsv_voc_enc_p", "gsv_voc_decode_workspace", "gsv_voc_decode",
@@ -81,6 +81,7 @@ def lib():
         "gsv_t2s_prefill_slots_staged": [vp, i, vp, i, i, vp, vp, vp, vp, sz, vp],
         "gsv_t2s_commit_slots": [vp, i, vp, i, vp],
         "gsv_t2s_adopt_slots": [vp, i, vp, i, vp, vp, i, vp],
+        "gsv_t2s_move_slots": [vp, i, vp, i, vp, i, vp],
         "gsv_t2s_decode_hidden": [vp, i, vp, vp],
         "gsv_t2s_decode": [vp, i, i, i, vp],
         "gsv_t2s_flush": [vp, i, vp],

@@ -77,6 +77,8 @@ class Text2SemanticDecoder:
         self.refill_priority = int(os.environ.get("GSV_REFILL_PRIO", "0")) # stream priority of the prompt passes' side stream
         self.step_priority = int(os.environ.get("GSV_STEP_PRIO", "0"))     # ... and of the stream the slot loop's steps run on
         self.refill_ahead = int(os.environ.get("GSV_REFILL_AHEAD", "8"))   # async_refill: requests prefilled AHEAD of the slots that will run them (0: the park / prompt pass / commit loop)
+        # continuous batching, queue empty: the live requests move to a smaller bound state when they fit one of these sizes (0 / empty: off)
+        self.tail_levels = [int(v) for v in os.environ.get("GSV_TAIL_LEVELS", "16,8,4").split(",") if v.strip() and int(v) > 0]
         self.use_graph = True
         self.fuse_token_step = os.environ.get("GSV_FUSE_TOKEN", "1") != "0"  # greedy steps: layer 0's attention kernel does the token kernel's work (<= 16 sequences)
         self._eos_pipe = None
@@ -109,7 +111,7 @@ class Text2SemanticDecoder:
         cands = []
         try:
             for _ in range(tune_placement):
-                self.cuda_graph_buckets, self._rt, self._ws, self._ws_staged, self._h, self._ahead = {}, {}, None, None, None, None
+                self.cuda_graph_buckets, self._rt, self._ws, self._ws_staged, self._h, self._ahead, self._tails = {}, {}, None, None, None, None, {}
                 self._build_runtime(dtype, device, gpt_cache)
                 cands.append((self._time_step(min(self._rt)), {k: getattr(self, k) for k in self._RUNTIME_FIELDS}))
                 self._h = None
@@ -228,6 +230,7 @@ class Text2SemanticDecoder:
         self._ws = None
         self._ws_staged = None
         self._ahead = None
+        self._tails = {}
         torch.cuda.synchronize(device)
 
     def __del__(self):
@@ -364,6 +367,48 @@ class Text2SemanticDecoder:
         sv = (ctypes.c_int32 * n)(*[int(v) for v in src_slots])
         ov = None if tok_override is None else (ctypes.c_int64 * n)(*[int(v) for v in tok_override])
         N.check(N.lib().gsv_t2s_adopt_slots(self._h, batch, d, src_batch, sv, ov, n, N.current_stream_ptr(self.device)))
+
+    def move_slots(self, batch_dst, slots_dst, batch_src, slots_src):
+        """gsv_t2s_move_slots on the current stream: live slots of one stepped state continue in slots of another"""
+        n = len(slots_dst)
+        d = (ctypes.c_int32 * n)(*[int(v) for v in slots_dst])
+        sv = (ctypes.c_int32 * n)(*[int(v) for v in slots_src])
+        N.check(N.lib().gsv_t2s_move_slots(self._h, batch_dst, d, batch_src, sv, n, N.current_stream_ptr(self.device)))
+
+    def _tail_state(self, n_slots, max_kv):
+        """a bound state of (about) `n_slots` slots with a K/V cache of its own that IS stepped: where the last live requests of a
+        continuous-batching run continue once the queue is empty (`_infer_batched_ahead`, gsv_t2s_move_slots).  Its batch size
+        differs from every other bound state's (states are keyed by it): `n_slots`, or the next smaller free one."""
+        tails = self.__dict__.setdefault("_tails", {})
+        key = (n_slots, max_kv)
+        if key in tails:
+            return tails[key]
+        S = n_slots
+        taken = set(self._rt) | ({self._ahead["batch"]} if getattr(self, "_ahead", None) else set())
+        while S in taken and S > 1:
+            S -= 1
+        if S in taken:
+            return None
+        dev, dh = self.device, self.model_dim // self.num_head
+        kv_dtype = torch.bfloat16 if self.dtype == torch.float8_e4m3fn else self.dtype
+        spec = [("kv_len", (S,), torch.int64), ("x_len", (S,), torch.int64), ("pre_tokens", (S, max_kv + 1), torch.int64),
+                ("seen", (S, self.vocab_size), torch.uint8), ("step", (S,), torch.int32), ("eos_at", (S,), torch.int32),
+                ("logits", (S, self.vocab_size), torch.float32), ("hidden", (S, self.model_dim), torch.float32),
+                ("tok_override", (S,), torch.int64), ("ctl", (8,), torch.int32), ("fctl", (4,), torch.float32)]
+        rt = {"batch": S, "T": max_kv, "key": key, "tail": True,
+              "k": torch.zeros(self.num_layers, S, self.num_head, max_kv, dh, dtype=kv_dtype, device=dev),
+              "v": torch.zeros(self.num_layers, S, self.num_head, max_kv, dh, dtype=kv_dtype, device=dev)}
+        for name, shp, dt in spec:
+            rt[name] = torch.zeros(*shp, dtype=dt, device=dev)
+        rt["eos_at"].fill_(-1)
+        rt["fctl"].fill_(1.0)
+        st = N.T2SState(S, max_kv, *[rt[k].data_ptr() for k in (
+            "k", "v", "kv_len", "x_len", "pre_tokens", "seen", "step", "eos_at", "logits", "hidden", "tok_override", "ctl", "fctl")])
+        torch.cuda.synchronize(dev)       # binding may re-allocate the handle's scratch: nothing may be running on it
+        N.check(N.lib().gsv_t2s_bind_state(self._h, ctypes.byref(st)))
+        self._rt[S] = rt                  # stepped like a family's state (`_decode` / `_flush` look it up); not a KV bucket family
+        tails[key] = rt
+        return rt
 
     def commit_slots(self, batch, sl):
         N.check(N.lib().gsv_t2s_commit_slots(self._h, batch, sl.data_ptr(), int(sl.numel()), N.current_stream_ptr(self.device)))
@@ -739,6 +784,9 @@ class Text2SemanticDecoder:
         cap = max(b.max_kv_cache for b in self.cuda_graph_buckets[B])
         sh = self._ahead_state(max(1, min(self.refill_ahead, B)), cap)
         S = sh["slots"]
+        # tail compaction: bound BEFORE the first step (binding may re-allocate the handle's scratch), largest first
+        tails = [t for t in (self._tail_state(lv, cap) for lv in sorted(set(self.tail_levels), reverse=True) if lv < B) if t is not None]
+        B0 = B
         for k in ("ctl", "fctl"):
             sh[k].copy_(rt[k])          # the prompt pass's first logits obey the same control words
         if getattr(self, "_refill_stream", None) is None:
@@ -767,7 +815,46 @@ class Text2SemanticDecoder:
         snap_host = torch.empty((2, 2, B), dtype=torch.int64).pin_memory()
         snaps: list = []
         keep: list = []                 # tensors of the pass in flight
-        self.last_stats = {"slots": B, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0, "passes": 1}
+        self.last_stats = {"slots": B, "steps": 0, "kv_rows": 0, "prefill_rows": actual, "refills": 0, "passes": 1,
+                           "slot_steps": 0, "live_slot_steps": 0, "compactions": []}
+
+        def compact():
+            """queue empty, nothing prefilled ahead: the live requests continue on the smallest tail state that holds them (the
+            reference keeps stepping the full batch, t2s_model.py:684-694).  Every outstanding window is read back first (its
+            records name slots of the state that is left)."""
+            nonlocal B, rt, state, req, start, steps, joined, snap_host
+            if not tails or not exhausted or ready:
+                return
+            if inflight[0] is not None:     # the last prompt pass: its requests are in `ready` until adopted; nothing else will come
+                if not inflight[0].query():
+                    return
+                inflight[0] = None
+                keep.clear()
+            n_live = sum(st == LIVE for st in state)
+            if n_live == 0 or not any(t["batch"] < B and t["batch"] >= n_live for t in tails):
+                return
+            while snaps:
+                examine(*snaps.pop(0))
+            live = [i for i in range(B) if state[i] == LIVE]
+            fit = [t for t in tails if t["batch"] < B and t["batch"] >= len(live)]
+            if not live or not fit:
+                return
+            dst = min(fit, key=lambda t: t["batch"])
+            nb = dst["batch"]
+            for k in ("ctl", "fctl"):
+                dst[k].copy_(rt[k])
+            dst["fused_ok"] = rt.get("fused_ok", False)
+            dst["kv_len"].fill_(-1)
+            self.move_slots(nb, list(range(len(live))), B, live)
+            self.last_stats["compactions"].append((window, B, nb, len(live)))
+            pad = nb - len(live)
+            state = [LIVE] * len(live) + [EMPTY] * pad
+            req = [req[i] for i in live] + [-1] * pad
+            start = [start[i] for i in live] + [0] * pad
+            steps = [steps[i] for i in live] + [0] * pad
+            joined = [0] * nb                # every outstanding window has been examined
+            B, rt = nb, dst
+            snap_host = torch.empty((2, 2, B), dtype=torch.int64).pin_memory()
 
         def top_up(force=False):
             """one packed prompt pass for the next requests, into the free slots of the ahead state"""
@@ -880,9 +967,14 @@ class Text2SemanticDecoder:
                 if ready:
                     continue
                 break
+            compact()
+            if not any(st == LIVE for st in state):
+                continue
             n = 1 if idx == 0 else min(check_interval, 1000 - idx)
             self._decode(B, n)
             self._flush(B)
+            self.last_stats["slot_steps"] += B * n
+            self.last_stats["live_slot_steps"] += n * sum(st == LIVE for st in state)
             idx = 0 if idx + n >= 1000 else idx + n
             buf = window & 1
             snap_host[buf].copy_(torch.stack([rt["kv_len"], rt["eos_at"].to(torch.int64)]), non_blocking=True)

@@ -163,6 +163,16 @@ int gsv_t2s_commit_slots(gsv_t2s* h, int batch, const int32_t* slots, int nrows,
 int gsv_t2s_adopt_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int batch_src, const int32_t* slots_src,
                         const int64_t* tok_override, int nrows, void* stream);
 
+/* Tail compaction of the slot loop (the reference lets finished slots "keep decoding garbage" once its queue is empty,
+ * t2s_model.py:684-694: the last requests then pay the step of the full batch size).  Moves LIVE slots of one stepped state into
+ * slots of ANOTHER bound state with a KV cache of its own (max_kv >= the source's) between two steps, on the step's stream:
+ * K/V rows [0, kv_len), kv_len, x_len, the token history (pre_tokens), the repetition-penalty set (seen), step, eos_at,
+ * tok_override and what the next step reads of the previous one (logits, hidden, pending token).  The next gsv_t2s_decode of
+ * `batch_dst` continues every moved request where `batch_src` left it.  slots_dst / slots_src are HOST arrays [nrows <= 64];
+ * a slot may be listed once per side.  Slots of `batch_dst` that are not listed keep their state (park them with kv_len = -1). */
+int gsv_t2s_move_slots(gsv_t2s* h, int batch_dst, const int32_t* slots_dst, int batch_src, const int32_t* slots_src, int nrows,
+                       void* stream);
+
 /* replaces T2STransformer.decode_next_token (t2s_model.py:67-105,129-143) for an EXPLICIT input
  * x [B][hidden] (parity seam): appends K/V at kv_len[b], attends to [0, kv_len[b]], writes the
  * final hidden state to state.hidden and bumps kv_len.  No sampling.  Takes the path gsv_t2s_decode would take for
