@@ -337,6 +337,10 @@ def setup_dist(a):
         return world, rank, torch.device("cpu"), dist
     if a.share_gpu and a.dist_backend == "nccl" and world > 1:
         raise SystemExit("--share-gpu needs --dist-backend gloo: RCCL wants one device per rank")
+    if not a.share_gpu and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # under a launcher too (the bare launch checks before it starts ranks): N ranks never share fewer than N devices silently
+        raise SystemExit("bench.py --gpus %d: rank %d sees %d GPU(s) for %s ranks on this node; --share-gpu (with --dist-backend gloo) is the "
+                         "explicit testing mode" % (a.gpus, rank, torch.cuda.device_count(), os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world != a.gpus:      # a line that says n_gpus: 1 for a --gpus 8 request is worse than no line
         raise SystemExit("bench.py --gpus %d is running with WORLD_SIZE=%d: launch it bare (it starts its own ranks) or under "
                          "torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
@@ -644,7 +648,7 @@ def run_single(a):
                 t2f.load_state_dict(gw)
                 t2f.initialize_runtime(torch.float32, dev, GPT_CACHE)
                 vof = _VocoderNative(hps["model"], {k: torch.from_numpy(v) for k, v in sw.items()}, torch.float32, dev)
-                t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW); vof.flow_dec(z_p, mask, ge)
+                tok32 = t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW); au32 = vof.flow_dec(z_p, mask, ge)
                 _sync(dev); s0 = time.perf_counter()
                 for _ in range(3):
                     t2f.infer(x, y, bert, top_k=1, max_new_tokens=N_NEW)
@@ -652,11 +656,50 @@ def run_single(a):
                 for _ in range(3):
                     vof.flow_dec(z_p, mask, ge)
                 _sync(dev); t2 = time.perf_counter()
+                # where the fp32 AR time goes beyond the raw steps: its own prompt pass + first step (TTFT), the raw hipGraph step
+                tf = []
+                for _ in range(10):
+                    _sync(dev); q0 = time.perf_counter()
+                    xy, xl, yl, _, _ = t2f.embed_prompt([x[0]], [y[0]], [bert[0]])
+                    t2f.prefill(1, 0, xy, xl, yl)
+                    t2f._decode(1, 1)
+                    _sync(dev)
+                    tf.append((time.perf_counter() - q0) * 1e3)
+                t2f._decode(1, 20); _sync(dev); q0 = time.perf_counter()
+                t2f._decode(1, 100); _sync(dev)
+                raw32 = (time.perf_counter() - q0) * 1e3 / 100
+                ar32 = (t1 - s0) / 3 * 1e3
                 out["fp32_parity_mode"] = {
                     "ar_tokens_per_s": 3 * N_NEW / (t1 - s0), "ar_ms_per_token": (t1 - s0) / 3 / N_NEW * 1e3,
                     "vocoder_ms": (t2 - t1) / 3 * 1e3, "tokens_per_s_end_to_end": 3 * N_NEW / (t2 - s0),
+                    "ttft_ms_p50": float(np.median(tf)), "raw_step_ms": raw32,
+                    "ar_ms_breakdown": {"utterance": ar32, "prompt_pass_and_first_step": float(np.median(tf)), "raw_steps": raw32 * (N_NEW - 1),
+                                        "loop_and_readback": ar32 - float(np.median(tf)) - raw32 * (N_NEW - 1)},
                     "note": "same workload with dtype fp32: the configuration whose greedy tokens are bit-exact and whose waveform "
                             "is within 1e-3 of the fp32 CPU reference (tests/test_hip_t2s.py, test_hip_vocoder.py)"}
+                # ---- precision ledger: what the benchmarked bf16 mode costs against the fp32 mode, from the product's own two modes
+                # (no oracle here): the bench requests' greedy tokens and the bench waveform
+                led = {"requests": []}
+                for j in range(len(reqs)):
+                    xj, yj, bj = reqs[j]
+                    tb = t2s.infer(xj, yj, bj, top_k=1, max_new_tokens=N_NEW)[0, 0].cpu().numpy()
+                    tf32 = (tok32 if j == 0 and xj is x else t2f.infer(xj, yj, bj, top_k=1, max_new_tokens=N_NEW))[0, 0].cpu().numpy()
+                    n = min(len(tb), len(tf32))
+                    neq = np.nonzero(tb[:n] != tf32[:n])[0]
+                    led["requests"].append({"tokens": int(n), "matched_prefix": int(neq[0]) if neq.size else int(n),
+                                            "agreement": float((tb[:n] == tf32[:n]).mean())})
+                ab = voc.flow_dec(z_p, mask, ge).float().cpu().numpy().ravel()
+                af = au32.float().cpu().numpy().ravel()
+                led["matched_prefix_min"] = min(r["matched_prefix"] for r in led["requests"])
+                led["matched_prefix_mean"] = float(np.mean([r["matched_prefix"] for r in led["requests"]]))
+                led["token_agreement_mean"] = float(np.mean([r["agreement"] for r in led["requests"]]))
+                led["waveform_max_abs_diff"] = float(np.abs(ab - af).max())
+                led["waveform_mean_abs_diff"] = float(np.abs(ab - af).mean())
+                led["waveform_rms_fp32"] = float(np.sqrt((af.astype(np.float64) ** 2).mean()))
+                led["note"] = ("bf16-mode output against the fp32-mode output of the SAME library on the bench inputs (greedy, %d tokens per request; the "
+                               "%d-frame waveform from the same z_p): once a token differs the two sequences are different utterances, so `agreement` "
+                               "after the matched prefix measures decorrelation, not error" % (N_NEW, FRAMES))
+                out["bf16_vs_fp32"] = led
                 del t2f, vof
         except Exception as exc:   # extras must never cost the bench line
             log("extras skipped: %r" % (exc,))
@@ -667,6 +710,17 @@ def run_single(a):
             out["cpu_baseline"] = cb
             if cb.get("value"):
                 out["speedup_vs_cpu_baseline"] = value / cb["value"]
+                ratios = {"end_to_end": value / cb["value"]}
+                if cb.get("ar_tokens_per_s"):
+                    ratios["ar_only"] = out["ar_tokens_per_s_per_gpu"] / cb["ar_tokens_per_s"]
+                if cb.get("vocoder_audio_s_per_s"):
+                    ratios["vocoder_only"] = out["vocoder_audio_s_per_s_per_gpu"] / cb["vocoder_audio_s_per_s"]
+                f32 = out.get("fp32_parity_mode")
+                if f32:
+                    ratios["fp32_mode_end_to_end"] = f32["tokens_per_s_end_to_end"] / cb["value"]
+                    if cb.get("ar_tokens_per_s"):
+                        ratios["fp32_mode_ar_only"] = f32["ar_tokens_per_s"] / cb["ar_tokens_per_s"]
+                out["speedup_vs_cpu_baseline_by_leg"] = ratios
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
