@@ -432,9 +432,11 @@ void t2s_launch_ffn(gsv_t2s* h, const gsv_t2s_state& s, int l, hipStream_t st) {
     const int B = s.batch;
     static const int ffn_single_max_b = getenv("GSV_FFN_SINGLE_MAX_B") ? atoi(getenv("GSV_FFN_SINGLE_MAX_B")) : 8;   // tuning aid
     bool four = false;
-    if constexpr (sizeof(WT) == 2) {     // four sequences per block: bf16 handles only (an fp32 instantiation would spill 53 registers and is never launched)
+#ifdef GSV_AB_KERNELS                   // four sequences per block (bf16 handles; spills 16 registers): an A/B kernel, not in the shipped library -- above 16
+    if constexpr (sizeof(WT) == 2) {     // sequences a bf16 handle runs the batched chain, and the per-sequence path behind it (caches beyond 1024 positions) R = 2
         if (B > 16) { hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 4>), dim3(kNJ, cdiv(B, 4)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<4>(), st, f, B); four = true; }
     }
+#endif
     if (four) {}
     else if (B > ffn_single_max_b) hipLaunchKernelGGL((t2s_ffn_multi_kernel<WT, 2>), dim3(kNJ, cdiv(B, 2)), dim3(kNT), sizeof(float) * ffn_multi_lds_floats<2>(), st, f, B);
     else if (ffn_slices<WT>(B) == kNJFine) {
@@ -453,8 +455,10 @@ int t2s_multi_lds_attr() {
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_attn_multi_kernel<WT, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, la));
     HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<2>())));
+#ifdef GSV_AB_KERNELS
     if constexpr (sizeof(WT) == 2)      // four sequences per block: bf16 handles only (t2s_launch_ffn); no fp32 instantiation exists
         HIPCHK(hipFuncSetAttribute((const void*)t2s_ffn_multi_kernel<WT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * ffn_multi_lds_floats<4>())));
+#endif
     return GSV_OK;
 }
 

@@ -2,7 +2,7 @@
 // wups / flowfuse) and enc_p.  Workspaces come from the caller; nothing is allocated inside a pass.
 #include <tuple>
 
-#include "abi_common.h"
+#include "voc_launch.h"
 #include "flowfuse.h"
 #include "flowstage.h"
 #include "rbfuse.h"
@@ -133,7 +133,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.nseg = (int*)take(sizeof(int) * 64);
     w.seg = nullptr;
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
-    for (int i = 0; i < 15; ++i) w.st[i] = take(sizeof(AT) * se);
+    for (int i = 0; i < 15; ++i) w.st[i] = (i < 11 || sizeof(AT) == 2) ? take(sizeof(AT) * se) : nullptr;   // [11..14]: wdma's activated copies, bf16 handles only
     w.bytes = off;
     return w;
 }
@@ -297,10 +297,11 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
         Epi eu; eu.in_slope = 0.1f;
         // 64 / 128 / 256 channels: the resblock convs stage their rows by LDS-DMA (wdma.h), so the state x of a branch travels with its
         // activated copy lrelu(x) -- written by whoever writes x (the transposed conv here, the second conv of a pair below)
-        const bool dma = sizeof(AT) == 2 && v->dma_zero && wdma_shape(sg.cout, ldo, Tn) && !(sg.rb_c && ldo == sg.rb_c);
+        bool dma = sizeof(AT) == 2 && v->dma_zero && wdma_shape(sg.cout, ldo, Tn) && !(sg.rb_c && ldo == sg.rb_c);
         int ru = run_wups<AT>(sg.up, x, ldi, Tc, xu, ldo, 0.1f, st, dma ? w.st[11] : nullptr, 0.1f);
-        if (ru != 0 && dma) return fail(GSV_ERR_STATE, "the transposed conv in front of a wdma stage must run on wups");
         if (ru > 0) return ru;
+        if (ru < 0) dma = false;   // no wups shape for this transposed conv (GSV_NO_WUPS, a stride / tap count outside its table): nobody writes the
+                                   // activated copy, so the stage's resblock convs take the wconv / cgemm / tapgemm path below
         if (ru < 0)
             if (int rc = run_conv<AT, AT, AT>(sg.up, x, ldi, Tc, xu, ldo, Tc, eu, st)) return rc;
         if (sizeof(AT) == 2 && sg.rb_c && ldo == sg.rb_c) {
@@ -934,10 +935,11 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
             v->post_c = ch;
         }
     }
-    if (!rc && sizeof(CT) == 2 && !v->dma_zero) {
-        HIPCHK(hipMalloc(&v->dma_zero, 4096));
-        HIPCHK(hipMemsetAsync(v->dma_zero, 0, 4096, st));
-        HIPCHK(hipMalloc(&v->dma_sink, 4096));
+    if (!rc && sizeof(CT) == 2 && !v->dma_zero) {   // failures here go through `rc`: the temporaries below are still freed behind the stream
+        hipError_t e = hipMalloc(&v->dma_zero, 4096);
+        if (e == hipSuccess) e = hipMemsetAsync(v->dma_zero, 0, 4096, st);
+        if (e == hipSuccess) e = hipMalloc(&v->dma_sink, 4096);
+        if (e != hipSuccess) rc = fail(GSV_ERR_HIP, "wdma zero page / sink: %s", hipGetErrorString(e));
     }
     if (!rc && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize<CT>(v, temps, st);
     (void)hipStreamSynchronize(st);

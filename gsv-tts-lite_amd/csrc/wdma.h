@@ -194,7 +194,11 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
     issue_x(blk, xbuf0);
     load_weights();
     if (tid < MS * 32) bl[tid] = bias_raw;
-    wait_vm<0>();
+    // Only the first tile's rows (and the bias) have to have landed here: they are OLDER than the NT * KSW fragment loads, which were
+    // issued in the order the MFMA loop consumes them -- hipcc's own counted waits in front of each fragment's first MFMA let the first
+    // tile's loop start behind the first fragments while the rest of the block's 90-360 KB of weights is still streaming in (round 6;
+    // the drain here cost every launch the whole weight pull, ~6 us at 128 channels, before its first MFMA).  vmcnt holds 6 bits.
+    wait_vm<(NT * KSW < 63 ? NT * KSW : 63)>();
     lds_barrier();
     if constexpr (DIRECT) {
 #pragma unroll
@@ -369,11 +373,19 @@ __device__ __forceinline__ void wdma_body(const bf16_t* __restrict__ X, const ui
         }   // DIRECT
 
         stamp();
-        // next tile's rows: this wave's DMAs are older than its stores of this tile
+        // next tile's rows: this wave's DMAs are older than its stores of this tile.  The counts are the stores the epilogue above issues per
+        // wave: NVR (= 2 WN in the DIRECT form: two per 32-row tile) for Y, as many again for A.  An instruction more than counted (hipcc
+        // splitting a store, a scratch access) only over-waits; one FEWER would under-wait and read stale rows with no error -- so the
+        // relation is pinned here, and -DWDMA_DRAIN builds every counted wait as vmcnt(0) (the A/B build behind the bit-identity test's claim).
+        static_assert(NVR == 2 * WN, "the counted waits assume NVR = 2 WN stores per output tensor per tile");
         if (has_next) {
+#ifdef WDMA_DRAIN
+            wait_vm<0>();
+#else
             if (!epi) wait_vm<0>();
             else if (A) wait_vm<2 * NVR>();
             else wait_vm<NVR>();
+#endif
         }
         lds_barrier();
         stamp();

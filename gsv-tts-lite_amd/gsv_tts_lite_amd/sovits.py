@@ -122,9 +122,16 @@ class _VocoderNative:
                                                 N.current_stream_ptr(self.device)))
         return y
 
+    def _ready(self, t):
+        """fp32, contiguous, on the device: what the C ABI takes.  The common case (it already is) costs one check, not two tensor ops --
+        a pass that starts on an idle stream pays every host microsecond in front of its first launch (tools/voc_gap.py)."""
+        if t.dtype is torch.float32 and t.device == self.device and t.is_contiguous():
+            return t
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
     def _prep(self, z, ge):
-        z = z.to(device=self.device, dtype=torch.float32).contiguous()
-        ge = ge.to(device=self.device, dtype=torch.float32).contiguous()
+        z = self._ready(z)
+        ge = self._ready(ge)
         assert z.dim() == 3 and z.shape[0] == 1, "flow/dec run one (possibly time-concatenated) sequence"
         T = z.shape[2]
         Tg = ge.shape[2]
@@ -156,7 +163,7 @@ class _VocoderNative:
         if self._graph_worthy(int(z_p.shape[2]), int(ge.shape[2])):
             return self.flow_dec_bucket(z_p, y_mask, ge)
         z, ge, T, Tg = self._prep(z_p, ge)
-        mask = y_mask.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+        mask = self._ready(y_mask).reshape(-1)
         out = torch.empty(1, 1, T * self.samples_per_frame, dtype=torch.float32, device=self.device)
         ws = self._workspace(T)
         N.check(N.lib().gsv_voc_flow_dec(self._h, z.data_ptr(), mask.data_ptr(), ge.data_ptr(), T, Tg, out.data_ptr(),

@@ -65,6 +65,7 @@ ORC_API void orc_set_num_threads(int n) {
  *                 the form in which they cross the kernel boundary on bf16 handles (csrc/t2s_decode.h PartOf)
  *   ORC_R_FINE    with ORC_R_PART: W2 from 64 slices of 32 hidden units (the library's choice at <= 4 sequences,
  *                 gsv_t2s_ffn_slices)
+ *   ORC_R_FFN32   with ORC_R_LIN: mlp.0 / mlp.2 keep fp32 input rows (the two-sequences-per-block FFN kernel of 9..16 sequences)
  *                 (conv outputs after bias / conditioning / residual; the leaky-ReLU'd conv operands; the branch mean;
  *                 the flow's h, gate output, skip operand and updated half), fp32 accumulation inside each op
  * 0 = the fp32 reference arithmetic. */
@@ -75,6 +76,8 @@ ORC_API void orc_set_num_threads(int n) {
 #define ORC_R_VOC 16
 #define ORC_R_PART 32
 #define ORC_R_FINE 64
+#define ORC_R_FFN32 128   /* with ORC_R_LIN: the FFN's two linears take their input rows in fp32 (t2s_ffn_multi_kernel, two sequences per block:
+                           * 9..16 sequences; its dots are fp32 FMA chains on unpacked weights, csrc/t2s_decode_multi.h) */
 static int g_round = 0;
 ORC_API void orc_set_rounding(int flags) { g_round = flags; }
 ORC_API int orc_get_rounding(void) { return g_round; }
@@ -250,9 +253,12 @@ static void block_tail(const layer_t* L, int M, int D, int H, int part, float* x
     else linear_r(attn, M, D, L->out_w, L->out_b, D, tmp_d, 0, 0);
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln1_g, L->ln1_b, 1e-5f, x);
+    const int keep = g_round;
+    if (g_round & ORC_R_FFN32) g_round &= ~ORC_R_LIN;      /* the FFN of this path multiplies fp32 activations */
     linear_r(x, M, D, L->w1, L->b1, F, tmp_f, 1, 1);
     if (part) linear_sliced(tmp_f, M, F, L->w2, L->b2, D, (g_round & ORC_R_FINE) ? 32 : 64, tmp_d);   /* 32 slices of 64 hidden units, or 64 of 32 */
     else linear_r(tmp_f, M, F, L->w2, L->b2, D, tmp_d, 0, 1);
+    g_round = keep;
     for (size_t i = 0; i < (size_t)M * D; ++i) tmp_d[i] += x[i];
     orc_layernorm(tmp_d, M, D, L->ln2_g, L->ln2_b, 1e-5f, x);
 }

@@ -124,7 +124,7 @@ def sine_pe(n_pos: int, dim: int) -> np.ndarray:
     return pe
 
 
-R_KV, R_LIN, R_ATTN, R_FP8, R_VOC, R_PART, R_FINE = 1, 2, 4, 8, 16, 32, 64     # gsv_oracle.c ORC_R_*
+R_KV, R_LIN, R_ATTN, R_FP8, R_VOC, R_PART, R_FINE, R_FFN32 = 1, 2, 4, 8, 16, 32, 64, 128     # gsv_oracle.c ORC_R_*
 
 
 def round_bf16(a):
@@ -158,6 +158,8 @@ class T2SOracle:
     it from the HIP kernels: the tight pin of the kernels the bench times.  `batched_min` mirrors the library's
     switch to the batched decode step (gsv_t2s_batched_min), `ffn_slices` its FFN slice count per batch size
     (gsv_t2s_ffn_slices: 64 at <= 4 sequences, else 32)."""
+
+    FFN_SINGLE_MAX_B = 8      # the library's one-sequence-per-block FFN kernel up to here (gsv_abi.hip t2s_launch_ffn), two per block above
 
     def __init__(self, config, weights, gpt_cache, numerics="fp32", batched_min=12, ffn_slices=None):
         m = config["model"]
@@ -266,8 +268,9 @@ class T2SOracle:
         kv = np.ascontiguousarray(kv_len, np.int64)
         pack, flags = self.pack, 0
         if self.numerics != "fp32":
-            flags = R_KV | R_LIN                           # every dot of the step takes bf16 activations (per-sequence kernels: since round 5)
-            if bsz >= self.batched_min:                    # batched chain: bf16 (fp8) MFMA operands
+            flags = R_KV
+            if bsz >= self.batched_min and kc.shape[3] <= 1024:   # batched chain (gsv_t2s_decode takes it up to 1024 cache positions): bf16 (fp8) MFMA operands
+                flags |= R_LIN
                 if self.numerics == "fp8":
                     flags |= R_FP8
                     pack = self.pack8
@@ -277,6 +280,14 @@ class T2SOracle:
                 assert n_sl in (32, 64)
                 if n_sl == 64:
                     flags |= R_FINE
+                # which dots take ONE bf16 value per activation (round 5) and which still run fp32 FMA chains on unpacked weights:
+                #   <= 8 sequences      t2s_attn_kernel + t2s_ffn_kernel: bf16 activations everywhere
+                #   9 .. 16             t2s_attn_kernel (bf16 activations) + t2s_ffn_multi_kernel<.., 2> (fp32 activations)
+                #   > 16 (long caches)  t2s_attn_multi_kernel + t2s_ffn_multi_kernel: fp32 activations everywhere
+                if bsz <= self.FFN_SINGLE_MAX_B:
+                    flags |= R_LIN
+                elif bsz <= 16:
+                    flags |= R_LIN | R_FFN32
         lib().orc_set_rounding(flags)
         try:
             lib().orc_t2s_decode(_fp(pack), self.NL, self.D, self.H, x.shape[0], _fp(x), _fp(kc), _fp(vc),
