@@ -32,6 +32,11 @@ struct CGemmArgs {
     int k0, k1, k2;               // taps
     int d0, d1, d2;               // dilations
     int nb0, nb1;                 // blocks of branch 0 / 1 (the rest: branch 2)
+    int ns0, ns1, ns2;            // K split of a branch's tiles (1 = none): a tile's 64-channel chunks are dealt to ns CONSECUTIVE blocks; the last one
+                                  // adds the others' fp32 partial tiles (through `part`, behind `flag`) and owns the epilogue -- few row tiles (10 s of
+                                  // audio at 384 channels: 240 blocks of 66 / 42 / 18 iterations on 256 CUs) otherwise wait for the 11-tap blocks
+    float* part;                  // [split tile][ns - 1][BM x BN floats] or null
+    int* flag;                    // [split tile][ns - 1], zero between launches
     int ld, n_rows;
     float in_slope, out_slope;    // leaky-ReLU on the input / the output (1 = none)
     long long* dbg;               // null, or cycle stamps of block 0 / thread 0 (tools/cg_bench)
@@ -105,8 +110,15 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
     bf16_t* Y = br == 0 ? a.Y0 : (br == 1 ? a.Y1 : a.Y2);
     const int K = br == 0 ? a.k0 : (br == 1 ? a.k1 : a.k2);
     const int d = br == 0 ? a.d0 : (br == 1 ? a.d1 : a.d2);
+    const int ns = br == 0 ? a.ns0 : (br == 1 ? a.ns1 : a.ns2);
+    const int sp = ns > 1 ? b % ns : 0;           // this block's share of the chunks; the LAST share (sp == ns - 1) owns the epilogue
+    if (ns > 1) b /= ns;
+    // split tiles are numbered through the launch: branch 0's first, then branch 1's, ... (only split branches count)
+    const int tiles0 = a.nb0 / a.ns0, tiles1 = a.nb1 / a.ns1;
+    const int stile = b + (br >= 1 && a.ns0 > 1 ? tiles0 : 0) + (br == 2 && a.ns1 > 1 ? tiles1 : 0);
     const int tn = b % S::TN, tm = b / S::TN;
     const int r0 = tm * S::BM, n0 = tn * BN;
+    const int c_lo = ns > 1 ? sp * (S::NCH / ns) : 0, c_n = ns > 1 ? S::NCH / ns : S::NCH;
     const int hk = (K - 1) / 2;
     const int xrows = S::BM + 2 * hk * d;         // rows this conv needs staged
     unsigned char* xbuf = lds;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     auto w_issue = [&](int it) {        // it = chunk * K + tap  -> packed tile [tap][chunk] -> LDS buffer it % NWB
-        const int ch = it / K, tap = it % K;
+        const int ch = c_lo + it / K, tap = it % K;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(W + ((size_t)(tap * S::NCH + ch) * S::NPL) * C);
         unsigned char* dst = wbuf + (it % S::NWB) * S::WBUF + wid * 64 * 16;
 #pragma unroll
@@ -175,11 +187,11 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-    const int nit = S::NCH * K;
+    const int nit = c_n * K;                      // iteration it -> chunk c_lo + it / K, tap it % K
     auto stamp = [&](int i) { if (a.dbg && blockIdx.x == 0 && tid == 0 && i < 64) a.dbg[i] = (long long)__builtin_readcyclecounter(); };
     stamp(0);
-    x_issue(0);
-    x_commit(0);
+    x_issue(c_lo);
+    x_commit(c_lo % S::XB);
     constexpr int PF = S::NWB - 1;       // weight tiles in flight beyond the one being multiplied
     w_issue(0);
     if (PF > 1 && nit > 1) w_issue(1);
@@ -194,12 +206,12 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
     stamp(1);
     for (int it = 0; it < nit; ++it) {
         stamp(2 + it);
-        const int ch = it / K, tap = it - ch * K;
+        const int chl = it / K, tap = it - chl * K, ch = c_lo + chl;
         // the buffer of tile it + PF was last read in iteration it - 1, which every wave has left (the barrier below)
 #ifndef CG_SKIP_W
         if (it + PF < nit) w_issue(it + PF);
 #endif
-        const bool xi = tap == 0 && ch + 1 < S::NCH;
+        const bool xi = tap == 0 && chl + 1 < c_n;
         if (xi) x_issue(ch + 1);             // lands during this chunk's K iterations
         const unsigned char* xb = xbuf + (ch % S::XB) * S::XBUF + xlane + (unsigned)(tap * d) * 16;
         const unsigned char* wb = wbuf + (it % S::NWB) * S::WBUF + wlane;
@@ -225,7 +237,7 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
                     acc[i][t][0] += __uint_as_float(af[ks & 1][t][0] ^ bf[ks & 1][i][1]);
 #endif
         }
-        if (tap == K - 1 && ch + 1 < S::NCH) {
+        if (tap == K - 1 && chl + 1 < c_n) {
             if (S::XB == 1) {      // one activation buffer: everyone has to be done with this chunk before the next one lands in it
                 asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
                 __builtin_amdgcn_s_barrier();
@@ -248,6 +260,54 @@ __global__ __launch_bounds__((CgShape<C, BN, BM, RT>::NT), 2) void cgemm_kernel(
         asm volatile("" : : : "memory");      // no LDS read of the next iteration above the barrier
     }
     stamp(2 + nit);
+    if (ns > 1) {
+        // ---- K split: partial tiles in accumulator order, thread-linear ([(i, t, q4)][thread] 16-byte pieces: coalesced, and the consumer's
+        // threads own the same (row, channel) elements).  The producers are EARLIER blocks of the launch than their consumer: they have been
+        // dispatched when it spins, and they wait for nobody.  Coherence is PER INSTRUCTION (sc1: the partial tiles are written through and
+        // read around the XCDs' non-coherent L2 lines): an agent-scope release / acquire pair would write back and INVALIDATE a whole L2 per
+        // hand-off -- measured, the launch got slower (71 -> 101 us): every other block of that XCD lost its weight tiles.
+        constexpr size_t TILE_F = (size_t)RT * WN * 16 * S::NT;
+        float* pt = a.part + ((size_t)stile * 2) * TILE_F;          // two slots per split tile, whatever ns is
+        int* fl = a.flag + (size_t)stile * 2;
+        if (sp < ns - 1) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < WN; ++t)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {acc[i][t][4 * q4], acc[i][t][4 * q4 + 1], acc[i][t][4 * q4 + 2], acc[i][t][4 * q4 + 3]};
+                        float* dstp = pt + (size_t)sp * TILE_F + ((size_t)((i * WN + t) * 4 + q4) * S::NT + tid) * 4;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dstp), "v"(v) : "memory");
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // written through ...
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(fl + sp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag says so
+            return;
+        }
+        if (tid == 0) {
+            for (int p = 0; p < ns - 1; ++p) {
+                int spins = 0;                     // bounded: a launch must never hang the device (a producer that was never dispatched cannot
+                while (__hip_atomic_load(fl + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);   // exist: blocks dispatch in order)
+            }
+        }
+        __syncthreads();
+        for (int p = 0; p < ns - 1; ++p)           // fixed order: own share + share 0 + share 1
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+                for (int t = 0; t < WN; ++t)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float* srcp = pt + (size_t)p * TILE_F + ((size_t)((i * WN + t) * 4 + q4) * S::NT + tid) * 4;
+                        f32x4 v;
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(srcp) : "memory");
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][t][4 * q4 + e] += v[e];
+                    }
+        __syncthreads();                           // everyone has read the partial tiles: the flags go back to zero for the next launch
+        if (tid < ns - 1) __hip_atomic_store(fl + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- epilogue: lane (row n of tile i, half hi) holds channels n0 + BN/2 wn + 32 t + 16 hi + r
 #pragma unroll
     for (int i = 0; i < RT; ++i) {

@@ -59,6 +59,7 @@ struct gsv_voc {
     float* post_w = nullptr;         // conv_post weight [C][7] fp32 for conv_post_kernel
     void* dma_zero = nullptr;        // wdma.h: a zero page (rows outside the sequence) and a sink (stores of rows beyond it)
     void* dma_sink = nullptr;
+    int* cg_flag = nullptr;          // cgemm.h K split: hand-off flags of the partial tiles (zero between launches; a handle runs one pass at a time)
     int post_c = 0;
     bool fused_flow = false;
     EncP enc;                        // enc_p in HIP (bf16 mode, when its tensors were loaded)
@@ -107,6 +108,7 @@ struct VocWs {
     float *gc, *condbuf;
     int *seg_flag, *seg_id, *seg_first, *nseg;   // per-frame ge with few distinct columns (voc_kernels.h); seg = null: one row per frame
     const int* seg;
+    float* cg_part;   // cgemm.h K split: partial tiles (null on handles without a cgemm stage)
     void* st[15];  // stage buffers: xu, x (stage in/out), then per resblock branch {t1, xa, xb}; [11] lrelu(xu), [12..14] lrelu of a branch's state (wdma.h)
     size_t bytes;
 };
@@ -134,6 +136,7 @@ VocWs voc_layout(const gsv_voc* v, int T, int Tg, char* base) {
     w.seg = nullptr;
     const size_t se = (size_t)T * std::max(v->max_stage_elems_per_frame, ld_of(c.upsample_initial_channel));
     for (int i = 0; i < 15; ++i) w.st[i] = (i < 11 || sizeof(AT) == 2) ? take(sizeof(AT) * se) : nullptr;   // [11..14]: wdma's activated copies, bf16 handles only
+    w.cg_part = (sizeof(AT) == 2 && v->cg_flag) ? (float*)take(kCgPartBytes) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -346,10 +349,10 @@ int voc_dec_impl(gsv_voc* v, VocWs& w, int T, int Tg, float* out, hipStream_t st
             }
             // bf16, 16..128 channels: weights-in-registers kernel; the first conv writes lrelu(t1), which is
             // the only form its consumer reads, so the second conv stages its input without arithmetic
-            int rw = run_cgemm<AT>(b1, ldo, Tn, 0.1f, 0.1f, st);
+            int rw = run_cgemm<AT>(b1, ldo, Tn, 0.1f, 0.1f, st, w.cg_part, kCgPartBytes, v->cg_flag);
             if (rw > 0) return rw;
             if (rw == 0) {
-                rw = run_cgemm<AT>(b2, ldo, Tn, 1.0f, 1.0f, st);
+                rw = run_cgemm<AT>(b2, ldo, Tn, 1.0f, 1.0f, st, w.cg_part, kCgPartBytes, v->cg_flag);
                 if (rw != 0) return rw > 0 ? rw : fail(GSV_ERR_STATE, "cgemm accepted the first conv of a pair but not the second");
                 for (int j = 0; j < 3; ++j) cur[j] = (const AT*)b2[j].Y;
                 continue;
@@ -941,6 +944,15 @@ int voc_finalize_impl(gsv_voc* v, hipStream_t st) {
         if (e == hipSuccess) e = hipMalloc(&v->dma_sink, 4096);
         if (e != hipSuccess) rc = fail(GSV_ERR_HIP, "wdma zero page / sink: %s", hipGetErrorString(e));
     }
+    if (!rc && sizeof(CT) == 2 && !v->cg_flag) {    // a stage of 192 / 256 / 384 channels: cgemm.h, whose small launches K-split
+        bool wide = false;
+        for (const VocStage& sg : v->stages) wide = wide || sg.cout == 192 || sg.cout == 256 || sg.cout == 384;
+        if (wide) {
+            hipError_t e = hipMalloc(&v->cg_flag, sizeof(int) * 2 * kCgSplitMaxTiles);
+            if (e == hipSuccess) e = hipMemsetAsync(v->cg_flag, 0, sizeof(int) * 2 * kCgSplitMaxTiles, st);
+            if (e != hipSuccess) rc = fail(GSV_ERR_HIP, "cgemm hand-off flags: %s", hipGetErrorString(e));
+        }
+    }
     if (!rc && v->staged.count("enc_p.ssl_proj.weight")) rc = encp_finalize<CT>(v, temps, st);
     (void)hipStreamSynchronize(st);
     for (float* t : temps) (void)hipFree(t);
@@ -970,6 +982,8 @@ void voc_free(gsv_voc* v) {
     if (v->dma_zero) (void)hipFree(v->dma_zero);
     if (v->dma_sink) (void)hipFree(v->dma_sink);
     v->dma_zero = v->dma_sink = nullptr;
+    if (v->cg_flag) (void)hipFree(v->cg_flag);
+    v->cg_flag = nullptr;
     for (VocStage& s : v->stages) {
         free_conv(s.up);
         if (s.rb_w) (void)hipFree(s.rb_w);

@@ -14,13 +14,18 @@ namespace {
 // launch does not fit it (caller falls back to tapgemm): returns -1 then, 0 on success, > 0 = GSV_ERR_*.
 // wide resblock convs on the LDS-tiled GEMM (cgemm.h): 384 and 192 channels always, 256 channels from 16k rows on (below that
 // the weights-in-registers kernel's shorter block wins: measured 33 vs 39 us per launch at 5 000 rows, 267 vs 207 at 50 000)
+// K-split launches of cgemm.h: at most this many blocks before the split (the grid underfills 256 CUs), hence at most 2 x 85 split tiles per launch
+constexpr int kCgSplitMaxBlocks = 256;
+constexpr int kCgSplitMaxTiles = 2 * (kCgSplitMaxBlocks / 3);
+constexpr size_t kCgPartBytes = (size_t)kCgSplitMaxTiles * 2 * 128 * 192 * sizeof(float);   // the largest tile of the shapes that split: 128 rows x 192 channels
+
 template <typename AT>
-int run_cgemm(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
-    (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st;
+int run_cgemm(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st, float* part = nullptr, size_t part_bytes = 0, int* flag = nullptr) {
+    (void)brs; (void)ld; (void)n_rows; (void)in_slope; (void)out_slope; (void)st; (void)part; (void)part_bytes; (void)flag;
     return -1;
 }
 template <>
-inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st) {
+inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slope, float out_slope, hipStream_t st, float* part, size_t part_bytes, int* flag) {
     static const bool off = getenv("GSV_NO_CGEMM") != nullptr;
     const int C = brs[0].pc->cout;
     if (off || !(C == 384 || C == 192 || (C == 256 && n_rows >= 16384)) || ld != C) return -1;
@@ -44,9 +49,26 @@ inline int run_cgemm<bf16_t>(const Branch* brs, int ld, int n_rows, float in_slo
     a.ld = ld; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
     auto launch = [&](auto kern, size_t lds, int bm, int tn, int nt) -> int {
         const int tiles = cdiv(n_rows, bm) * tn;
-        a.nb0 = tiles; a.nb1 = tiles;
+        // Few row tiles (10 s of audio at 384 channels: 80 tiles per branch = 240 blocks of 66 / 42 / 18 iterations for 256 CUs; a streaming chunk:
+        // 24 blocks): the heavy branches' tiles are K-split over consecutive blocks (cgemm.h `ns`): 72 -> 59 us per launch at 5 000 rows, 66 -> 43
+        // at 500 (tools/cg_bench, profiles/r06_cgemm_ksplit.txt).  The scratch holds two partial tiles per split tile.
+        const int nch = C / 64;
+        int ns[3] = {1, 1, 1};
+        static const bool nosplit = getenv("GSV_CGEMM_NO_SPLIT") != nullptr;
+        if (!nosplit && part && flag && 3 * tiles <= kCgSplitMaxBlocks) {
+            const int ks[3] = {a.k0, a.k1, a.k2};
+            for (int i = 0; i < 3; ++i) {
+                if (ks[i] >= 9) ns[i] = nch % 3 == 0 ? 3 : (nch % 2 == 0 ? 2 : 1);
+                else if (ks[i] >= 5) ns[i] = nch % 2 == 0 ? 2 : 1;
+            }
+            const size_t need = (size_t)((ns[0] > 1 ? tiles : 0) + (ns[1] > 1 ? tiles : 0) + (ns[2] > 1 ? tiles : 0)) * 2 * bm * (C / tn) * sizeof(float);
+            if (need > part_bytes) ns[0] = ns[1] = ns[2] = 1;
+        }
+        a.ns0 = ns[0]; a.ns1 = ns[1]; a.ns2 = ns[2];
+        a.nb0 = tiles * ns[0]; a.nb1 = tiles * ns[1];
+        a.part = part; a.flag = flag;
         HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(nt), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(tiles * (ns[0] + ns[1] + ns[2])), dim3(nt), lds, st, a);
         HIPCHK(hipGetLastError());
         return GSV_OK;
     };

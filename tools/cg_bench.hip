@@ -50,11 +50,22 @@ int run(int n_rows, int dil, int use_res) {
     const int tiles = ((n_rows + S::BM - 1) / S::BM) * S::TN;
     a.X0 = a.X1 = a.X2 = dx; a.W0 = dw[0]; a.W1 = dw[1]; a.W2 = dw[2]; a.b0 = db[0]; a.b1 = db[1]; a.b2 = db[2];
     a.R0 = a.R1 = a.R2 = use_res ? dr : nullptr; a.Y0 = dy[0]; a.Y1 = dy[1]; a.Y2 = dy[2];
-    a.k0 = 11; a.k1 = 7; a.k2 = 3; a.d0 = a.d1 = a.d2 = dil; a.nb0 = tiles; a.nb1 = tiles;
+    // K split per branch (CG_SPLIT="3,2,1": the 11-tap branch's chunks over three consecutive blocks, the 7-tap branch's over two)
+    int ns[3] = {1, 1, 1};
+    if (const char* e = getenv("CG_SPLIT")) sscanf(e, "%d,%d,%d", &ns[0], &ns[1], &ns[2]);
+    for (int b = 0; b < 3; ++b) if (ns[b] < 1 || S::NCH % ns[b]) { printf("CG_SPLIT: %d does not divide %d chunks\n", ns[b], S::NCH); return 1; }
+    a.k0 = 11; a.k1 = 7; a.k2 = 3; a.d0 = a.d1 = a.d2 = dil; a.nb0 = tiles * ns[0]; a.nb1 = tiles * ns[1];
+    a.ns0 = ns[0]; a.ns1 = ns[1]; a.ns2 = ns[2];
+    const int nblocks = tiles * (ns[0] + ns[1] + ns[2]);
+    {
+        const size_t tile_f = (size_t)S::BM * BN;
+        CK(hipMalloc(&a.part, sizeof(float) * tile_f * 2 * 3 * tiles + 16));
+        CK(hipMalloc(&a.flag, sizeof(int) * 2 * 3 * tiles + 16)); CK(hipMemset(a.flag, 0, sizeof(int) * 2 * 3 * tiles + 16));
+    }
     a.ld = C; a.n_rows = n_rows; a.in_slope = in_slope; a.out_slope = out_slope;
     auto kern = cgemm_kernel<C, BN, BM, RT>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS));
-    hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(S::NT), S::LDS, 0, a);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(S::NT), S::LDS, 0, a);
     CK(hipDeviceSynchronize());
     // sampled CPU check
     double maxd = 0; size_t nbad = 0;
@@ -87,16 +98,16 @@ int run(int n_rows, int dil, int use_res) {
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(S::NT), S::LDS, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(S::NT), S::LDS, 0, a);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(S::NT), S::LDS, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(S::NT), S::LDS, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps;
     {
         long long* dbg; CK(hipMalloc(&dbg, 64 * 8)); CK(hipMemset(dbg, 0, 64 * 8));
         a.dbg = dbg;
-        hipLaunchKernelGGL(kern, dim3(3 * tiles), dim3(S::NT), S::LDS, 0, a);
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(S::NT), S::LDS, 0, a);
         CK(hipDeviceSynchronize());
         long long h[64]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
         a.dbg = nullptr;
@@ -106,8 +117,8 @@ int run(int n_rows, int dil, int use_res) {
         printf(" | epilogue %lld | total %lld\n", h[3 + nit] - h[2 + nit], h[3 + nit] - h[0]);
     }
     const double flops = 2.0 * 21 * (double)C * C * n_rows;
-    printf("C=%d BN=%d BM=%d RT=%d n_rows=%d dil=%d res=%d blocks=%d LDS %zu: %.1f us per launch  %.1f TF/s   max |diff| %.3g  bad %zu\n", C, BN, BM, RT, n_rows, dil, use_res,
-           3 * tiles, (size_t)S::LDS, us, flops / us * 1e-6, maxd, nbad);
+    printf("split %d/%d/%d  C=%d BN=%d BM=%d RT=%d n_rows=%d dil=%d res=%d blocks=%d LDS %zu: %.1f us per launch  %.1f TF/s   max |diff| %.3g  bad %zu\n", ns[0], ns[1], ns[2], C, BN, BM, RT, n_rows, dil, use_res,
+           nblocks, (size_t)S::LDS, us, flops / us * 1e-6, maxd, nbad);
     return 0;
 }
 

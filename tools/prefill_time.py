@@ -7,8 +7,8 @@ from gsv_tts_lite_amd.t2s import Text2SemanticDecoder
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda:0")
 cfg = synth.gpt_config()
-m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1)); m.initialize_runtime(torch.bfloat16, dev, [(B, 512), (B, 1024)])
-lens = synth.mixed_lengths(B)
+m = Text2SemanticDecoder(cfg); m.load_state_dict(synth.gpt_weights(cfg, seed=1)); m.initialize_runtime(torch.float32 if os.environ.get("GSV_DTYPE") == "fp32" else torch.bfloat16, dev, [(B, 512), (B, 1024)])
+lens = synth.mixed_lengths(B) if B > 1 else [(60, 100)]      # one prompt: the bench shape (40 + 60 phonemes, 100 prompt tokens)
 rs = [synth.synth_request(i, 40, t, n) for i, (t, n) in enumerate(lens)]
 X = [torch.from_numpy(r[0]).to(dev) for r in rs]; Y = [torch.from_numpy(r[1]).to(dev) for r in rs]; Bt = [torch.from_numpy(r[2]).to(dev) for r in rs]
 with torch.inference_mode():
