@@ -28,6 +28,7 @@ run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --sync-refi
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --lpt-budget --no-cpu-baseline > $O/cb_configs2_lpt_budget.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32.json 2> /dev/null
 GSV_REFILL_AHEAD=0 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32_staged_loop.json 2> /dev/null
+GSV_TAIL_LEVELS=0 run timeout 900 python $R/bench.py --workload cb --version v2Pro --no-cpu-baseline > $O/cb_v2pro_bs32_no_tail_compaction.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --no-cpu-baseline > $O/cb_bf16_bs64.json 2> /dev/null
 run timeout 900 python $R/bench.py --workload cb --version v2ProPlus --slots 64 --dtype fp8 --no-cpu-baseline > $O/cb_fp8_bs64.json 2> /dev/null
 # N > 1 through the bench's own launcher (no torchrun around it): two ranks on this box's one GPU, gloo
@@ -41,6 +42,10 @@ f=$(find /tmp/p2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "
   GSV_PROMPT_TOK=250 timeout 300 python $R/tools/step_time.py 32 bf16 | grep step | sed 's/$/   <- kv 350-450 (GSV_PROMPT_TOK=250): the kv the cb32 slot loop runs at/' ) > $O/step_time.txt 2>&1
 # 5. vocoder: pass times and per-kernel timelines
 timeout 600 python $R/tools/voc_time.py 2>&1 | grep "T=" > $O/voc_time.txt
+GSV_CGEMM_NO_SPLIT=1 timeout 600 python $R/tools/voc_time.py v2ProPlus 2>&1 | grep "T=" | sed 's/$/   <- GSV_CGEMM_NO_SPLIT=1/' >> $O/voc_time.txt
+timeout 300 python $R/tools/voc_gap.py 2>&1 | grep "T=" > $O/voc_gap.txt
+GSV_VOC_DTYPE=fp32 timeout 600 python $R/tools/voc_time.py v2Pro 2>&1 | grep "T=" | sed 's/$/   <- fp32 handle/' >> $O/voc_time.txt
+( timeout 120 python $R/tools/prefill_time.py 1; GSV_DTYPE=fp32 timeout 120 python $R/tools/prefill_time.py 1 | sed 's/$/   <- fp32 handle/'; timeout 120 python $R/tools/prefill_time.py 32 ) 2>&1 | grep rows > $O/prefill_time.txt
 for v in v2Pro v2ProPlus; do
   rm -rf /tmp/pv_$v; timeout 600 rocprofv3 --kernel-trace -d /tmp/pv_$v -- python $R/tools/voc_time.py $v > /dev/null 2>&1
   db=$(find /tmp/pv_$v -name "*.db" | head -1)
@@ -51,5 +56,6 @@ timeout 300 python $R/tools/sample_speed.py 2>&1 | grep token > $O/sample_speed.
 ( echo "arena (default), instances kept alive"; KEEP=1 timeout 300 python $R/tools/placement_ab.py 10 | grep step
   echo "separate allocations (GSV_NO_ARENA=1)"; GSV_NO_ARENA=1 KEEP=1 timeout 300 python $R/tools/placement_ab.py 10 | grep step ) > $O/placement_ab.txt 2>&1
 [ -x $R/tools/rb_bench ] && ( $R/tools/rb_bench 16 5000; $R/tools/rb_bench 32 3000 24; $R/tools/rb_bench 16 320000; $R/tools/rb_bench 32 160000; $R/tools/rb_bench 16 3200000; $R/tools/rb_bench 32 1600000 ) 2>&1 | grep -v stamps > $O/rbfuse_bench.txt
+[ -x $R/tools/cg_bench ] && ( for sp in 1,1,1 2,2,1 3,2,1 3,3,1; do CG_SPLIT=$sp timeout 30 $R/tools/cg_bench 384 5003 5 1 128; done; for sp in 1,1,1 3,2,1; do CG_SPLIT=$sp timeout 30 $R/tools/cg_bench 384 500 5 1 128; done ) 2>&1 | grep -v "block 0" > $O/cgemm_ksplit.txt
 [ -x $R/tools/cg_bench ] && ( for c in 384 256 192 128; do $R/tools/cg_bench $c 5003 5 1 128; done; $R/tools/cg_bench 384 50000 5 1 128; $R/tools/cg_bench 256 50000 5 1 128; $R/tools/cg_bench 192 400000 5 1 128; $R/tools/cg_bench 128 400000 5 1 128 ) 2>&1 | grep -v "block 0" > $O/cgemm_bench.txt
 ls -la $O >&2
