@@ -256,7 +256,8 @@ def test_wdma_pass_equals_the_wconv_pass_bit_for_bit(dev, tmp_path):
     register epilogue) against the path it replaced (wconv.h: rows through registers, leaky-ReLU at staging; GSV_NO_WDMA=1):
     the same arithmetic at the same rounding points, so flow + Generator must return the SAME samples -- at a length that is not
     a multiple of any tile (edge tiles, zero page, sink), at the bench length, and for a ten-utterance batch that hands the
-    256-channel stage to cgemm.  The switch is read once per process: two child processes."""
+    256-channel stage to cgemm.  The switch is read once per process: two child processes.  (Round 6: the shipped library has no
+    wconv.h kernel for 256 channels any more -- GSV_NO_WDMA=1 moves the 64 / 128-channel stages and leaves 256 on wdma.h.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -286,3 +287,57 @@ def test_wdma_pass_equals_the_wconv_pass_bit_for_bit(dev, tmp_path):
         a, b = outs[0][k], outs[1][k]
         assert np.isfinite(a).all() and a.shape == b.shape and np.abs(a).max() > 1e-3, k
         assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
+def test_cgemm_k_split_is_deterministic_replayable_and_close_to_the_unsplit_pass(dev, tmp_path):
+    """csrc/cgemm.h K split (round 6): with few row tiles (v2ProPlus' 384-channel stage at <= 10 s of audio, its 192-channel stage in a
+    streaming chunk) a tile's 64-channel chunks are dealt to consecutive blocks, the partial tiles meet through global memory behind
+    flags.  The hand-off must be invisible: (a) repeated passes return the SAME samples (a stale or early-read partial tile would
+    not), (b) a hipGraph replay of the pass -- the flags reset themselves, no host code runs between replays -- equals the eager
+    pass, replay after replay, (c) the pass with GSV_CGEMM_NO_SPLIT=1 (one block per tile: another fp32 summation order) stays
+    within bf16 rounding noise of it."""
+    import subprocess
+    import sys
+    from gsv_tts_lite_amd.sovits import _VocoderNative
+    hps = synth.sovits_hps("v2ProPlus")
+    w = synth.sovits_weights(hps, seed=23, hot_path_only=True)
+    v = _VocoderNative(hps["model"], {k: torch.from_numpy(a) for k, a in w.items()}, torch.bfloat16, dev)
+    ge = torch.from_numpy(synth.synth_ge(1, 1024, 23)).to(dev)
+    ref = {}
+    for T in (9, 131, 500):
+        z = torch.from_numpy(synth.hashed_uniform("cgs.z%d" % T, (1, 192, T), 23)).to(dev)
+        m = torch.ones(1, 1, T, device=dev)
+        first = v.flow_dec(z, m, ge)
+        assert torch.isfinite(first).all() and float(first.abs().max()) > 1e-3
+        for _ in range(6):
+            assert torch.equal(v.flow_dec(z, m, ge), first), T
+        for _ in range(3):
+            assert torch.equal(v.flow_dec_bucket(z, m, ge), first), T
+        ref[T] = first.cpu().numpy()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from gsv_tts_lite_amd import synth\n"
+        "from gsv_tts_lite_amd.sovits import _VocoderNative\n"
+        "dev = torch.device('cuda:0'); hps = synth.sovits_hps('v2ProPlus')\n"
+        "w = synth.sovits_weights(hps, seed=23, hot_path_only=True)\n"
+        "v = _VocoderNative(hps['model'], {k: torch.from_numpy(a) for k, a in w.items()}, torch.bfloat16, dev)\n"
+        "ge = torch.from_numpy(synth.synth_ge(1, 1024, 23)).to(dev)\n"
+        "out = {}\n"
+        "for T in (9, 131, 500):\n"
+        "    z = torch.from_numpy(synth.hashed_uniform('cgs.z%%d' %% T, (1, 192, T), 23)).to(dev)\n"
+        "    out['t%%d' %% T] = v.flow_dec(z, torch.ones(1, 1, T, device=dev), ge).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % (root, os.path.join(root, "gsv-tts-lite_amd")))
+    f = str(tmp_path / "nosplit.npz")
+    env = dict(os.environ); env["GSV_CGEMM_NO_SPLIT"] = "1"
+    p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    un = np.load(f)
+    differs = False
+    for T in (9, 131, 500):
+        a, b = ref[T], un["t%d" % T]
+        d = np.abs(a - b)
+        assert d.max() < 8e-2 and d.mean() < 8e-3, (T, float(d.max()), float(d.mean()))
+        differs = differs or bool(d.max() > 0)
+    assert differs, "GSV_CGEMM_NO_SPLIT=1 returned the split pass's samples bit for bit: the switch (or the split) is not taken"
