@@ -157,6 +157,11 @@ struct T2SBound {
     T2SStateX st;
     hipGraphExec_t graph = nullptr;       // the captured decode step
     hipGraphExec_t graph_ft = nullptr;    // ... with the token kernel's work in layer 0's attention kernel (GSV_STEP_FUSED_TOKEN)
+    // WINDOWS of 2 .. kMaxWin steps captured as ONE graph each ([fused token][steps]; round 6): between two hipGraphLaunch'es of a one-step
+    // graph the device idles ~8 us (rocprofv3 timeline, tools/step_gaps.py), inside a graph node follows node; a check window of five
+    // steps replayed as one graph pays that once instead of five times
+    static constexpr int kMaxWin = 8;
+    hipGraphExec_t wgraph[2][kMaxWin + 1] = {};
     // staging of a refill that runs on ANOTHER stream while the decode step keeps replaying on the caller's
     // (gsv_t2s_prefill_slots_staged / gsv_t2s_commit_slots): per-slot state the step also writes must not be
     // touched by the prompt pass; it lands here and the commit, ordered on the step's stream, moves it over
@@ -165,6 +170,14 @@ struct T2SBound {
     float *sg_logits = nullptr, *sg_hidden = nullptr;
     TokPart* sg_tok = nullptr;
 };
+
+void t2s_drop_graphs(T2SBound& b) {
+    if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (b.graph_ft) { (void)hipGraphExecDestroy(b.graph_ft); b.graph_ft = nullptr; }
+    for (auto& row : b.wgraph)
+        for (hipGraphExec_t& g : row)
+            if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+}
 
 void t2s_free_staging(T2SBound& b) {
     for (void* p : {(void*)b.sg_kv, (void*)b.sg_x, (void*)b.sg_step, (void*)b.sg_eos, (void*)b.sg_logits, (void*)b.sg_hidden, (void*)b.sg_tok})
@@ -365,10 +378,7 @@ int t2s_ensure_scratch(gsv_t2s* h, int B) {
     HIPCHK(hipMemset(h->tokpart, 0, sizeof(TokPart) * B * kNP));
     h->scratch_b = B;
     // graphs captured against the old scratch pointers are stale
-    for (auto& kv : h->bound)
-        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
-    for (auto& kv : h->bound)
-        if (kv.second.graph_ft) { (void)hipGraphExecDestroy(kv.second.graph_ft); kv.second.graph_ft = nullptr; }
+    for (auto& kv : h->bound) t2s_drop_graphs(kv.second);
     return GSV_OK;
 }
 
@@ -1027,8 +1037,7 @@ int gsv_t2s_destroy(gsv_t2s* h) {
     if (!h) return GSV_OK;
     (void)hipDeviceSynchronize();
     for (auto& kv : h->bound) {
-        if (kv.second.graph) (void)hipGraphExecDestroy(kv.second.graph);
-        if (kv.second.graph_ft) (void)hipGraphExecDestroy(kv.second.graph_ft);
+        t2s_drop_graphs(kv.second);
         t2s_free_staging(kv.second);
     }
     for (T2SLayer& L : h->layers) {
@@ -1099,8 +1108,7 @@ int gsv_t2s_bind_state(gsv_t2s* h, const gsv_t2s_state* st) {
         return fail(GSV_ERR_ARG, "state has null pointers");
     if (int rc = t2s_ensure_scratch(h, st->batch)) return rc;
     T2SBound& b = h->bound[st->batch];
-    if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
-    if (b.graph_ft) { (void)hipGraphExecDestroy(b.graph_ft); b.graph_ft = nullptr; }
+    t2s_drop_graphs(b);
     static_cast<gsv_t2s_state&>(b.st) = *st;
     b.st.eos_host = nullptr;
     t2s_free_staging(b);
@@ -1121,8 +1129,7 @@ int gsv_t2s_unbind_state(gsv_t2s* h, int batch) {
     auto it = h->bound.find(batch);
     if (it == h->bound.end()) return GSV_OK;
     T2SBound& b = it->second;
-    if (b.graph) (void)hipGraphExecDestroy(b.graph);
-    if (b.graph_ft) (void)hipGraphExecDestroy(b.graph_ft);
+    t2s_drop_graphs(b);
     t2s_free_staging(b);
     h->bound.erase(it);
     return GSV_OK;
@@ -1298,19 +1305,34 @@ int gsv_t2s_decode(gsv_t2s* h, int batch, int n_steps, int use_graph, void* stre
             if (int rc = bf ? t2s_step<bf16_t>(h, b->st, S(stream), ft) : t2s_step<float>(h, b->st, S(stream), ft)) return rc;
         return GSV_OK;
     }
-    hipGraphExec_t& exec = ft ? b->graph_ft : b->graph;
-    if (!exec) {
+    // `steps` decode steps captured as one graph (1 = the single-step graph)
+    auto graph_of = [&](int steps, hipGraphExec_t** out) -> int {
+        hipGraphExec_t& exec = steps == 1 ? (ft ? b->graph_ft : b->graph) : b->wgraph[ft ? 1 : 0][steps];
+        *out = &exec;
+        if (exec) return GSV_OK;
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream, ft) : t2s_step<float>(h, b->st, h->cap_stream, ft);
+        int rc = GSV_OK;                      // nothing between Begin and End returns: a stream left capturing is lost to the handle
+        for (int i = 0; i < steps && !rc; ++i) rc = bf ? t2s_step<bf16_t>(h, b->st, h->cap_stream, ft) : t2s_step<float>(h, b->st, h->cap_stream, ft);
         hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
         e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) return fail(GSV_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        return GSV_OK;
+    };
+    static const int win_max = getenv("GSV_STEP_WINDOW") ? std::max(1, std::min((int)T2SBound::kMaxWin, atoi(getenv("GSV_STEP_WINDOW")))) : 5;   // steps per graph (A/B: 1)
+    int left = n_steps;
+    while (left > 0) {
+        // whole windows of `win_max` steps, then the remainder as one smaller window: a step's kernels read every position from the
+        // state, so a captured window serves any kv
+        const int w = std::min(left, win_max);
+        hipGraphExec_t* exec = nullptr;
+        if (int rc = graph_of(w, &exec)) return rc;
+        HIPCHK(hipGraphLaunch(*exec, S(stream)));
+        left -= w;
     }
-    for (int i = 0; i < n_steps; ++i) HIPCHK(hipGraphLaunch(exec, S(stream)));
     return GSV_OK;
 }
 
@@ -1328,8 +1350,7 @@ int gsv_t2s_set_eos_mirror(gsv_t2s* h, int batch, int32_t* host_mapped) {
     if (!b) return fail(GSV_ERR_STATE, "no state bound for batch %d", batch);
     b->st.eos_host = host_mapped;
     // the captured steps hold their kernel arguments by value
-    if (b->graph) { (void)hipGraphExecDestroy(b->graph); b->graph = nullptr; }
-    if (b->graph_ft) { (void)hipGraphExecDestroy(b->graph_ft); b->graph_ft = nullptr; }
+    t2s_drop_graphs(*b);
     return GSV_OK;
 }
 
@@ -1346,10 +1367,7 @@ size_t gsv_t2s_device_bytes(gsv_t2s* h) {
 int gsv_t2s_set_debug(gsv_t2s* h, void* buf) {
     if (!h) return fail(GSV_ERR_ARG, "null handle");
     h->dbg = (unsigned long long*)buf;
-    for (auto& kv : h->bound)
-        if (kv.second.graph) { (void)hipGraphExecDestroy(kv.second.graph); kv.second.graph = nullptr; }
-    for (auto& kv : h->bound)
-        if (kv.second.graph_ft) { (void)hipGraphExecDestroy(kv.second.graph_ft); kv.second.graph_ft = nullptr; }
+    for (auto& kv : h->bound) t2s_drop_graphs(kv.second);
     return GSV_OK;
 }
 
