@@ -167,7 +167,11 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
     // blocks per CU measured 40.9 us vs 48.8 us for the 32-row tile (tools/tg_bench.hip)
     const bool mid_n = !splitk && !wide_m && !wide_n && (long)cdiv(n_rows, 256) * pc.mtiles * nz >= 256;
     const int bn = splitk ? 32 : ((wide_n || mid_n) ? 256 : 128);
-    const int kcb = (wide_n || mid_n) ? 128 : 256;    // staged bytes per row per chunk
+    // staged bytes per row per chunk.  The split-K tile of an fp32 conv (the parity mode's prompt pass: 97 launches per prompt) stages 256 channels
+    // per chunk instead of 64: a chunk is one dependent load -> LDS -> MFMA round trip with two k-steps per wave at 64 channels, and a K = 512 /
+    // 2048 contraction paid 8 / 32 of them (21-74 us per launch, 4.3 ms per prompt; round 6).  Row-count independent like every split-K tile.
+    constexpr int kcb_splitk = sizeof(CT) == 4 ? 1024 : 256;
+    const int kcb = splitk ? kcb_splitk : ((wide_n || mid_n) ? 128 : 256);
     size_t lds = (size_t)(bn + span) * (kcb + 16);
     if (splitk) lds = std::max(lds, (size_t)3 * 16 * 64 * sizeof(float));
     if (lds > 160 * 1024) return fail(GSV_ERR_ARG, "tapgemm: tap span %d needs %zu B of LDS", span, lds);
@@ -178,7 +182,7 @@ int run_conv_multi(const Branch* brs, int nbr, int ldx, int n_in, int ldy, int n
         return GSV_OK;
     };
     int rc;
-    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, 256, true>, dim3(cdiv(n_rows, 32), pc.mtiles, nz));
+    if (splitk) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 1, kcb_splitk, true>, dim3(cdiv(n_rows, 32), pc.mtiles, nz));
     else if (wide_m && wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 2, 128, false>, dim3(cdiv(n_rows, 256), cdiv(pc.mtiles, 2), nz));
     else if (wide_m) rc = launch(tapgemm_kernel<IT, CT, OT, 2, 1, 256, false>, dim3(cdiv(n_rows, 128), cdiv(pc.mtiles, 2), nz));
     else if (wide_n) rc = launch(tapgemm_kernel<IT, CT, OT, 1, 2, 128, false>, dim3(cdiv(n_rows, 256), pc.mtiles, nz));
