@@ -343,7 +343,9 @@ static __global__ __launch_bounds__(256, OCC) void tapgemm_kernel(TapGemmArgs a)
                 // Weight fragments come from L2 (~500+ cycles) and a block holds only 1-2 waves per SIMD, so
                 // they are fetched a whole GROUP of PF iterations ahead: PF loads in flight cover PF
                 // iterations of LDS reads + MFMAs.  Two cursors walk (tap, k-step): load and compute.
-                constexpr int PF = SPLITK ? 2 : (WM == 1 ? 8 : 4);
+                // split-K: every k-step a wave owns in a chunk is requested at once (2 at 128 bf16 channels per chunk; 8 at the fp32 tile's 256: with two in
+                // flight that chunk was four dependent L2 round trips, round 6) -- a prefetch depth, not an order: results are unchanged
+                constexpr int PF = SPLITK ? ((KC / KS / 4) >= 8 ? 8 : 2) : (WM == 1 ? 8 : 4);
                 int tl = 0, ksl = SPLITK ? wid : 0;          // load cursor
                 while (ksl >= kst) { ksl -= kst; ++tl; }
                 int tc = tl, ksc = ksl;                      // compute cursor
