@@ -76,7 +76,7 @@ class Text2SemanticDecoder:
         self.refill_wait = int(os.environ.get("GSV_REFILL_WAIT", "1"))     # ... for at most this many windows
         self.refill_priority = int(os.environ.get("GSV_REFILL_PRIO", "0")) # stream priority of the prompt passes' side stream
         self.step_priority = int(os.environ.get("GSV_STEP_PRIO", "0"))     # ... and of the stream the slot loop's steps run on
-        self.refill_ahead = int(os.environ.get("GSV_REFILL_AHEAD", "8"))   # async_refill: requests prefilled AHEAD of the slots that will run them (0: the park / prompt pass / commit loop)
+        self.refill_ahead = int(os.environ.get("GSV_REFILL_AHEAD", "32"))  # async_refill: requests prefilled AHEAD of the slots that will run them, at most one per slot (0: the park / prompt pass / commit loop)
         # continuous batching, queue empty: the live requests move to a smaller bound state when they fit one of these sizes (0 / empty: off)
         self.tail_levels = [int(v) for v in os.environ.get("GSV_TAIL_LEVELS", "16,8,4").split(",") if v.strip() and int(v) > 0]
         self.use_graph = True
